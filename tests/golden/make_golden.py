@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (imported from
+/root/reference, unmodified source) on CPU.  Runs only in the build container —
+the reference never travels to the GPU box; the .npz files written next to this
+script do.
+
+What is patched to make the reference executable here:
+  * 14 absent leaf modules (torchvision, librosa, tensorboardX, ...) are stubbed
+    with MagicMock; none is touched by forward / loss / step;
+  * torch.Tensor.cuda := identity (disentangled_vae.py:224 calls .cuda() on eps);
+  * ConvolutionalMulVAE is constructed with device=cpu;
+  * for T != 64 the two frame-count-dependent layers are replaced by same-typed
+    layers of size T*128 (the literal 8192 at disentangled_vae.py:165,171) and
+    Adam is rebuilt over the new parameter list.
+Weights come from oracle/fill.py (deterministic by state_dict key), inputs from
+seeded NumPy streams, the three eps tensors from torch.manual_seed(seed) drawn in
+the reference's own order — they are recorded in the fixture.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+for name in ["torchvision", "torchvision.utils", "torchvision.transforms", "mpl_toolkits.axes_grid1",
+             "librosa", "librosa.display", "soundfile", "tensorboardX", "wavenet_vocoder", "pyworld",
+             "pysptk", "lws", "preprocessing.processing", "preprocessing.WORLD_processing"]:
+    sys.modules[name] = MagicMock()
+
+import torch  # noqa: E402
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+
+from model.disentangled_vae import ConvolutionalMulVAE, LinearNorm, init_weights  # noqa: E402
+from oracle.fill import fill_state_dict, synthetic_pair  # noqa: E402
+
+CASES = [
+    # name, B, T, data seed, eps seed
+    ("c0_b4_t64", 4, 64, 1234, 7),
+    ("b3_t64", 3, 64, 4321, 11),
+    ("b2_t128", 2, 128, 1234, 13),
+]
+
+
+def build(batch, n_frames, lr=1e-4):
+    w = ConvolutionalMulVAE("VCTK", 64, 80, 32, lr, 0.01, 500, False, batch_size=batch,
+                            speaker_size=4, device=torch.device("cpu"), latent_dim=32,
+                            mse_cof=10, kl_cof=10)
+    if n_frames != 64:
+        m = w.model
+        m.enc_linear = LinearNorm(n_frames * 128, 2048)
+        m.dec_pre_linear2 = torch.nn.Linear(2048, n_frames * 128)
+        m.apply(init_weights)
+        w.optimizer = torch.optim.Adam(m.parameters(), lr=lr)
+    w.model.load_state_dict(fill_state_dict(w.model.state_dict()))
+    w.model.train()
+    return w
+
+
+def run_case(name, batch, n_frames, seed, eps_seed):
+    torch.set_num_threads(8)
+    w = build(batch, n_frames)
+    x1, x2 = synthetic_pair(batch, n_frames, seed)
+
+    # the three draws of _reparameterize, in call order (disentangled_vae.py:252,255,261)
+    torch.manual_seed(eps_seed)
+    eps = [torch.empty(batch, 28).normal_(), torch.empty(batch, 28).normal_(), torch.empty(batch, 4).normal_()]
+
+    out = {"batch": batch, "n_frames": n_frames, "seed": seed, "eps_seed": eps_seed,
+           "eps_c1": eps[0].numpy(), "eps_c2": eps[1].numpy(), "eps_s": eps[2].numpy()}
+
+    # (1) forward + loss + backward, no optimiser step: outputs and gradients
+    torch.manual_seed(eps_seed)
+    fw = w.model(x1, x2)
+    losses = w.loss_functionGVAE2(x1, x2, *fw, train=True)
+    w.optimizer.zero_grad()
+    losses[0].backward()
+    out["losses_fwd"] = np.array([float(v.detach()) for v in losses], dtype=np.float64)
+    fw_names = ["recons_x1", "recons_x2", "recons_x1_hat", "recons_x2_hat", "q_z1_mu", "q_z1_logvar",
+                "q_z2_mu", "q_z2_logvar", "z_style_mu", "z_style_logvar"]
+    for n, t in zip(fw_names, fw):
+        t = t.detach()
+        if t.numel() <= 4096:
+            out["fw_" + n] = t.numpy()
+        else:
+            out["fw_" + n + "_sum"] = np.float64(t.double().sum())
+            out["fw_" + n + "_abs"] = np.float64(t.double().abs().sum())
+            out["fw_" + n + "_slice"] = t[:, ::16, ::8].contiguous().numpy()
+    names = [n for n, _ in w.model.named_parameters()]
+    out["param_names"] = np.array(names)
+    out["grad_norm"] = np.array([float(p.grad.double().norm()) for _, p in w.model.named_parameters()])
+    out["grad_absmax"] = np.array([float(p.grad.abs().max()) for _, p in w.model.named_parameters()])
+    # a few full small gradients
+    sd_g = dict(w.model.named_parameters())
+    for k in ["style.linear_layer.weight", "content.linear_layer.bias", "dec_linear2.linear_layer.bias",
+              "enc_modules.0.1.weight", "enc_modules.0.1.bias", "postnet.convolutions.4.1.weight",
+              "dec_modules.2.1.bias", "enc_lstm.bias_ih_l0_reverse", "dec_lstm2.bias_hh_l1"]:
+        out["g_" + k] = sd_g[k].grad.detach().numpy().copy()
+    # BatchNorm running statistics after this one forward (two updates each)
+    for k, v in w.model.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"):
+            out["bn_" + k] = v.detach().numpy().copy()
+
+    # (2) a fresh model: the reference's own step() twice (zero_grad, fwd, loss, bwd, Adam, 8x .item())
+    w2 = build(batch, n_frames)
+    torch.manual_seed(eps_seed)
+    s1 = w2.step(x1, x2, None, train=True)
+    # eps of the second step: next draws of the same stream
+    st = torch.get_rng_state()
+    eps2 = [torch.empty(batch, 28).normal_(), torch.empty(batch, 28).normal_(), torch.empty(batch, 4).normal_()]
+    torch.set_rng_state(st)
+    s2 = w2.step(x2, x1, None, train=True)
+    out["step1"] = np.array(s1, dtype=np.float64)
+    out["step2"] = np.array(s2, dtype=np.float64)
+    out["eps2_c1"], out["eps2_c2"], out["eps2_s"] = (e.numpy() for e in eps2)
+    out["param_norm_after2"] = np.array([float(p.detach().double().norm()) for _, p in w2.model.named_parameters()])
+    assert np.allclose(out["step1"], out["losses_fwd"], rtol=1e-6), (out["step1"], out["losses_fwd"])
+
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print(name, "losses", out["step1"], "step2", out["step2"][0])
+
+
+if __name__ == "__main__":
+    for c in CASES:
+        run_case(*c)

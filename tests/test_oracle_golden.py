@@ -1,0 +1,86 @@
+"""Pins the oracle (oracle/dvae_ref.py) against vectors produced by running the real
+reference (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.dvae_ref import RefTrainer, loss_gvae2
+from oracle.fill import fill_state_dict, synthetic_pair
+
+CASES = ["c0_b4_t64", "b3_t64", "b2_t128"]
+FW = ["recons_x1", "recons_x2", "recons_x1_hat", "recons_x2_hat", "q_z1_mu", "q_z1_logvar",
+      "q_z2_mu", "q_z2_logvar", "z_style_mu", "z_style_logvar"]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def _trainer(g):
+    tr = RefTrainer(int(g["batch"]), n_frames=int(g["n_frames"]))
+    tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
+    tr.model.train()
+    return tr
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_state_dict_keys_match_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    tr = _trainer(g)
+    assert [n for n, _ in tr.model.named_parameters()] == list(g["param_names"])
+    assert len(list(g["param_names"])) == 84
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_loss_grads(golden_dir, name):
+    g = _load(golden_dir, name)
+    tr = _trainer(g)
+    B, T = int(g["batch"]), int(g["n_frames"])
+    x1, x2 = synthetic_pair(B, T, int(g["seed"]))
+    eps = tuple(torch.from_numpy(g[k]) for k in ("eps_c1", "eps_c2", "eps_s"))
+    outs = tr.model(x1, x2, eps)
+    losses = loss_gvae2(x1, x2, outs, B)
+    got = np.array([float(v.detach()) for v in losses])
+    np.testing.assert_allclose(got, g["losses_fwd"], rtol=2e-6)
+    for n, t in zip(FW, outs):
+        t = t.detach()
+        if "fw_" + n in g.files:
+            np.testing.assert_allclose(t.numpy(), g["fw_" + n], rtol=1e-4, atol=1e-5)
+        else:
+            np.testing.assert_allclose(float(t.double().abs().sum()), float(g["fw_" + n + "_abs"]), rtol=1e-5)
+            np.testing.assert_allclose(t[:, ::16, ::8].numpy(), g["fw_" + n + "_slice"], rtol=1e-3, atol=1e-4)
+    losses[0].backward()
+    gn = np.array([float(p.grad.double().norm()) for _, p in tr.model.named_parameters()])
+    ref = g["grad_norm"]
+    # conv biases in front of a training-mode BatchNorm have a mathematically zero gradient
+    # (pure round-off in the reference): compare those on an absolute scale only.
+    big = ref > 1e-3
+    np.testing.assert_allclose(gn[big], ref[big], rtol=2e-3)
+    assert np.all(gn[~big] < 1e-2)
+    for k in g.files:
+        if k.startswith("g_"):
+            p = dict(tr.model.named_parameters())[k[2:]]
+            scale = max(1e-6, float(np.abs(g[k]).max()))
+            assert float(np.abs(p.grad.numpy() - g[k]).max()) <= 2e-3 * scale, k
+        if k.startswith("bn_"):
+            v = tr.model.state_dict()[k[3:]].numpy()
+            np.testing.assert_allclose(v, g[k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_two_train_steps(golden_dir, name):
+    g = _load(golden_dir, name)
+    tr = _trainer(g)
+    B, T = int(g["batch"]), int(g["n_frames"])
+    x1, x2 = synthetic_pair(B, T, int(g["seed"]))
+    eps1 = tuple(torch.from_numpy(g[k]) for k in ("eps_c1", "eps_c2", "eps_s"))
+    eps2 = tuple(torch.from_numpy(g[k]) for k in ("eps2_c1", "eps2_c2", "eps2_s"))
+    s1 = tr.step(x1, x2, eps1, train=True)
+    s2 = tr.step(x2, x1, eps2, train=True)
+    np.testing.assert_allclose(np.array(s1), g["step1"], rtol=2e-6)
+    # after one Adam step (|update| = lr per weight, sign-driven) allow a looser match
+    np.testing.assert_allclose(np.array(s2), g["step2"], rtol=2e-4)
+    pn = np.array([float(p.detach().double().norm()) for _, p in tr.model.named_parameters()])
+    np.testing.assert_allclose(pn, g["param_norm_after2"], rtol=1e-3, atol=2e-3)
