@@ -1,0 +1,109 @@
+"""ctypes binding of libdvae_hip.so (C ABI declared in include/dvae_hip.h).
+
+The library is the product: if it is missing or a call fails, this module raises —
+there is no PyTorch/CPU fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch  # noqa: F401  (loads torch's bundled libamdhip64.so.7 first, so ours binds to the same runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdvae_hip.so")
+_lib = None
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class LstmDir(C.Structure):
+    """dvae_lstm_dir_t"""
+    _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
+                ("dgates", vp), ("dc_ws", vp), ("reverse", i32), ("pad_", i32)]
+
+
+# name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
+SIGNATURES = {
+    "dvae_version": (i32, []),
+    "dvae_last_hip_error": (i32, []),
+    "dvae_gemm_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv5_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "dvae_conv5_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "dvae_conv5_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv_pack_w": (i32, [vp, vp, i32, i32, vp]),
+    "dvae_conv_unpack_add_w": (i32, [vp, vp, i32, i32, vp]),
+    "dvae_bn_ws_bytes": (i64, [i32, i32, i32]),
+    "dvae_bn_stats_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
+    "dvae_bn_apply_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_lstm_seq_fwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
+    "dvae_lstm_seq_bwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
+    "dvae_latent_fwd": (i32, [vp] * 9 + [i32, i32, i32, vp]),
+    "dvae_latent_bwd": (i32, [vp] * 11 + [i32, i32, i32, vp]),
+    "dvae_kl_fwd": (i32, [vp, vp, vp, i64, f32, vp]),
+    "dvae_kl_bwd": (i32, [vp, vp, vp, vp, vp, i64, f32, vp]),
+    "dvae_l1_ws_bytes": (i64, [i64]),
+    "dvae_l1_sum_fwd": (i32, [vp, vp, vp, vp, i64, f32, vp]),
+    "dvae_l1_sum_bwd": (i32, [vp, vp, vp, vp, i64, f32, vp]),
+    "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "dvae_frames_to_mel": (i32, [vp, vp, i32, i32, i32, vp]),
+    "dvae_permute_102": (i32, [vp, vp, i32, i32, i32, vp]),
+    "dvae_colsum_add": (i32, [vp, vp, vp, i32, i32, i64, vp]),
+    "dvae_transpose": (i32, [vp, vp, i32, i32, vp]),
+    "dvae_act_fwd": (i32, [vp, i64, i32, vp]),
+    "dvae_act_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "dvae_prof_enable": (i32, [i32]),
+    "dvae_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into libdvae_hip.so (in-tree)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
+            if f.endswith((".hip", ".h"))]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")])
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is the product path and there is no fallback. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc).")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+class DvaeHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        err = lib().dvae_last_hip_error() if rc == -2 else 0
+        raise DvaeHipError(f"{what} failed: rc={rc} hipError={err}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must be contiguous fp32 unless noted."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,248 @@
+// Training-mode BatchNorm1d (+ReLU/tanh, + residual) on frame-major [R, C] data, forward and backward.
+// HBM/L2-bound passes: 16-byte vector accesses along the channel axis, per-thread fp64 partial sums
+// (the only place the path leaves fp32: it makes the one-pass E[y^2]-E[y]^2 variance exact enough
+// to match a two-pass fp32 reference), wavefront-free cross-row reduction through LDS, deterministic
+// two-stage reduction (partials -> finalize) instead of atomics.
+//
+// Group semantics: row r belongs to segment n = r % N and group g = n / (N/G).  The reference calls
+// encode()/decode()/postnet() once per utterance of the pair, so each call has its own batch statistics
+// and updates the running statistics once: G = 2 here reproduces that, in call order.
+#include "common.h"
+
+namespace {
+
+constexpr int ROWS_PER_CHUNK = 256;
+
+__host__ __device__ inline int n_chunks(int R) { return (R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK; }
+
+// partial[chunk][g][c][2] (fp64): sum and sum of squares (MODE 0), or sum(dU) and sum(dU*yhat) (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ Y, const float* __restrict__ dZ,
+                                                         const float* __restrict__ Z, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, double* __restrict__ part,
+                                                         int R, int N, int C, int G, int act) {
+  // block: 64 channel lanes x 4 row lanes ; grid: (ceil(C/64), chunks)
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * ROWS_PER_CHUNK;
+  const int r1 = min(R, r0 + ROWS_PER_CHUNK);
+  const int per = N / G;
+  double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+  if (c < C) {
+    float mu0 = 0.f, mu1 = 0.f, rs0 = 1.f, rs1 = 1.f;
+    if (MODE == 1) {
+      mu0 = mean[c];
+      rs0 = rstd[c];
+      if (G > 1) {
+        mu1 = mean[C + c];
+        rs1 = rstd[C + c];
+      }
+    }
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const int g = (r % N) / per;
+      const float y = Y[(int64_t)r * C + c];
+      double v0, v1;
+      if (MODE == 0) {
+        v0 = (double)y;
+        v1 = (double)y * (double)y;
+      } else {
+        const float du = dZ[(int64_t)r * C + c] * act_grad_from_out(Z[(int64_t)r * C + c], act);
+        const float yh = (y - (g ? mu1 : mu0)) * (g ? rs1 : rs0);
+        v0 = (double)du;
+        v1 = (double)du * (double)yh;
+      }
+      if (g == 0) {
+        s00 += v0;
+        s01 += v1;
+      } else {
+        s10 += v0;
+        s11 += v1;
+      }
+    }
+  }
+  __shared__ double red[4][64][4];
+  red[rl][cl][0] = s00;
+  red[rl][cl][1] = s01;
+  red[rl][cl][2] = s10;
+  red[rl][cl][3] = s11;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    double o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
+    for (int g = 0; g < G; ++g) {
+      double* p = part + (((int64_t)blockIdx.y * G + g) * C + c) * 2;
+      p[0] = o[2 * g];
+      p[1] = o[2 * g + 1];
+    }
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, float* __restrict__ mean,
+                                         float* __restrict__ rstd, float* __restrict__ rmean,
+                                         float* __restrict__ rvar, int64_t* __restrict__ nbt, int chunks, int R,
+                                         int N, int C, int G, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += G;
+  if (c >= C) return;
+  const double cnt = (double)(R / N) * (double)(N / G);
+  float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+      const double* p = part + (((int64_t)k * G + g) * C + c) * 2;
+      s += p[0];
+      q += p[1];
+    }
+    const double m = s / cnt;
+    double var = q / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[g * C + c] = (float)m;
+    rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float unb = (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+    rm = (1.f - momentum) * rm + momentum * (float)m;
+    rv = (1.f - momentum) * rv + momentum * unb;
+  }
+  if (rmean) rmean[c] = rm;
+  if (rvar) rvar[c] = rv;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res,
+                                                       float* __restrict__ Z, int64_t total4, int N, int C, int G,
+                                                       int act) {
+  const int c4n = C >> 2;
+  const int per = N / G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const int g = (int)(r % N) / per;
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + i * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + g * C + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) z[k] = act_apply((y[k] - mu[k]) * rs[k] * ga[k] + be[k], act);
+    if (res) {
+      const f32x4 rr = *reinterpret_cast<const f32x4*>(res + i * 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) z[k] += rr[k];
+    }
+    *reinterpret_cast<f32x4*>(Z + i * 4) = z;
+  }
+}
+
+// s12[g][c][2] = (sum dU, sum dU*yhat) as float; dgamma += sum_g s2 ; dbeta += sum_g s1
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ s12,
+                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int chunks, int C,
+                                       int G) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+      const double* p = part + (((int64_t)k * G + g) * C + c) * 2;
+      s += p[0];
+      q += p[1];
+    }
+    s12[(g * C + c) * 2] = (float)s;
+    s12[(g * C + c) * 2 + 1] = (float)q;
+    tb += s;
+    tg += q;
+  }
+  if (dgamma) dgamma[c] += (float)tg;
+  if (dbeta) dbeta[c] += (float)tb;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dZ, const float* __restrict__ Y,
+                                                           const float* __restrict__ Z, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ s12, float* dY,
+                                                           int64_t total4, int R, int N, int C, int G, int act) {
+  const int c4n = C >> 2;
+  const int per = N / G;
+  const float inv_cnt = 1.f / ((float)(R / N) * (float)per);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const int g = (int)(r % N) / per;
+    const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + i * 4);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + i * 4);
+    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + i * 4);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + g * C + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float du = dz[k] * act_grad_from_out(z[k], act);
+      const float yh = (y[k] - mu[k]) * rs[k];
+      const float s1 = s12[(g * C + c + k) * 2], s2 = s12[(g * C + c + k) * 2 + 1];
+      o[k] = ga[k] * rs[k] * (du - s1 * inv_cnt - yh * s2 * inv_cnt);
+    }
+    *reinterpret_cast<f32x4*>(dY + i * 4) = o;
+  }
+}
+
+int check(int R, int N, int C, int G) {
+  if (R <= 0 || N <= 0 || C <= 0 || G < 1 || G > 2) return DVAE_EINVAL;
+  if ((R % N) || (N % G) || (C & 3)) return DVAE_EINVAL;
+  return DVAE_OK;
+}
+
+}  // namespace
+
+DVAE_API int64_t dvae_bn_ws_bytes(int R, int C, int G) {
+  // partials + s12
+  return (int64_t)n_chunks(R) * G * C * 2 * sizeof(double) + (int64_t)G * C * 2 * sizeof(float) + 64;
+}
+
+DVAE_API int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* running_mean, float* running_var,
+                               int64_t* num_batches_tracked, void* ws, int R, int N, int C, int G, float eps,
+                               float momentum, void* stream) {
+  if (check(R, N, C, G) || !Y || !mean || !rstd || !ws) return DVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = n_chunks(R);
+  double* part = (double*)ws;
+  dim3 grid((C + 63) / 64, ch);
+  hipLaunchKernelGGL((bn_partial_kernel<0>), grid, dim3(256), 0, s, Y, nullptr, nullptr, nullptr, nullptr, part, R, N,
+                     C, G, 0);
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, mean, rstd,
+                     running_mean, running_var, num_batches_tracked, ch, R, N, C, G, eps, momentum);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const float* residual, float* Z, int R, int N, int C, int G, int act,
+                               void* stream) {
+  if (check(R, N, C, G) || !Y || !mean || !rstd || !gamma || !beta || !Z) return DVAE_EINVAL;
+  const int64_t total4 = (int64_t)R * C / 4;
+  const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, mean, rstd, gamma, beta,
+                     residual, Z, total4, N, C, G, act);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const float* mean, const float* rstd,
+                         const float* gamma, float* dY, float* dgamma, float* dbeta, void* ws, int R, int N, int C,
+                         int G, int act, void* stream) {
+  if (check(R, N, C, G) || !dZ || !Y || !Z || !mean || !rstd || !gamma || !dY || !ws) return DVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int ch = n_chunks(R);
+  double* part = (double*)ws;
+  float* s12 = (float*)((char*)ws + (int64_t)ch * G * C * 2 * sizeof(double));
+  dim3 grid((C + 63) / 64, ch);
+  hipLaunchKernelGGL((bn_partial_kernel<1>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, s12, dgamma, dbeta, ch, C,
+                     G);
+  const int64_t total4 = (int64_t)R * C / 4;
+  const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, dZ, Y, Z, mean, rstd, gamma, s12, dY, total4,
+                     R, N, C, G, act);
+  return dvae_check_launch();
+}

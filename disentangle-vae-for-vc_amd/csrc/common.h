@@ -1,0 +1,63 @@
+// Shared helpers for the gfx950 kernels of libdvae_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dvae_hip.h"
+
+#define DVAE_API extern "C" __attribute__((visibility("default")))
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+extern int g_dvae_last_hip_error;
+
+static inline int dvae_check_launch() {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    g_dvae_last_hip_error = (int)e;
+    return DVAE_ELAUNCH;
+  }
+  return DVAE_OK;
+}
+
+// ---- profiling hooks (prof.cpp) ----
+void dvae_prof_begin(int family, hipStream_t s, double flops);
+void dvae_prof_end(int family, hipStream_t s);
+extern int g_dvae_prof_family;
+
+struct ProfScope {
+  int fam;
+  hipStream_t s;
+  bool on;
+  ProfScope(int family, hipStream_t st, double flops) : fam(family), s(st) {
+    on = (g_dvae_prof_family == family);
+    if (on) dvae_prof_begin(family, s, flops);
+  }
+  ~ProfScope() {
+    if (on) dvae_prof_end(fam, s);
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ float act_apply(float u, int act) {
+  if (act == DVAE_ACT_RELU) return u > 0.f ? u : 0.f;
+  if (act == DVAE_ACT_TANH) return tanhf(u);
+  return u;
+}
+// derivative of the activation expressed through its OUTPUT z
+__device__ __forceinline__ float act_grad_from_out(float z, int act) {
+  if (act == DVAE_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == DVAE_ACT_TANH) return 1.f - z * z;
+  return 1.f;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }

@@ -1,0 +1,431 @@
+// The HBM-bound and tiny kernels of the step: reparameterise + latent assembly, KL and L1 reductions
+// (wavefront shuffle reductions, fp64 only for the final cross-workgroup sums), flat Adam, layout changes.
+#include "common.h"
+
+int g_dvae_last_hip_error = 0;
+
+DVAE_API int dvae_version(void) { return 100; }
+DVAE_API int dvae_last_hip_error(void) { return g_dvae_last_hip_error; }
+
+namespace {
+
+// ------------------------------------------------------------------ latent
+__global__ void latent_fwd_kernel(const float* __restrict__ style, const float* __restrict__ content,
+                                  const float* __restrict__ eps_c, const float* __restrict__ eps_s,
+                                  float* __restrict__ z, float* __restrict__ q_mu, float* __restrict__ q_lv,
+                                  float* __restrict__ s_mu, float* __restrict__ s_lv, int Bh, int S, int Cn) {
+  const int D = S + Cn;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * Bh * D) return;
+  const int n = idx / D, dcol = idx - n * D;
+  const int b = n % Bh;
+  if (dcol < S) {
+    const float mu = 0.5f * (style[b * 2 * S + dcol] + style[(Bh + b) * 2 * S + dcol]);
+    const float lv = 0.5f * (style[b * 2 * S + S + dcol] + style[(Bh + b) * 2 * S + S + dcol]);
+    q_mu[idx] = mu;
+    q_lv[idx] = lv;
+    z[idx] = eps_s[b * S + dcol] * expf(0.5f * lv) + mu;
+    if (n < Bh) {
+      s_mu[b * S + dcol] = mu;
+      s_lv[b * S + dcol] = lv;
+    }
+  } else {
+    const int k = dcol - S;
+    const float mu = content[n * 2 * Cn + k];
+    const float lv = content[n * 2 * Cn + Cn + k];
+    q_mu[idx] = mu;
+    q_lv[idx] = lv;
+    z[idx] = eps_c ? eps_c[n * Cn + k] * expf(0.5f * lv) + mu : mu;
+  }
+}
+
+__global__ void latent_bwd_kernel(const float* __restrict__ style, const float* __restrict__ content,
+                                  const float* __restrict__ eps_c, const float* __restrict__ eps_s,
+                                  const float* __restrict__ dz, const float* __restrict__ dq_mu,
+                                  const float* __restrict__ dq_lv, const float* __restrict__ ds_mu,
+                                  const float* __restrict__ ds_lv, float* __restrict__ dstyle,
+                                  float* __restrict__ dcontent, int Bh, int S, int Cn) {
+  const int D = S + Cn;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 2 * Bh * D) return;
+  const int n = idx / D, dcol = idx - n * D;
+  const int b = n % Bh;
+  auto ld = [](const float* p, int i) { return p ? p[i] : 0.f; };
+  if (dcol < S) {
+    if (n >= Bh) {  // x2's style head is detached (disentangled_vae.py:257-258)
+      dstyle[n * 2 * S + dcol] = 0.f;
+      dstyle[n * 2 * S + S + dcol] = 0.f;
+      return;
+    }
+    const int i1 = b * D + dcol, i2 = (Bh + b) * D + dcol;
+    const float lv = 0.5f * (style[b * 2 * S + S + dcol] + style[(Bh + b) * 2 * S + S + dcol]);
+    const float gz = ld(dz, i1) + ld(dz, i2);
+    const float gmu = gz + ld(dq_mu, i1) + ld(dq_mu, i2) + ld(ds_mu, b * S + dcol);
+    const float glv = gz * eps_s[b * S + dcol] * 0.5f * expf(0.5f * lv) + ld(dq_lv, i1) + ld(dq_lv, i2) +
+                      ld(ds_lv, b * S + dcol);
+    dstyle[b * 2 * S + dcol] = 0.5f * gmu;
+    dstyle[b * 2 * S + S + dcol] = 0.5f * glv;
+  } else {
+    const int k = dcol - S;
+    const float lv = content[n * 2 * Cn + Cn + k];
+    const float gz = ld(dz, idx);
+    dcontent[n * 2 * Cn + k] = gz + ld(dq_mu, idx);
+    dcontent[n * 2 * Cn + Cn + k] =
+        (eps_c ? gz * eps_c[n * Cn + k] * 0.5f * expf(0.5f * lv) : 0.f) + ld(dq_lv, idx);
+  }
+}
+
+// ------------------------------------------------------------------ KL
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                     float* __restrict__ out, int64_t n, float scale) {
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const float m = mu[i], l = lv[i];
+    acc += (double)(1.f + l - m * m - expf(l));
+  }
+  acc = wave_sum_d(acc);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) * (double)scale);
+}
+
+__global__ void kl_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                              const float* __restrict__ gout, float* __restrict__ dmu, float* __restrict__ dlv,
+                              int64_t n, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = gout[0] * scale;
+  dmu[i] = g * (-2.f * mu[i]);
+  dlv[i] = g * (1.f - expf(lv[i]));
+}
+
+// ------------------------------------------------------------------ L1
+constexpr int L1_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         double* __restrict__ part, int64_t n) {
+  const int64_t n4 = n >> 2;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + 4 * i);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(y + 4 * i);
+    acc += fabsf(a[0] - b[0]) + fabsf(a[1] - b[1]) + fabsf(a[2] - b[2]) + fabsf(a[3] - b[3]);
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += fabsf(x[i] - y[i]);
+  double d = wave_sum_d((double)acc);
+  __shared__ double red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(64) void l1_final_kernel(const double* __restrict__ part, float* __restrict__ out,
+                                                      int nparts, float scale) {
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 64) a += part[i];
+  a = wave_sum_d(a);
+  if (threadIdx.x == 0) out[0] = (float)(a * (double)scale);
+}
+
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     const float* __restrict__ gout, float* __restrict__ dy,
+                                                     int64_t n, float scale) {
+  const float g = gout[0] * scale;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = x[i] - y[i];
+    dy[i] = d > 0.f ? -g : (d < 0.f ? g : 0.f);
+  }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                   float b1, float b2, float eps, float gs, float bc1, float bc2s) {
+  // torch.optim.Adam (no amsgrad, no weight decay):
+  //   m += (g-m)(1-b1) ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+  const int64_t n4 = n >> 2;
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + 4 * i);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + 4 * i);
+    f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gs;
+      mm[k] = mm[k] + (gr - mm[k]) * (1.f - b1);
+      vv[k] = vv[k] * b2 + (1.f - b2) * gr * gr;
+      pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) / bc2s + eps));
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+    *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+  }
+  if (blockIdx.x == 0) {
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+      const float gr = g[i] * gs;
+      const float mk = m[i] + (gr - m[i]) * (1.f - b1);
+      const float vk = v[i] * b2 + (1.f - b2) * gr * gr;
+      m[i] = mk;
+      v[i] = vk;
+      p[i] -= step_size * (mk / (sqrtf(vk) / bc2s + eps));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ layout
+// X[t][g*Bh+b][c] = x_g[b][c][t] ; tile-transpose through LDS over (c,t) per segment
+__global__ __launch_bounds__(256) void mel_to_frames_kernel(const float* __restrict__ x1,
+                                                            const float* __restrict__ x2, float* __restrict__ X,
+                                                            int Bh, int C, int T, int N) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const float* __restrict__ src = (n < Bh ? x1 + (int64_t)n * C * T : x2 + (int64_t)(n - Bh) * C * T);
+  const int c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, t = t0 + tx;
+    tile[k][tx] = (c < C && t < T) ? src[(int64_t)c * T + t] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int t = t0 + k, c = c0 + tx;
+    if (t < T && c < C) X[((int64_t)t * N + n) * C + c] = tile[tx][k];
+  }
+}
+
+// out[n][c][t] = X[t][n][c]
+__global__ __launch_bounds__(256) void frames_to_mel_kernel(const float* __restrict__ X, float* __restrict__ out,
+                                                            int N, int C, int T) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z;
+  const int c0 = blockIdx.y * 32, t0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int t = t0 + k, c = c0 + tx;
+    tile[k][tx] = (t < T && c < C) ? X[((int64_t)t * N + n) * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, t = t0 + tx;
+    if (c < C && t < T) out[((int64_t)n * C + c) * T + t] = tile[tx][k];
+  }
+}
+
+__global__ __launch_bounds__(256) void permute_102_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          int A, int B, int C4) {
+  // in[a][b][c] -> out[b][a][c], float4 along c
+  const int64_t total = (int64_t)A * B * C4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C4);
+    const int64_t ab = i / C4;
+    const int a = (int)(ab % A);
+    const int b = (int)(ab / A);
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(in)[((int64_t)a * B + b) * C4 + c];
+  }
+}
+
+constexpr int CS_ROWS = 512;
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ o1,
+                                                     float* __restrict__ o2, int R, int C, int64_t ld) {
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+  float s = 0.f;
+  if (c < C)
+    for (int r = r0 + rl; r < r1; r += 4) s += X[(int64_t)r * ld + c];
+  __shared__ float red[4][64];
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const float tot = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    atomicAdd(o1 + c, tot);
+    if (o2) atomicAdd(o2 + c, tot);
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                        int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? in[(int64_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < C && r < R) out[(int64_t)c * R + r] = tile[tx][k];
+  }
+}
+
+// dU = dZ * act'(Z)   (Linear + ReLU backward, disentangled_vae.py:211)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dz, const float* __restrict__ z, float* du,
+                                                      int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    du[i] = dz[i] * act_grad_from_out(z[i], act);
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(float* y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = act_apply(y[i], act);
+}
+
+// W[co][ci][5] -> Wp[tap][co][ci]
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ W, float* __restrict__ Wp,
+                                                        int64_t cc) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cc; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int tap = 0; tap < 5; ++tap) Wp[tap * cc + i] = W[i * 5 + tap];
+  }
+}
+__global__ __launch_bounds__(256) void conv_unpack_add_kernel(const float* __restrict__ dWp, float* __restrict__ dW,
+                                                              int64_t cc) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cc; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+    for (int tap = 0; tap < 5; ++tap) dW[i * 5 + tap] += dWp[tap * cc + i];
+  }
+}
+
+inline int nblk(int64_t n, int per = 256, int cap = 2048) {
+  int64_t b = (n + per - 1) / per;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+DVAE_API int dvae_latent_fwd(const float* style, const float* content, const float* eps_c, const float* eps_s,
+                             float* z, float* q_mu, float* q_lv, float* s_mu, float* s_lv, int Bh, int S, int Cn,
+                             void* stream) {
+  if (!style || !content || !eps_s || !z || !q_mu || !q_lv || !s_mu || !s_lv || Bh < 1 || S < 1 || Cn < 1)
+    return DVAE_EINVAL;
+  const int total = 2 * Bh * (S + Cn);
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, style, content,
+                     eps_c, eps_s, z, q_mu, q_lv, s_mu, s_lv, Bh, S, Cn);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_latent_bwd(const float* style, const float* content, const float* eps_c, const float* eps_s,
+                             const float* dz, const float* dq_mu, const float* dq_lv, const float* ds_mu,
+                             const float* ds_lv, float* dstyle, float* dcontent, int Bh, int S, int Cn,
+                             void* stream) {
+  if (!style || !content || !eps_s || !dstyle || !dcontent || Bh < 1 || S < 1 || Cn < 1) return DVAE_EINVAL;
+  const int total = 2 * Bh * (S + Cn);
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, style, content,
+                     eps_c, eps_s, dz, dq_mu, dq_lv, ds_mu, ds_lv, dstyle, dcontent, Bh, S, Cn);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_kl_fwd(const float* mu, const float* lv, float* out, int64_t n, float scale, void* stream) {
+  if (!mu || !lv || !out || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mu, lv, out, n, scale);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_kl_bwd(const float* mu, const float* lv, const float* gout, float* dmu, float* dlv, int64_t n,
+                         float scale, void* stream) {
+  if (!mu || !lv || !gout || !dmu || !dlv || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, lv,
+                     gout, dmu, dlv, n, scale);
+  return dvae_check_launch();
+}
+
+DVAE_API int64_t dvae_l1_ws_bytes(int64_t n) {
+  (void)n;
+  return (int64_t)L1_BLOCKS * sizeof(double);
+}
+
+DVAE_API int dvae_l1_sum_fwd(const float* x, const float* y, float* out, void* ws, int64_t n, float scale,
+                             void* stream) {
+  if (!x || !y || !out || !ws || n < 1) return DVAE_EINVAL;
+  if ((((uintptr_t)x) | ((uintptr_t)y)) & 15) return DVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = nblk(n / 4 + 1, 256, L1_BLOCKS);
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(blocks), dim3(256), 0, s, x, y, (double*)ws, n);
+  hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(64), 0, s, (const double*)ws, out, blocks, scale);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_l1_sum_bwd(const float* x, const float* y, const float* gout, float* dy, int64_t n, float scale,
+                             void* stream) {
+  if (!x || !y || !gout || !dy || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, y, gout, dy, n, scale);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                            float beta2, float eps, float grad_scale, int step, void* stream) {
+  if (!p || !g || !m || !v || n < 1 || step < 1) return DVAE_EINVAL;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return DVAE_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                     lr, beta1, beta2, eps, grad_scale, (float)bc1, (float)sqrt(bc2));
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_mel_to_frames(const float* x1, const float* x2, float* X, int Bh, int C, int T, void* stream) {
+  if (!x1 || !X || Bh < 1 || C < 1 || T < 1) return DVAE_EINVAL;
+  const int N = x2 ? 2 * Bh : Bh;
+  dim3 grid((T + 31) / 32, (C + 31) / 32, N);
+  hipLaunchKernelGGL(mel_to_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, X, Bh, C, T, N);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_frames_to_mel(const float* X, float* out, int N, int C, int T, void* stream) {
+  if (!X || !out || N < 1 || C < 1 || T < 1) return DVAE_EINVAL;
+  dim3 grid((T + 31) / 32, (C + 31) / 32, N);
+  hipLaunchKernelGGL(frames_to_mel_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, out, N, C, T);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_permute_102(const float* in, float* out, int A, int B, int C, void* stream) {
+  if (!in || !out || A < 1 || B < 1 || C < 4 || (C & 3)) return DVAE_EINVAL;
+  const int64_t total = (int64_t)A * B * (C / 4);
+  hipLaunchKernelGGL(permute_102_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, in, out, A, B, C / 4);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_colsum_add(const float* X, float* out1, float* out2, int R, int C, int64_t ld, void* stream) {
+  if (!X || !out1 || R < 1 || C < 1) return DVAE_EINVAL;
+  dim3 grid((C + 63) / 64, (R + CS_ROWS - 1) / CS_ROWS);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_transpose(const float* in, float* out, int R, int C, void* stream) {
+  if (!in || !out || R < 1 || C < 1) return DVAE_EINVAL;
+  dim3 grid((C + 31) / 32, (R + 31) / 32);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out, R, C);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_act_bwd(const float* dZ, const float* Z, float* dU, int64_t n, int act, void* stream) {
+  if (!dZ || !Z || !dU || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dZ, Z, dU, n, act);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_act_fwd(float* Y, int64_t n, int act, void* stream) {
+  if (!Y || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, Y, n, act);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void* stream) {
+  if (!W || !Wp || Cout < 1 || Cin < 1) return DVAE_EINVAL;
+  const int64_t cc = (int64_t)Cout * Cin;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(nblk(cc)), dim3(256), 0, (hipStream_t)stream, W, Wp, cc);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_conv_unpack_add_w(const float* dWp, float* dW, int Cout, int Cin, void* stream) {
+  if (!dWp || !dW || Cout < 1 || Cin < 1) return DVAE_EINVAL;
+  const int64_t cc = (int64_t)Cout * Cin;
+  hipLaunchKernelGGL(conv_unpack_add_kernel, dim3(nblk(cc)), dim3(256), 0, (hipStream_t)stream, dWp, dW, cc);
+  return dvae_check_launch();
+}

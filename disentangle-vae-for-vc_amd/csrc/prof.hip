@@ -1,0 +1,57 @@
+// Opt-in timing of one kernel family with HIP events recorded on the launch stream itself
+// (torch.cuda.Event only sees torch's current stream; these bracket the launches wherever they go).
+// Off by default: the hot path then pays one predictable branch per launch.
+#include <vector>
+#include "common.h"
+
+int g_dvae_prof_family = 0;
+
+namespace {
+struct Rec {
+  hipEvent_t a, b;
+};
+std::vector<Rec> g_pool;   // grows on demand while profiling is enabled
+size_t g_used = 0;
+double g_flops = 0.0;
+}  // namespace
+
+void dvae_prof_begin(int family, hipStream_t s, double flops) {
+  (void)family;
+  if (g_used == g_pool.size()) {
+    Rec r;
+    (void)hipEventCreate(&r.a);
+    (void)hipEventCreate(&r.b);
+    g_pool.push_back(r);
+  }
+  g_flops += flops;
+  (void)hipEventRecord(g_pool[g_used].a, s);
+}
+
+void dvae_prof_end(int family, hipStream_t s) {
+  (void)family;
+  (void)hipEventRecord(g_pool[g_used].b, s);
+  ++g_used;
+}
+
+DVAE_API int dvae_prof_enable(int family) {
+  g_dvae_prof_family = family;
+  g_used = 0;
+  g_flops = 0.0;
+  return DVAE_OK;
+}
+
+DVAE_API int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops) {
+  double tot = 0.0;
+  for (size_t i = 0; i < g_used; ++i) {
+    (void)hipEventSynchronize(g_pool[i].b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g_pool[i].a, g_pool[i].b);
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int64_t)g_used;
+  if (flops) *flops = g_flops;
+  g_used = 0;
+  g_flops = 0.0;
+  return DVAE_OK;
+}

@@ -1,0 +1,88 @@
+"""Feeder of the training step: same-speaker utterance pairs of mel segments.
+
+`SpeechDatasetGVAE` keeps the semantics of /root/reference/preprocessing/dataset.py:53-123:
+directory layout `<root>/<speaker>/*.npy` with arrays [80, L]; per speaker the utterance list is
+shuffled, cut into two halves and the i-th files of each half form a pair (:63-76, re-done by
+`shuffle_data()` each epoch :78-91); each item is cropped to `samples_length` frames at a random
+offset, or right-padded with zeros when shorter (:100-109); the label is the index of the speaker
+directory (:111-112).  Differences: an explicit RNG (reproducible), sorted directory listing, and
+L == samples_length crops at 0 instead of raising (np.random.choice(0) in the reference).
+
+`SyntheticPairs` is the generator used by bench.py / tests: U[0,1) mels (the range produced by
+preprocessing/encoder/utils.py:132-133) already resident on the device.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+class SpeechDatasetGVAE(Dataset):
+    def __init__(self, file_path, sr=16000, samples_length=64, seed: Optional[int] = None):
+        self.file_path = file_path
+        self.sr = sr
+        self.samples_length = samples_length
+        self.rng = np.random.RandomState(seed) if seed is not None else np.random
+        self.speaker_ids = sorted(d for d in os.listdir(file_path) if os.path.isdir(os.path.join(file_path, d)))
+        self.spk_utt = [np.array(sorted(glob.glob(os.path.join(file_path, s, "*.npy")))) for s in self.speaker_ids]
+        self.utterance_fp = np.empty((0, 2), dtype=object)
+        self.shuffle_data()
+
+    def shuffle_data(self):
+        pairs = []
+        for utt in self.spk_utt:
+            self.rng.shuffle(utt)
+            half = utt.shape[0] // 2
+            pairs += [(utt[i], utt[half + i]) for i in range(half)]
+        self.utterance_fp = np.array(pairs, dtype=object).reshape(-1, 2)
+
+    def _crop(self, mel):
+        T = self.samples_length
+        L = mel.shape[1]
+        if L < T:
+            return np.pad(mel, ((0, 0), (0, T - L)), "constant", constant_values=0)
+        start = int(self.rng.randint(0, L - T)) if L > T else 0
+        return mel[:, start:start + T]
+
+    def __getitem__(self, index):
+        u1, u2 = self.utterance_fp[index]
+        mel1, mel2 = self._crop(np.load(u1)), self._crop(np.load(u2))
+        spk = self.speaker_ids.index(os.path.basename(os.path.dirname(u1)))
+        return torch.from_numpy(np.ascontiguousarray(mel1)), torch.from_numpy(np.ascontiguousarray(mel2)), \
+            torch.tensor(spk)
+
+    def __len__(self):
+        return len(self.utterance_fp)
+
+    def get_utterance(self, speaker, utterance):
+        return np.load(os.path.join(self.file_path, speaker, utterance))
+
+
+def write_synthetic_corpus(root, n_speakers=2, n_utt=8, n_mel=80, length=96, seed=0):
+    """BASELINE config[0]: `n_speakers` x `n_utt` float64 .npy files of shape [80, length], U[0,1)."""
+    rs = np.random.RandomState(seed)
+    for s in range(n_speakers):
+        d = os.path.join(root, f"spk{s:03d}")
+        os.makedirs(d, exist_ok=True)
+        for u in range(n_utt):
+            np.save(os.path.join(d, f"utt{u:03d}_mel.npy"), rs.uniform(0.0, 1.0, size=(n_mel, length)))
+    return root
+
+
+class SyntheticPairs:
+    """Device-resident synthetic batches: x1, x2 ~ U[0,1) fp32 [B, 80, T]; speaker ids uniform over n_speakers
+    (ids are unused by the loss, variational_base_vae.py:58)."""
+
+    def __init__(self, batch, n_frames, n_speakers=10, seed=1234, device="cuda", n_mel=80):
+        rs = np.random.RandomState(seed)
+        self.x1 = torch.from_numpy(rs.uniform(0, 1, size=(batch, n_mel, n_frames)).astype(np.float32)).to(device)
+        self.x2 = torch.from_numpy(rs.uniform(0, 1, size=(batch, n_mel, n_frames)).astype(np.float32)).to(device)
+        self.spk = torch.from_numpy(rs.randint(0, n_speakers, size=(batch,))).to(device)
+
+    def batch(self):
+        return self.x1, self.x2, self.spk

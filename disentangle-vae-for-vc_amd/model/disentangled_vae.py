@@ -1,0 +1,350 @@
+"""MI355X-native DisentangledVAE / ConvolutionalMulVAE.
+
+Drop-in for /root/reference/model/disentangled_vae.py: same class names, constructor arguments,
+method signatures, return tuples and `state_dict` keys — but `torch.nn` is used
+only as a PARAMETER CONTAINER.  No torch.nn forward is ever called: all tensor math goes through
+the hand-written HIP kernels of libdvae_hip.so (ops.py), forward and backward.
+
+MI355X-first design decisions (none of them visible through the API):
+  * the utterance pair (x1, x2) runs through encoder, decoder and postnet ONCE as a batch of
+    N = 2B mel segments (x1 rows then x2 rows); BatchNorm statistics stay per utterance of the
+    pair (2 groups), exactly as the reference's two separate calls produce them;
+  * activations are frame-major [T, N, C]: a conv tap is a row shift, an LSTM frame is one
+    contiguous slab, every GEMM-shaped op is one MFMA contraction over rows;
+  * parameters/gradients/moments live in flat buffers (optim.FlatAdam).
+
+Extra constructor argument `n_frames` (default 64) sizes the two layers the reference hard-codes
+to 8192 = 64*128 (disentangled_vae.py:165,171) so T = 128/256/512 work.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import (ACT_NONE, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, KlFn, L1SumFn, LatentFn, LinearFn,
+                   LstmLayerFn, Permute102Fn, mel_to_frames)
+from ..optim import FlatAdam
+from .variational_base_vae import VariationalBaseModelVAE
+
+N_MEL = 80
+
+
+# ------------------------------------------------------------------ parameter containers
+class _Conv1dParams(nn.Module):
+    """weight [Cout, Cin, 5] + bias, torch Conv1d layout (state_dict contract)."""
+
+    def __init__(self, cin, cout, k=5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class ConvNorm(nn.Module):
+    """Key level `.conv.` of the reference's ConvNorm (disentangled_vae.py:103-121)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=5, **_):
+        super().__init__()
+        self.conv = _Conv1dParams(in_channels, out_channels, kernel_size)
+
+
+class _BatchNormParams(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class _LinearParams(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        self.bias = nn.Parameter(torch.full((o,), 0.01))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class LinearNorm(nn.Module):
+    """Key level `.linear_layer.` of the reference's LinearNorm (disentangled_vae.py:90-100)."""
+
+    def __init__(self, in_dim, out_dim, **_):
+        super().__init__()
+        self.linear_layer = _LinearParams(in_dim, out_dim)
+
+
+class _LSTMParams(nn.Module):
+    """Parameters of nn.LSTM with torch's names/layout/default init U(+-1/sqrt(H)); gate order i,f,g,o."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, bidirectional=False):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.bidirectional = num_layers, bidirectional
+        b = 1.0 / math.sqrt(hidden_size)
+        for l in range(num_layers):
+            in_l = input_size if l == 0 else hidden_size * (2 if bidirectional else 1)
+            for sfx in ([""] + (["_reverse"] if bidirectional else [])):
+                for name, shape in (("weight_ih", (4 * hidden_size, in_l)), ("weight_hh", (4 * hidden_size, hidden_size)),
+                                    ("bias_ih", (4 * hidden_size,)), ("bias_hh", (4 * hidden_size,))):
+                    p = nn.Parameter(torch.empty(*shape).uniform_(-b, b))
+                    setattr(self, f"{name}_l{l}{sfx}", p)
+
+    def layer(self, l):
+        g = lambda n: getattr(self, n)
+        fwd = (g(f"weight_ih_l{l}"), g(f"weight_hh_l{l}"), g(f"bias_ih_l{l}"), g(f"bias_hh_l{l}"))
+        if self.bidirectional:
+            return fwd + (g(f"weight_ih_l{l}_reverse"), g(f"weight_hh_l{l}_reverse"), g(f"bias_ih_l{l}_reverse"),
+                          g(f"bias_hh_l{l}_reverse"))
+        return fwd + (None, None, None, None)
+
+
+def _conv_bn(cin, cout, keyed):
+    return nn.Sequential(ConvNorm(cin, cout) if keyed else _Conv1dParams(cin, cout), _BatchNormParams(cout))
+
+
+def _conv_of(block):
+    c = block[0]
+    return c.conv if isinstance(c, ConvNorm) else c
+
+
+def init_weights(m):
+    """reference init_weights (disentangled_vae.py:26-32): xavier-uniform Linear (bias 0.01) and Conv1d (bias 0)."""
+    if isinstance(m, _LinearParams):
+        nn.init.xavier_uniform_(m.weight)
+        m.bias.data.fill_(0.01)
+    if isinstance(m, _Conv1dParams):
+        nn.init.xavier_uniform_(m.weight)
+        m.bias.data.fill_(0)
+
+
+class Postnet(nn.Module):
+    """Five conv(k5)+BatchNorm blocks, tanh on all but the last (disentangled_vae.py:43-87)."""
+
+    def __init__(self):
+        super().__init__()
+        ch = [N_MEL, 512, 512, 512, 512, N_MEL]
+        self.convolutions = nn.ModuleList(_conv_bn(ch[i], ch[i + 1], keyed=True) for i in range(5))
+
+    def forward_frames(self, y, n_seg, groups, residual=None):
+        """y [T*N, 80] frame-major -> postnet(y) (+ residual fused into the last BatchNorm apply)."""
+        last = len(self.convolutions) - 1
+        for i, blk in enumerate(self.convolutions):
+            c, bn = _conv_of(blk), blk[1]
+            y = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
+                                  ACT_TANH if i < last else ACT_NONE, self.training)
+        return y
+
+    def forward(self, x):
+        """x [B, 80, T] -> [B, 80, T], as called by voice conversion (variational_base_vae.py:292)."""
+        B, C, T = x.shape
+        y = self.forward_frames(mel_to_frames(x.contiguous()), B, 1)
+        return FramesToMelFn.apply(y, B, C, T)
+
+
+class DisentangledVAE(nn.Module):
+    """reference: disentangled_vae.py:124-286."""
+
+    def __init__(self, speaker_size, input_sz=(1, 64, 80), kernel_szs=[512, 512, 512], hidden_sz: int = 256,
+                 latent_sz: int = 32, c: float = 512, c_delta: float = 0.001, beta: float = 0.1,
+                 beta_delta: float = 0, dim_neck=64, latent_dim=64, dim_pre=512, batch_size=10, n_frames: int = 64):
+        super().__init__()
+        self.batch_size = batch_size
+        self._input_sz = input_sz
+        self._channel_szs = [input_sz[0]] + list(kernel_szs)
+        self._hidden_sz = hidden_sz
+        self._c, self._c_delta = c, c_delta
+        self._beta, self._beta_delta = beta, beta_delta
+        self.latent_dim = latent_dim
+        self.dim_neck = dim_neck
+        self.speaker_size = speaker_size
+        self.n_frames = n_frames
+        flat = n_frames * 2 * dim_neck
+
+        self.postnet = Postnet()
+        self.enc_modules = nn.ModuleList(_conv_bn(N_MEL if i == 0 else 512, 512, keyed=True) for i in range(3))
+        self.enc_lstm = _LSTMParams(dim_pre, dim_neck, 2, bidirectional=True)
+        self.enc_linear = LinearNorm(flat, 2048)
+        self.style = LinearNorm(2048, speaker_size * 2)
+        self.content = LinearNorm(2048, (latent_dim - speaker_size) * 2)
+
+        self.dec_pre_linear1 = _LinearParams(latent_dim, 2048)
+        self.dec_pre_linear2 = _LinearParams(2048, flat)
+        self.dec_lstm1 = _LSTMParams(dim_neck * 2, 512, 1)
+        self.dec_modules = nn.ModuleList(_conv_bn(dim_pre, dim_pre, keyed=False) for _ in range(3))
+        self.dec_lstm2 = _LSTMParams(dim_pre, 1024, 2)
+        self.dec_linear2 = LinearNorm(1024, N_MEL)
+        self.apply(init_weights)
+
+        # explicit reparameterisation noise for parity runs: (eps_content1, eps_content2, eps_style),
+        # the reference's three normal_() draws in call order (disentangled_vae.py:252,255,261)
+        self.eps_override: Optional[Sequence[torch.Tensor]] = None
+
+    # ---- parameters in the order their gradients complete during backward (for bucketed all-reduce)
+    def backward_param_order(self):
+        order = []
+        take = lambda mod, pre: order.extend((pre + n, p) for n, p in mod.named_parameters())
+        for i in reversed(range(5)):
+            take(self.postnet.convolutions[i], f"postnet.convolutions.{i}.")
+        take(self.dec_linear2, "dec_linear2.")
+        take(self.dec_lstm2, "dec_lstm2.")
+        for i in reversed(range(3)):
+            take(self.dec_modules[i], f"dec_modules.{i}.")
+        take(self.dec_lstm1, "dec_lstm1.")
+        take(self.dec_pre_linear2, "dec_pre_linear2.")
+        take(self.dec_pre_linear1, "dec_pre_linear1.")
+        take(self.content, "content.")
+        take(self.style, "style.")
+        take(self.enc_linear, "enc_linear.")
+        take(self.enc_lstm, "enc_lstm.")
+        for i in reversed(range(3)):
+            take(self.enc_modules[i], f"enc_modules.{i}.")
+        assert len(order) == len(list(self.parameters()))
+        return order
+
+    # ---- frame-major building blocks
+    def _check(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("DisentangledVAE runs only on the MI355X HIP path; there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure)")
+        if x.shape[1] != N_MEL or x.shape[2] != self.n_frames:
+            raise ValueError(f"expected [B, {N_MEL}, {self.n_frames}] mel segments, got {tuple(x.shape)}")
+
+    def _lstm(self, mod, x, T, n_seg):
+        for l in range(mod.num_layers):
+            x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l))
+        return x
+
+    def _encode_frames(self, x, T, n_seg, groups):
+        for blk in self.enc_modules:
+            c, bn = _conv_of(blk), blk[1]
+            x = ConvBnActFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training)
+        h = self._lstm(self.enc_lstm, x, T, n_seg)                       # [T*N, 128]
+        d2 = 2 * self.dim_neck
+        flat = Permute102Fn.apply(h, T, n_seg, d2, (n_seg, T * d2))     # index t*128+d as in :209
+        lin = self.enc_linear.linear_layer
+        feat = LinearFn.apply(flat, lin.weight, lin.bias, ACT_RELU)
+        st, ct = self.style.linear_layer, self.content.linear_layer
+        return LinearFn.apply(feat, st.weight, st.bias, ACT_NONE), LinearFn.apply(feat, ct.weight, ct.bias, ACT_NONE)
+
+    def _decode_frames(self, z, T, n_seg, groups):
+        p1, p2 = self.dec_pre_linear1, self.dec_pre_linear2
+        h = LinearFn.apply(z, p1.weight, p1.bias, ACT_NONE)
+        h = LinearFn.apply(h, p2.weight, p2.bias, ACT_NONE)              # [N, T*128]  (no activation, :232-233)
+        d2 = 2 * self.dim_neck
+        h = Permute102Fn.apply(h, n_seg, T, d2, (T * n_seg, d2))
+        h = self._lstm(self.dec_lstm1, h, T, n_seg)
+        for blk in self.dec_modules:
+            c, bn = blk[0], blk[1]
+            h = ConvBnActFn.apply(h, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training)
+        h = self._lstm(self.dec_lstm2, h, T, n_seg)
+        lin = self.dec_linear2.linear_layer
+        return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE)        # [T*N, 80]
+
+    # ---- reference API
+    def encode(self, x):
+        """x [B,80,T] -> (style_mu, style_logvar, content_mu, content_logvar)  (disentangled_vae.py:198-220)"""
+        self._check(x)
+        B, _, T = x.shape
+        style, content = self._encode_frames(mel_to_frames(x.contiguous()), T, B, 1)
+        s, c = self.speaker_size, self.latent_dim - self.speaker_size
+        return style[:, :s], style[:, s:], content[:, :c], content[:, c:]
+
+    def _reparameterize(self, mu, logvar, train=True):
+        """API-compatible standalone form (disentangled_vae.py:222-228).  The training path does not call it:
+        forward() fuses the three reparameterisations into one HIP kernel (ops.LatentFn)."""
+        if not train:
+            return mu
+        eps = torch.randn(logvar.shape, device=logvar.device, dtype=logvar.dtype)
+        return eps * torch.exp(0.5 * logvar) + mu
+
+    def decode(self, z):
+        """z [B, latent] -> [B,80,T]  (disentangled_vae.py:230-248)"""
+        if not z.is_cuda:
+            raise RuntimeError("DisentangledVAE.decode runs only on the HIP device")
+        B, T = z.shape[0], self.n_frames
+        y = self._decode_frames(z.contiguous(), T, B, 1)
+        return FramesToMelFn.apply(y, B, N_MEL, T)
+
+    def _eps(self, Bh, dev, train):
+        S, Cn = self.speaker_size, self.latent_dim - self.speaker_size
+        if self.eps_override is not None:
+            e1, e2, es = (e.to(dev, torch.float32) for e in self.eps_override)
+            eps_c = torch.cat((e1, e2), 0).contiguous() if train else None
+            return eps_c, es.contiguous()
+        eps_c = torch.randn((2 * Bh, Cn), device=dev, dtype=torch.float32) if train else None
+        return eps_c, torch.randn((Bh, S), device=dev, dtype=torch.float32)
+
+    def forward(self, x1, x2, train=True):
+        """-> (recons_x1, recons_x2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar, q_z2_mu, q_z2_logvar,
+        z_style_mu, z_style_logvar)   (disentangled_vae.py:250-279)"""
+        self._check(x1)
+        self._check(x2)
+        Bh, _, T = x1.shape
+        N = 2 * Bh
+        S, Cn = self.speaker_size, self.latent_dim - self.speaker_size
+        x = mel_to_frames(x1.contiguous(), x2.contiguous())              # [T*N, 80]
+        style, content = self._encode_frames(x, T, N, 2)
+        eps_c, eps_s = self._eps(Bh, x1.device, train)
+        z, q_mu, q_lv, s_mu, s_lv = LatentFn.apply(style, content, eps_c, eps_s, Bh, S, Cn)
+        y = self._decode_frames(z, T, N, 2)                              # [T*N, 80]
+        y_hat = self.postnet.forward_frames(y, N, 2, residual=y)         # y + postnet(y)
+        rec = FramesToMelFn.apply(y, N, N_MEL, T)
+        rec_hat = FramesToMelFn.apply(y_hat, N, N_MEL, T)
+        return (rec[:Bh], rec[Bh:], rec_hat[:Bh], rec_hat[Bh:], q_mu[:Bh], q_lv[:Bh], q_mu[Bh:], q_lv[Bh:],
+                s_mu, s_lv)
+
+    def update_c(self):
+        self._c += self._c_delta
+
+    def update_beta(self):
+        self._beta += self._beta_delta
+
+
+class ConvolutionalMulVAE(VariationalBaseModelVAE):
+    """reference: disentangled_vae.py:288-350 (model + Adam owner, loss_functionGVAE2)."""
+
+    def __init__(self, dataset, width, height, latent_sz, learning_rate, alpha, log_interval, normalize, batch_size,
+                 speaker_size, channels=1, device=torch.device("cuda"), latent_dim=256, beta=0.1, mse_cof=10,
+                 kl_cof=10, style_cof=0.1, n_frames: Optional[int] = None):
+        super().__init__(dataset, width, height, channels, latent_sz, learning_rate, device, log_interval, batch_size)
+        self.batch_size = batch_size
+        self.alpha = alpha
+        self.lr = learning_rate
+        self.latent_dim = latent_dim
+        self.mse_cof, self.kl_cof, self.style_cof = mse_cof, kl_cof, style_cof
+        n_frames = width if n_frames is None else n_frames
+        self.model = DisentangledVAE(latent_dim=self.latent_dim, beta=0.1, batch_size=batch_size,
+                                     speaker_size=speaker_size, n_frames=n_frames).to(device)
+        self.optimizer = FlatAdam(self.model.backward_param_order(), lr=self.lr)
+        self.train_losses, self.test_losses = [], []
+
+    def loss_functionGVAE2(self, x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar,
+                           q_z2_mu, q_z2_logvar, style_mu1, style_logvar1, train=False):
+        """8-tuple (LOSS, L1_x1, L1_x2, L1_x1hat, L1_x2hat, KL_z1, KL_z2, z_kl_style), disentangled_vae.py:310-327.
+        The variables are named MSE_* in the reference but are L1 sums divided by the CONFIGURED batch size."""
+        inv_b = 1.0 / float(self.batch_size)
+        l1 = [L1SumFn.apply(x1, x_recon1, inv_b), L1SumFn.apply(x2, x_recon2, inv_b),
+              L1SumFn.apply(x1, recons_x1_hat, inv_b), L1SumFn.apply(x2, recons_x2_hat, inv_b)]
+        kl1 = KlFn.apply(q_z1_mu, q_z1_logvar, -0.5 / q_z1_mu.shape[0])
+        kl2 = KlFn.apply(q_z2_mu, q_z2_logvar, -0.5 / q_z2_mu.shape[0])
+        kl_style = KlFn.apply(style_mu1, style_logvar1, -inv_b)
+        loss = self.mse_cof * (l1[0] + l1[1] + l1[2] + l1[3]) + self.kl_cof * (kl1 + kl2)
+        return loss, l1[0], l1[1], l1[2], l1[3], kl1, kl2, kl_style
+
+    def update_(self):
+        self.model.update_c()
+        self.model.update_beta()
+
+    def update_kl(self):
+        self.kl_cof = min(self.kl_cof * 2, 10)
+
+    def set_kl(self, beta):
+        self.kl = beta

@@ -1,0 +1,141 @@
+"""Training-loop surface of the reference's VariationalBaseModelVAE
+(/root/reference/model/variational_base_vae.py:30-202), device-agnostic and data-parallel capable.
+
+Kept: `step`, `train`, `run_training`, `load_last_model`, checkpoint naming
+`DisentangledVAE_VCTK_{epoch}.pth` holding `model.state_dict()`.
+Changed on purpose:
+  * no hard-coded `.to("cuda")` (:81-82): batches go to `self.device`;
+  * the 8 `.item()` host syncs of :70 become ONE device->host copy of the 8 scalars;
+  * optional data parallelism: `attach_reducer()` installs ddp.GradReducer, after which `step`
+    overlaps a bucketed RCCL all-reduce of the flat gradient buffer with backward;
+  * TensorBoard is optional (tensorboardX is not a dependency): scalars go to `logs_path/scalars.jsonl`;
+  * out of scope here: estimate_trained_model / voice_conversion_mel / test.
+"""
+from __future__ import annotations
+
+import json
+import os
+from glob import glob
+from pathlib import Path
+
+import torch
+
+
+class VariationalBaseModelVAE:
+    def __init__(self, dataset, width, height, channels, latent_sz, learning_rate, device, log_interval, batch_size,
+                 normalize=False, flatten=True):
+        self.dataset = dataset
+        self.width, self.height, self.channels = width, height, channels
+        self.input_sz = (channels, width, height)
+        self.latent_sz = latent_sz
+        self.lr = learning_rate
+        self.device = device
+        self.log_interval = log_interval
+        self.normalize_data = normalize
+        self.flatten_data = flatten
+        self.model = None       # set by subclasses
+        self.optimizer = None
+        self.batch_size = batch_size
+        self.reducer = None     # ddp.GradReducer when data parallel
+
+    def loss_function(self):
+        raise NotImplementedError
+
+    # ---- data parallel (new functionality: the reference is single-device)
+    def attach_reducer(self, reducer):
+        self.reducer = reducer
+
+    # ---- variational_base_vae.py:58-70
+    def step(self, data1, data2, speaker_ids, train=False):
+        if train:
+            self.optimizer.zero_grad()
+        outs = self.model(data1, data2)
+        losses = self.loss_functionGVAE2(data1, data2, *outs, train=train)
+        if train:
+            if self.reducer is not None:
+                self.reducer.begin()
+            losses[0].backward()
+            scale = 1.0
+            if self.reducer is not None:
+                self.reducer.finish()
+                scale = 1.0 / self.reducer.world_size
+            self.optimizer.step(grad_scale=scale)
+        vals = torch.stack([l.detach() for l in losses]).tolist()   # one D2H copy instead of 8 .item() syncs
+        return tuple(vals)
+
+    # ---- variational_base_vae.py:74-101
+    def train(self, train_loader, epoch, logging_func=print):
+        self.model.train()
+        tot = [0.0] * 8
+        last_style = 0.0
+        for data1, data2, speaker_ids in train_loader:
+            data1 = data1.to(self.device, non_blocking=True).float()
+            data2 = data2.to(self.device, non_blocking=True).float()
+            speaker_ids = speaker_ids.view(-1)
+            vals = self.step(data1, data2, speaker_ids, train=True)
+            for i in range(8):
+                tot[i] += vals[i]
+            last_style = vals[7]
+        if hasattr(train_loader.dataset, "shuffle_data"):
+            train_loader.dataset.shuffle_data()
+        logging_func("====> Epoch: {} Average loss: {:.4f}".format(epoch, tot[0] / max(1, len(train_loader.dataset))))
+        # NB the reference returns the style KL of the LAST batch, not the total (:101)
+        return tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], last_style
+
+    # ---- variational_base_vae.py:127-149
+    def load_last_model(self, checkpoints_path, logging_func=print):
+        name = self.model.__class__.__name__
+        ids = []
+        for f in glob(f"{checkpoints_path}/*.pth"):
+            parts = Path(f).stem.split("_")
+            if len(parts) == 3 and parts[2].isdigit():
+                ids.append((int(parts[2]), f))
+        if not ids:
+            logging_func(f"Training {name} model from scratch...")
+            return 1
+        start_epoch, last = max(ids, key=lambda it: it[0])
+        self.model.load_state_dict(torch.load(last, map_location=self.device))
+        opt = last[:-4] + ".opt"
+        if os.path.exists(opt):
+            self.optimizer.load_state_dict(torch.load(opt, map_location="cpu"))
+        logging_func(f"Loading {name} model from last checkpoint ({start_epoch})...")
+        return start_epoch + 1
+
+    def update_(self):
+        pass
+
+    def _is_rank0(self):
+        return self.reducer is None or self.reducer.rank == 0
+
+    # ---- variational_base_vae.py:156-202
+    def run_training(self, train_loader, test_loader, epochs, report_interval, sample_sz=64, reload_model=True,
+                     checkpoints_path="", logs_path="", images_path="", estimation_dir="", logging_func=print,
+                     start_epoch=None):
+        start_epoch = self.load_last_model(checkpoints_path, logging_func) if reload_model else 1
+        run_name = "DisentangledVAE_VCTK"
+        log_f = None
+        if logs_path and self._is_rank0():
+            os.makedirs(os.path.join(logs_path, run_name), exist_ok=True)
+            log_f = open(os.path.join(logs_path, run_name, "scalars.jsonl"), "a")
+        history = []
+        for epoch in range(start_epoch, start_epoch + epochs):
+            r1, r2, r1h, r2h, k1, k2, ks = self.train(train_loader, epoch, logging_func)
+            nb = max(1, len(train_loader))
+            rec = {"epoch": epoch, "Loss/Reconstruction Loss1": r1 / nb, "Loss/Reconstruction Loss2": r2 / nb,
+                   "Loss/Reconstruction Loss1 hat": r1h / nb, "Loss/Reconstruction Loss2 hat": r2h / nb,
+                   "Loss/Z1 KL Loss": k1 / nb, "Loss/Z2 KL Loss": k2 / nb, "Loss/Z KL Style": ks / nb}
+            history.append(rec)
+            if self._is_rank0():
+                logging_func(json.dumps(rec))
+                if log_f:
+                    log_f.write(json.dumps(rec) + "\n")
+                    log_f.flush()
+            if epoch % report_interval == 0 and self._is_rank0() and checkpoints_path:
+                os.makedirs(checkpoints_path, exist_ok=True)
+                with torch.no_grad():
+                    base = f"{checkpoints_path}/{run_name}_{epoch}"
+                    torch.save(self.model.state_dict(), base + ".pth")      # reference format: weights only
+                    torch.save(self.optimizer.state_dict(), base + ".opt")  # added: Adam moments + step count
+        if log_f:
+            log_f.close()
+        return history

@@ -1,0 +1,443 @@
+"""Autograd bindings of the HIP kernels (forward AND backward are hand-written HIP; autograd only
+routes tensors between them).  Every tensor is fp32, contiguous, on the GPU; activations are
+frame-major [T*N, C] (see include/dvae_hip.h).
+
+Weight gradients are ACCUMULATED by the kernels straight into `param.grad` (views of one flat
+buffer owned by the optimiser, see optim.py) — the backward functions return None for parameters.
+`grad_ready_hook`, when set, is called with the parameter as soon as its gradient is complete
+(used by ddp.py to overlap the bucketed all-reduce with the rest of backward).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+EPI_STORE, EPI_ACCUM, EPI_ATOMIC = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+grad_ready_hook: Optional[Callable[[torch.Tensor], None]] = None
+
+
+def _ok(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError(f"HIP op needs contiguous fp32 GPU tensors, got {t.device} {t.dtype} "
+                             f"contiguous={t.is_contiguous()}")
+
+
+def _grad_buf(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _ready(*ps):
+    if grad_ready_hook is not None:
+        for p in ps:
+            if p is not None:
+                grad_ready_hook(p)
+
+
+def _split_k(m_tiles: int, k: int) -> int:
+    """Pick a split so that the launch has ~>=512 workgroups but each keeps >= 256 of K."""
+    s = 1
+    while m_tiles * s < 512 and k // (s * 2) >= 256:
+        s *= 2
+    return s
+
+
+def _tiles(m, n):
+    return ((m + 127) // 128) * ((n + 127) // 128)
+
+
+# ----------------------------------------------------------------------------- raw launches
+def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi=EPI_STORE, split_k=1):
+    check(lib().dvae_gemm_f32(ptr(A), ptr(B), ptr(Cout), ptr(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),
+                              act, epi, split_k, stream()), "dvae_gemm_f32")
+
+
+def linear_fwd(x, w, b, act=ACT_NONE):
+    """y[M,Nout] = act(x[M,K] @ w[Nout,K]^T + b)"""
+    M, K = x.shape
+    Nout = w.shape[0]
+    y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
+    sk = _split_k(_tiles(M, Nout), K)
+    if sk > 1:
+        y.zero_()
+        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, ACT_NONE, EPI_ATOMIC, sk)
+        if act != ACT_NONE:
+            check(lib().dvae_act_fwd(ptr(y), y.numel(), act, stream()), "dvae_act_fwd")
+    else:
+        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, act, EPI_STORE, 1)
+    return y
+
+
+def linear_dgrad(dy, w):
+    """dx[M,K] = dy[M,Nout] @ w[Nout,K]"""
+    M, Nout = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False)
+    return dx
+
+
+def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None):
+    """wgrad[Nout,K] += dy[rows,Nout]^T @ x[rows,K] (atomic accumulation, split over rows)"""
+    Nout, K = wgrad.shape
+    rows = dy.shape[0] if rows is None else rows
+    lda = Nout if lda is None else lda
+    ldb = K if ldb is None else ldb
+    sk = _split_k(_tiles(Nout, K), rows)
+    gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, EPI_ATOMIC, sk)
+
+
+def colsum_add(x, out1, out2=None, rows=None, cols=None, ld=None):
+    rows = x.shape[0] if rows is None else rows
+    cols = x.shape[1] if cols is None else cols
+    ld = x.shape[1] if ld is None else ld
+    check(lib().dvae_colsum_add(ptr(x), ptr(out1), ptr(out2), rows, cols, ld, stream()), "dvae_colsum_add")
+
+
+def mel_to_frames(x1, x2=None):
+    """[Bh,C,T] (x2 optional) -> frame-major [T*N, C]"""
+    _ok(x1, x2)
+    Bh, Cc, T = x1.shape
+    N = Bh * (2 if x2 is not None else 1)
+    X = torch.empty((T * N, Cc), device=x1.device, dtype=torch.float32)
+    check(lib().dvae_mel_to_frames(ptr(x1), ptr(x2), ptr(X), Bh, Cc, T, stream()), "dvae_mel_to_frames")
+    return X
+
+
+def transpose2d(x):
+    R, Cc = x.shape
+    out = torch.empty((Cc, R), device=x.device, dtype=torch.float32)
+    check(lib().dvae_transpose(ptr(x), ptr(out), R, Cc, stream()), "dvae_transpose")
+    return out
+
+
+# ----------------------------------------------------------------------------- Linear (+ReLU)
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (+ optional ReLU): disentangled_vae.py:165-171,194 used at :211-213,232-233,247."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        _ok(x, weight, bias)
+        y = linear_fwd(x, weight, bias, act)
+        ctx.save_for_backward(x, weight, bias, y if act != ACT_NONE else None)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act != ACT_NONE:
+            du = torch.empty_like(dy)
+            check(lib().dvae_act_bwd(ptr(dy), ptr(y), ptr(du), dy.numel(), ctx.act, stream()), "dvae_act_bwd")
+            dy = du
+        dx = linear_dgrad(dy, weight) if ctx.needs_input_grad[0] else None
+        linear_wgrad_acc(dy, x, _grad_buf(weight))
+        colsum_add(dy, _grad_buf(bias))
+        _ready(weight, bias)
+        return dx, None, None, None
+
+
+# ----------------------------------------------------------------------------- Conv1d(k5) + BatchNorm + act
+class ConvBnActFn(torch.autograd.Function):
+    """act(BatchNorm1d_train(Conv1d_k5_p2(x))) [+ residual] on frame-major rows.
+    Reference blocks: encoder :151-162/:201-202, decoder :175-191/:242-243, Postnet :43-87."""
+
+    @staticmethod
+    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, running_mean, running_var, nbt, residual,
+                n_seg, groups, act, training):
+        _ok(x, conv_w, conv_b, bn_w, bn_b, residual)
+        L = lib()
+        R, Cin = x.shape
+        Cout = conv_w.shape[0]
+        dev = x.device
+        st = stream()
+        wp = torch.empty((5, Cout, Cin), device=dev, dtype=torch.float32)
+        check(L.dvae_conv_pack_w(ptr(conv_w), ptr(wp), Cout, Cin, st), "dvae_conv_pack_w")
+        y = torch.empty((R, Cout), device=dev, dtype=torch.float32)
+        check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, st), "dvae_conv5_fwd")
+        if training:
+            G = groups
+            mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
+            rstd = torch.empty((G, Cout), device=dev, dtype=torch.float32)
+            ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
+            check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt),
+                                      ptr(ws), R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_fwd")
+        else:
+            G = 1
+            mean = running_mean.detach().reshape(1, Cout).contiguous()
+            rstd = torch.rsqrt(running_var.detach() + BN_EPS).reshape(1, Cout).contiguous()
+        z = torch.empty((R, Cout), device=dev, dtype=torch.float32)
+        check(L.dvae_bn_apply_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(bn_w), ptr(bn_b), ptr(residual), ptr(z),
+                                  R, n_seg, Cout, G, act, st), "dvae_bn_apply_fwd")
+        ctx.save_for_backward(x, wp, y, z, mean, rstd, conv_w, conv_b, bn_w, bn_b)
+        ctx.cfg = (n_seg, G, act, training, residual is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, wp, y, z, mean, rstd, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
+        n_seg, G, act, training, has_res = ctx.cfg
+        if not training:
+            raise RuntimeError("backward through eval-mode BatchNorm is not part of the training path")
+        L = lib()
+        st = stream()
+        dz = dz.contiguous()
+        R, Cin = x.shape
+        Cout = y.shape[1]
+        dev = x.device
+        if has_res and act != ACT_NONE:
+            raise RuntimeError("residual is only supported with ACT_NONE")
+        ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
+        dy = torch.empty_like(y)
+        check(L.dvae_bn_bwd(ptr(dz), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(bn_w), ptr(dy),
+                            ptr(_grad_buf(bn_w)), ptr(_grad_buf(bn_b)), ptr(ws), R, n_seg, Cout, G, act, st),
+              "dvae_bn_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)
+            check(L.dvae_conv5_dgrad(ptr(dy), ptr(wp), ptr(dx), R, n_seg, Cin, Cout, st), "dvae_conv5_dgrad")
+        dwp = torch.zeros((5, Cout, Cin), device=dev, dtype=torch.float32)
+        sk = _split_k(5 * _tiles(Cout, Cin), R)
+        check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(dwp), R, n_seg, Cin, Cout, sk, st), "dvae_conv5_wgrad")
+        check(L.dvae_conv_unpack_add_w(ptr(dwp), ptr(_grad_buf(conv_w)), Cout, Cin, st), "dvae_conv_unpack_add_w")
+        colsum_add(dy, _grad_buf(conv_b))
+        _ready(conv_w, conv_b, bn_w, bn_b)
+        dres = dz if has_res else None
+        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------- LSTM layer
+class LstmLayerFn(torch.autograd.Function):
+    """One nn.LSTM layer (1 or 2 directions) over frame-major rows: x[T*N, In] -> h[T*N, ndir*H].
+    Reference: enc_lstm :163/:208, dec_lstm1 :172/:238, dec_lstm2 :193/:246."""
+
+    @staticmethod
+    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+        L = lib()
+        st = stream()
+        dev = x.device
+        R, In = x.shape
+        H = w_hh.shape[1]
+        ndir = 2 if w_ih_r is not None else 1
+        ldh = ndir * H
+        h_out = torch.empty((R, ldh), device=dev, dtype=torch.float32)
+        params = [(w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r)][:ndir]
+        dirs = (_lib.LstmDir * ndir)()
+        gates, cells = [], []
+        for d, (wi, wh, bi, bh) in enumerate(params):
+            g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
+            gemm(x, wi, g, bi + bh, R, 4 * H, In, In, In, 4 * H, True, True)
+            c = torch.empty((R, H), device=dev, dtype=torch.float32)
+            gates.append(g)
+            cells.append(c)
+            dirs[d].gates = ptr(g)
+            dirs[d].w_hh = ptr(wh)
+            dirs[d].h_out = h_out.data_ptr() + 4 * d * H
+            dirs[d].c_all = ptr(c)
+            dirs[d].reverse = d
+        check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
+        ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
+        ctx.cfg = (T, N, H, ndir)
+        return h_out
+
+    @staticmethod
+    def backward(ctx, dh):
+        T, N, H, ndir = ctx.cfg
+        sv = ctx.saved_tensors
+        x, h_out = sv[0], sv[1]
+        gates = sv[2:2 + ndir]
+        cells = sv[2 + ndir:2 + 2 * ndir]
+        flat = sv[2 + 2 * ndir:]
+        params = [flat[4 * d:4 * d + 4] for d in range(ndir)]
+        L = lib()
+        st = stream()
+        dev = x.device
+        R, In = x.shape
+        ldh = ndir * H
+        dh = dh.contiguous()
+        dirs = (_lib.LstmDir * ndir)()
+        keep = []
+        dgs = []
+        for d, (wi, wh, bi, bh) in enumerate(params):
+            wht = transpose2d(wh)  # [H, 4H]
+            dg = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
+            dc = torch.empty((N, H), device=dev, dtype=torch.float32)
+            keep += [wht, dc]
+            dgs.append(dg)
+            dirs[d].gates = ptr(gates[d])
+            dirs[d].w_hh = ptr(wht)
+            dirs[d].c_all = ptr(cells[d])
+            dirs[d].dh_out = dh.data_ptr() + 4 * d * H
+            dirs[d].dgates = ptr(dg)
+            dirs[d].dc_ws = ptr(dc)
+            dirs[d].reverse = d
+        check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, In), device=dev, dtype=torch.float32)
+        for d, (wi, wh, bi, bh) in enumerate(params):
+            dg = dgs[d]
+            if dx is not None:
+                gemm(dg, wi, dx, None, R, In, 4 * H, 4 * H, In, In, True, False, ACT_NONE,
+                     EPI_STORE if d == 0 else EPI_ACCUM)
+            linear_wgrad_acc(dg, x, _grad_buf(wi))
+            if T > 1:
+                rows = R - N
+                # h_prev of frame t is h[t-1] (forward) / h[t+1] (reverse)
+                if d == 0:
+                    a_ptr, b_ptr = dg.data_ptr() + 4 * N * 4 * H, h_out.data_ptr()
+                else:
+                    a_ptr, b_ptr = dg.data_ptr(), h_out.data_ptr() + 4 * (N * ldh + H)
+                gw = _grad_buf(wh)
+                sk = _split_k(_tiles(4 * H, H), rows)
+                check(L.dvae_gemm_f32(a_ptr, b_ptr, ptr(gw), None, 4 * H, H, rows, 4 * H, ldh, H, 0, 0, ACT_NONE,
+                                      EPI_ATOMIC, sk, st), "dvae_gemm_f32(dW_hh)")
+            colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
+            _ready(wi, wh, bi, bh)
+        del keep
+        return (dx,) + (None,) * 10
+
+
+# ----------------------------------------------------------------------------- layout
+class FramesToMelFn(torch.autograd.Function):
+    """[T*N, C] -> [N, C, T] (decode()'s final transpose, disentangled_vae.py:248)."""
+
+    @staticmethod
+    def forward(ctx, y, N, Cc, T):
+        _ok(y)
+        out = torch.empty((N, Cc, T), device=y.device, dtype=torch.float32)
+        check(lib().dvae_frames_to_mel(ptr(y), ptr(out), N, Cc, T, stream()), "dvae_frames_to_mel")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return mel_to_frames(dout.contiguous()), None, None, None
+
+
+class Permute102Fn(torch.autograd.Function):
+    """x viewed as [A,B,C] -> [B,A,C], returned with `out_shape` (the reshape between frame-major LSTM rows
+    and the flat [B, T*128] bottleneck, disentangled_vae.py:209,235)."""
+
+    @staticmethod
+    def forward(ctx, x, A, B, Cc, out_shape):
+        _ok(x)
+        ctx.dims = (A, B, Cc, tuple(x.shape))
+        out = torch.empty(tuple(out_shape), device=x.device, dtype=torch.float32)
+        check(lib().dvae_permute_102(ptr(x), ptr(out), A, B, Cc, stream()), "dvae_permute_102")
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        A, B, Cc, in_shape = ctx.dims
+        dout = dout.contiguous()
+        dx = torch.empty(in_shape, device=dout.device, dtype=torch.float32)
+        check(lib().dvae_permute_102(ptr(dout), ptr(dx), B, A, Cc, stream()), "dvae_permute_102")
+        return dx, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- latent / losses
+class LatentFn(torch.autograd.Function):
+    """Style averaging (x2 head detached), three reparameterisations and the q_z concatenations
+    (disentangled_vae.py:222-228, 252-272) in one kernel."""
+
+    @staticmethod
+    def forward(ctx, style, content, eps_c, eps_s, Bh, S, Cn):
+        _ok(style, content, eps_c, eps_s)
+        dev = style.device
+        D = S + Cn
+        z = torch.empty((2 * Bh, D), device=dev, dtype=torch.float32)
+        q_mu = torch.empty_like(z)
+        q_lv = torch.empty_like(z)
+        s_mu = torch.empty((Bh, S), device=dev, dtype=torch.float32)
+        s_lv = torch.empty_like(s_mu)
+        check(lib().dvae_latent_fwd(ptr(style), ptr(content), ptr(eps_c), ptr(eps_s), ptr(z), ptr(q_mu), ptr(q_lv),
+                                    ptr(s_mu), ptr(s_lv), Bh, S, Cn, stream()), "dvae_latent_fwd")
+        ctx.save_for_backward(style, content, eps_c, eps_s)
+        ctx.dims = (Bh, S, Cn)
+        return z, q_mu, q_lv, s_mu, s_lv
+
+    @staticmethod
+    def backward(ctx, dz, dq_mu, dq_lv, ds_mu, ds_lv):
+        style, content, eps_c, eps_s = ctx.saved_tensors
+        Bh, S, Cn = ctx.dims
+        c = lambda t: None if t is None else t.contiguous()
+        dz, dq_mu, dq_lv, ds_mu, ds_lv = c(dz), c(dq_mu), c(dq_lv), c(ds_mu), c(ds_lv)
+        dstyle = torch.empty_like(style)
+        dcontent = torch.empty_like(content)
+        check(lib().dvae_latent_bwd(ptr(style), ptr(content), ptr(eps_c), ptr(eps_s), ptr(dz), ptr(dq_mu),
+                                    ptr(dq_lv), ptr(ds_mu), ptr(ds_lv), ptr(dstyle), ptr(dcontent), Bh, S, Cn,
+                                    stream()), "dvae_latent_bwd")
+        return dstyle, dcontent, None, None, None, None, None
+
+
+class KlFn(torch.autograd.Function):
+    """scale * sum(1 + lv - mu^2 - exp(lv))  (disentangled_vae.py:320-323)."""
+
+    @staticmethod
+    def forward(ctx, mu, lv, scale):
+        mu, lv = mu.contiguous(), lv.contiguous()
+        _ok(mu, lv)
+        out = torch.empty((), device=mu.device, dtype=torch.float32)
+        check(lib().dvae_kl_fwd(ptr(mu), ptr(lv), ptr(out), mu.numel(), scale, stream()), "dvae_kl_fwd")
+        ctx.save_for_backward(mu, lv)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, lv = ctx.saved_tensors
+        g = g.contiguous()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(lv)
+        check(lib().dvae_kl_bwd(ptr(mu), ptr(lv), ptr(g), ptr(dmu), ptr(dlv), mu.numel(), ctx.scale, stream()),
+              "dvae_kl_bwd")
+        return dmu, dlv, None
+
+
+class L1SumFn(torch.autograd.Function):
+    """scale * sum|x - y|  (F.l1_loss(reduction='sum').div(batch_size), disentangled_vae.py:314-318)."""
+
+    @staticmethod
+    def forward(ctx, x, y, scale):
+        x, y = x.contiguous(), y.contiguous()
+        _ok(x, y)
+        L = lib()
+        n = x.numel()
+        out = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = torch.empty((L.dvae_l1_ws_bytes(n),), device=x.device, dtype=torch.uint8)
+        check(L.dvae_l1_sum_fwd(ptr(x), ptr(y), ptr(out), ptr(ws), n, scale, stream()), "dvae_l1_sum_fwd")
+        ctx.save_for_backward(x, y)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous()
+        dy = torch.empty_like(y)
+        check(lib().dvae_l1_sum_bwd(ptr(x), ptr(y), ptr(g), ptr(dy), x.numel(), ctx.scale, stream()),
+              "dvae_l1_sum_bwd")
+        return None, dy, None
+
+
+def prof_enable(family: int):
+    check(lib().dvae_prof_enable(family), "dvae_prof_enable")
+
+
+def prof_collect():
+    ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+    check(lib().dvae_prof_collect(C.byref(ms), C.byref(n), C.byref(fl)), "dvae_prof_collect")
+    return ms.value, n.value, fl.value

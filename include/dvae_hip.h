@@ -1,0 +1,178 @@
+/*
+ * dvae_hip.h — C ABI of libdvae_hip.so: the MI355X (gfx950) kernels behind the
+ * disentangled-VAE training step.
+ *
+ * The reference (v-manhlt3/Disentangle-VAE-for-VC) has no FFI/plugin layer: its
+ * hot path reaches ATen/cuDNN through torch.nn.  Each entry point below names
+ * the reference construct (file:line under /root/reference) whose tensor math it
+ * replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (workspaces too);
+ *     the library allocates nothing and keeps no state between calls, except
+ *     the opt-in profiling event pool (dvae_prof_*);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *     no call synchronises the device;
+ *   - return value: 0 on success, a negative DVAE_E* code otherwise; nothing
+ *     throws, nothing exits;
+ *   - activations are FRAME-MAJOR: a tensor "[T, N, C]" holds frame t of mel
+ *     segment n at row r = t*N + n of a row-major [T*N, C] matrix.  N counts
+ *     segments of the utterance PAIR batched together (x1 rows first, then x2),
+ *     so BatchNorm statistics are taken per GROUP of N/G consecutive segments.
+ *   - all arithmetic is fp32 (MFMA v_mfma_f32_32x32x2_f32 / 16x16x4_f32).
+ */
+#ifndef DVAE_HIP_H
+#define DVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVAE_OK 0
+#define DVAE_EINVAL (-1)  /* bad shape / alignment / null pointer */
+#define DVAE_ELAUNCH (-2) /* hipLaunch failed; see dvae_last_hip_error() */
+
+#define DVAE_ACT_NONE 0
+#define DVAE_ACT_RELU 1
+#define DVAE_ACT_TANH 2
+
+#define DVAE_EPI_STORE 0  /* C  = result                    */
+#define DVAE_EPI_ACCUM 1  /* C += result (plain read-modify-write, no split-K) */
+#define DVAE_EPI_ATOMIC 2 /* C += result with global_atomic_add_f32 (split-K allowed) */
+
+int dvae_version(void);
+/* hipError_t of the last failed launch (0 if none) */
+int dvae_last_hip_error(void);
+
+/* ---- dense contraction (replaces aten::addmm / mm / convolution[_backward]) ----
+ * C[M,N] (+)= act( opA(A)[M,K] * opB(B)[K,N] + bias[N] )
+ *   a_kcontig = 1: A stored [M][K] (lda = row stride)   0: stored [K][M]
+ *   b_kcontig = 1: B stored [N][K] (torch Linear/LSTM weight layout)   0: stored [K][N]
+ * lda, ldb must be multiples of 4 and A, B 16-byte aligned; K % 4 == 0 if an operand is k-contiguous,
+ * M % 4 == 0 (N % 4 == 0) if A (B) is not.
+ * Replaces: nn.Linear forward/backward (disentangled_vae.py:165-171,194,211-213,232-233,247),
+ * LSTM input projections and weight gradients (:163,172,193).
+ */
+int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
+                  int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                  int a_kcontig, int b_kcontig, int act, int epi, int split_k, void* stream);
+
+/* ---- Conv1d(k=5, stride 1, pad 2) on frame-major data (disentangled_vae.py:111-114, 178-181) ----
+ * Weights are used in PACKED form Wp[5][Cout][Cin] (see dvae_conv_pack_w).
+ * fwd : Y[R,Cout]   = sum_tap X[r+(tap-2)*N, :] * Wp[tap]^T + bias      (rows outside [0,R) are zero)
+ * dgrad: dX[R,Cin]  = sum_tap dY[r-(tap-2)*N, :] * Wp[tap]
+ * wgrad: dWp[tap][Cout][Cin] += sum_r dY[r, co] * X[r+(tap-2)*N, ci]     (atomic accumulation)
+ * R = T*N rows, N = segments per frame.
+ */
+int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y,
+                   int R, int N, int Cin, int Cout, void* stream);
+int dvae_conv5_dgrad(const float* dY, const float* Wp, float* dX,
+                     int R, int N, int Cin, int Cout, void* stream);
+int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp,
+                     int R, int N, int Cin, int Cout, int split_k, void* stream);
+/* W[Cout][Cin][5] (torch layout, state_dict contract) -> Wp[5][Cout][Cin] */
+int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void* stream);
+/* dW[Cout][Cin][5] += dWp[5][Cout][Cin] */
+int dvae_conv_unpack_add_w(const float* dWp, float* dW, int Cout, int Cin, void* stream);
+
+/* ---- BatchNorm1d in training mode + activation (disentangled_vae.py:58,69,78,159,182,189; F.relu :202,243; tanh :83) ----
+ * Statistics are per GROUP g = (r % N) / (N/G) (one group per encode()/decode()/postnet() call of the
+ * reference, which sees x1 and x2 separately).  ws: >= dvae_bn_ws_bytes(R, C, G) bytes.
+ * dvae_bn_stats_fwd: mean[G][C], rstd[G][C] (biased var, eps); running_mean/var updated once per group in
+ *   group order with `momentum` and the unbiased variance; *num_batches_tracked += G. running_* may be null.
+ * dvae_bn_apply_fwd: Z = act((Y-mean)*rstd*gamma + beta) (+ residual if non-null)
+ * dvae_bn_bwd: given dZ, saved Y and Z: dY (may alias dZ), dgamma += , dbeta += ; the residual branch's
+ *   gradient is dZ itself (handled by the caller).
+ */
+int64_t dvae_bn_ws_bytes(int R, int C, int G);
+int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* running_mean, float* running_var,
+                      int64_t* num_batches_tracked, void* ws, int R, int N, int C, int G,
+                      float eps, float momentum, void* stream);
+int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
+                      const float* beta, const float* residual, float* Z,
+                      int R, int N, int C, int G, int act, void* stream);
+int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const float* mean, const float* rstd,
+                const float* gamma, float* dY, float* dgamma, float* dbeta, void* ws,
+                int R, int N, int C, int G, int act, void* stream);
+
+/* ---- LSTM recurrence, frame-major, one launch per frame (nn.LSTM at disentangled_vae.py:163,172,193) ----
+ * One dvae_lstm_dir_t per direction (1 or 2).  Gate order i,f,g,o (torch).
+ * fwd : gates[T,N,4H] holds X*W_ih^T + b_ih + b_hh on entry and the ACTIVATED gates on exit;
+ *       h_out[t] (row stride ldh; direction d writes columns [d*H,(d+1)*H) via its own pointer), c_all[T,N,H].
+ * bwd : w_hh_t is W_hh transposed, [H][4H]; dh_out = gradient w.r.t. h_out (same strides);
+ *       dgates[T,N,4H] = gradient w.r.t. the pre-activation gates; dc_ws[N,H] scratch.
+ */
+typedef struct {
+  float* gates;       /* [T,N,4H] */
+  const float* w_hh;  /* fwd: [4H,H]   bwd: W_hh^T [H,4H] */
+  float* h_out;       /* fwd: out [T,N,ldh]   bwd: unused */
+  float* c_all;       /* [T,N,H] */
+  const float* dh_out;/* bwd only: [T,N,ldh] */
+  float* dgates;      /* bwd only: [T,N,4H] */
+  float* dc_ws;       /* bwd only: [N,H] */
+  int reverse;        /* 0: t = 0..T-1, 1: t = T-1..0 */
+  int pad_;
+} dvae_lstm_dir_t;
+int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
+int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
+
+/* ---- reparameterise + latent assembly (disentangled_vae.py:222-228, 252-272) ----
+ * style[N,2S], content[N,2Cn] with N = 2*Bh (x1 rows then x2 rows); eps_c[N,Cn] (null => z = mu), eps_s[Bh,S].
+ * Outputs: z[N,S+Cn], q_mu[N,S+Cn], q_lv[N,S+Cn] (rows [0,Bh) = q_z1, [Bh,N) = q_z2), s_mu[Bh,S], s_lv[Bh,S].
+ * The x2 style head is detached (:257-258): its gradient rows are written as zero.
+ */
+int dvae_latent_fwd(const float* style, const float* content, const float* eps_c, const float* eps_s,
+                    float* z, float* q_mu, float* q_lv, float* s_mu, float* s_lv,
+                    int Bh, int S, int Cn, void* stream);
+int dvae_latent_bwd(const float* style, const float* content, const float* eps_c, const float* eps_s,
+                    const float* dz, const float* dq_mu, const float* dq_lv, const float* ds_mu,
+                    const float* ds_lv, float* dstyle, float* dcontent, int Bh, int S, int Cn, void* stream);
+
+/* ---- KL reduction (disentangled_vae.py:320-323): out[0] = scale * sum(1 + lv - mu^2 - exp(lv)) ---- */
+int dvae_kl_fwd(const float* mu, const float* lv, float* out, int64_t n, float scale, void* stream);
+/* dmu = g*scale*(-2mu), dlv = g*scale*(1-exp(lv)); g = *gout (device scalar) */
+int dvae_kl_bwd(const float* mu, const float* lv, const float* gout, float* dmu, float* dlv,
+                int64_t n, float scale, void* stream);
+
+/* ---- L1 reconstruction loss, reduction='sum' (disentangled_vae.py:314-318): out[0] = scale*sum|x-y| ----
+ * ws: >= dvae_l1_ws_bytes(n). */
+int64_t dvae_l1_ws_bytes(int64_t n);
+int dvae_l1_sum_fwd(const float* x, const float* y, float* out, void* ws, int64_t n, float scale, void* stream);
+/* dy = -sign(x-y) * g * scale */
+int dvae_l1_sum_bwd(const float* x, const float* y, const float* gout, float* dy, int64_t n, float scale,
+                    void* stream);
+
+/* ---- Adam over one flat parameter buffer (torch.optim.Adam at disentangled_vae.py:304) ----
+ * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). `step` is 1-based. */
+int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                   float beta2, float eps, float grad_scale, int step, void* stream);
+
+/* ---- layout plumbing ----
+ * dvae_mel_to_frames: x1,x2 [Bh,C,T] (torch layout, variational_base_vae.py:81-82) -> X[T, 2*Bh, C]; x2 may be
+ *   null (then N = Bh).  dvae_frames_to_mel is the inverse ([T,N,C] -> out[N,C,T]).
+ * dvae_permute_102: in[A,B,C] -> out[B,A,C]
+ * dvae_colsum_add: out1[c] += sum_r X[r,c] (and out2 if non-null); X row stride ld.
+ * dvae_transpose: in[R,C] -> out[C,R]
+ */
+int dvae_mel_to_frames(const float* x1, const float* x2, float* X, int Bh, int C, int T, void* stream);
+int dvae_frames_to_mel(const float* X, float* out, int N, int C, int T, void* stream);
+int dvae_permute_102(const float* in, float* out, int A, int B, int C, void* stream);
+int dvae_colsum_add(const float* X, float* out1, float* out2, int R, int C, int64_t ld, void* stream);
+int dvae_transpose(const float* in, float* out, int R, int C, void* stream);
+/* dU = dZ * act'(Z), Z = activation OUTPUT (ReLU after enc_linear, disentangled_vae.py:211); dU may alias dZ */
+/* Y = act(Y) in place (used after a split-K Linear) */
+int dvae_act_fwd(float* Y, int64_t n, int act, void* stream);
+int dvae_act_bwd(const float* dZ, const float* Z, float* dU, int64_t n, int act, void* stream);
+
+/* ---- opt-in per-family kernel timing with HIP events on the launch stream (bench.py roofline) ----
+ * family: 0 = off, 1 = GEMM/conv contraction kernel, 2 = LSTM step kernels.
+ * dvae_prof_collect: synchronises the recorded events, returns total ms, launch count and algorithmic FLOPs. */
+int dvae_prof_enable(int family);
+int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,330 @@
+"""Per-kernel parity of the HIP path (through the C ABI via dvae_amd.ops) against plain PyTorch fp32
+on the CPU.  Tolerances: fp32 contraction with a different summation order -> relative 2e-4 of the
+tensor's magnitude (north_star: 1e-4 on the loss scalars, checked in test_hip_model.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(got, ref, rel=2e-4, name=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    scale = max(1e-6, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= rel * scale, f"{name}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 72, 80), (16384, 512, 128), (8, 2048, 32), (130, 260, 516)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_nt_bias_act(ops, M, N, K, act):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    y = torch.empty(M, N, device="cuda")
+    ops.gemm(dev(x), dev(w), y, dev(b), M, N, K, K, K, N, True, True, act, ops.EPI_STORE, 1)
+    ref = x @ w.t() + b
+    ref = [ref, torch.relu(ref), torch.tanh(ref)][act]
+    close(y, ref, name="gemm_nt")
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(128, 2048, 8192, 16), (8, 56, 2048, 4), (256, 128, 1024, 2)])
+def test_gemm_nt_splitk_atomic(ops, M, N, K, sk):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    y = torch.zeros(M, N, device="cuda")
+    ops.gemm(dev(x), dev(w), y, dev(b), M, N, K, K, K, N, True, True, 0, ops.EPI_ATOMIC, sk)
+    close(y, x.double() @ w.double().t() + b.double(), name="gemm_splitk")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 80, 512), (16384, 128, 256)])
+def test_gemm_nn_dgrad(ops, M, N, K):
+    dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5)
+    dx = torch.empty(M, N, device="cuda")
+    ops.gemm(dev(dy), dev(w), dx, None, M, N, K, K, N, N, True, False)
+    close(dx, dy.double() @ w.double(), name="gemm_nn")
+    # accumulate epilogue
+    ops.gemm(dev(dy), dev(w), dx, None, M, N, K, K, N, N, True, False, 0, ops.EPI_ACCUM)
+    close(dx, 2 * (dy.double() @ w.double()), name="gemm_nn_accum")
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(256, 128, 512, 1), (80, 512, 1000, 4), (2048, 128, 16384, 8), (8, 2048, 6, 1)])
+def test_gemm_tn_wgrad(ops, M, N, K, sk):
+    dy, x = rnd(K, M, seed=6), rnd(K, N, seed=7)
+    base = rnd(M, N, seed=8)
+    dw = dev(base.clone())
+    ops.gemm(dev(dy), dev(x), dw, None, M, N, K, M, N, N, False, False, 0, ops.EPI_ATOMIC, sk)
+    close(dw, base.double() + dy.double().t() @ x.double(), name="gemm_tn")
+
+
+def test_gemm_rejects_bad_args(ops):
+    from dvae_amd._lib import DvaeHipError
+    a = torch.zeros(16, 6, device="cuda")
+    with pytest.raises(DvaeHipError):
+        ops.gemm(a, a, a, None, 16, 16, 6, 6, 6, 16, True, True)   # K % 4 != 0 for k-contiguous operands
+
+
+# ------------------------------------------------------------------ conv k5 on frame-major rows
+def to_frames(x):  # [N,C,T] -> [T*N, C]
+    N, Cc, T = x.shape
+    return x.permute(2, 0, 1).reshape(T * N, Cc).contiguous()
+
+
+def from_frames(y, N, T):  # [T*N, C] -> [N,C,T]
+    return y.reshape(T, N, -1).permute(1, 2, 0).contiguous()
+
+
+@pytest.mark.parametrize("N,T,Cin,Cout", [(8, 64, 80, 512), (6, 32, 512, 80), (128, 16, 512, 512), (3, 5, 80, 80)])
+def test_conv5_fwd_dgrad_wgrad(ops, N, T, Cin, Cout):
+    from dvae_amd._lib import check, lib, ptr, stream
+    L = lib()
+    x = rnd(N, Cin, T, seed=1).requires_grad_()
+    w = (rnd(Cout, Cin, 5, seed=2) * 0.1).requires_grad_()
+    b = rnd(Cout, seed=3)
+    y_ref = F.conv1d(x, w, b, padding=2)
+    gy = rnd(N, Cout, T, seed=4)
+    y_ref.backward(gy)
+
+    R = N * T
+    xf, wd = dev(to_frames(x.detach())), dev(w.detach())
+    wp = torch.empty(5, Cout, Cin, device="cuda")
+    check(L.dvae_conv_pack_w(ptr(wd), ptr(wp), Cout, Cin, stream()), "pack")
+    close(wp, w.detach().permute(2, 0, 1), rel=0, name="pack")
+    y = torch.empty(R, Cout, device="cuda")
+    check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(dev(b)), ptr(y), R, N, Cin, Cout, stream()), "fwd")
+    close(from_frames(y.cpu(), N, T), y_ref, name="conv_fwd")
+
+    gyf = dev(to_frames(gy))
+    dx = torch.empty(R, Cin, device="cuda")
+    check(L.dvae_conv5_dgrad(ptr(gyf), ptr(wp), ptr(dx), R, N, Cin, Cout, stream()), "dgrad")
+    close(from_frames(dx.cpu(), N, T), x.grad, name="conv_dgrad")
+
+    dwp = torch.zeros(5, Cout, Cin, device="cuda")
+    check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 4, stream()), "wgrad")
+    dw = torch.zeros(Cout, Cin, 5, device="cuda")
+    check(L.dvae_conv_unpack_add_w(ptr(dwp), ptr(dw), Cout, Cin, stream()), "unpack")
+    close(dw, w.grad, name="conv_wgrad")
+
+
+# ------------------------------------------------------------------ BatchNorm(train) + act, per group
+@pytest.mark.parametrize("N,T,Cc,G,act", [(8, 64, 512, 2, 1), (6, 32, 80, 2, 0), (4, 16, 512, 1, 2), (128, 8, 512, 2, 2)])
+def test_conv_bn_act_block(ops, N, T, Cc, G, act):
+    """Whole ConvBnActFn (conv + BN stats/apply + backward) against torch on CPU, two groups = two calls."""
+    Cin = 80
+    x = rnd(N, Cin, T, seed=1)
+    conv = torch.nn.Conv1d(Cin, Cc, 5, padding=2)
+    bn = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(Cc, Cin, 5, seed=2) * 0.2)
+        conv.bias.copy_(rnd(Cc, seed=3) * 0.5 + 1.0)      # a large mean: stresses the variance computation
+        bn.weight.copy_(rnd(Cc, seed=4, lo=0.5, hi=1.5))
+        bn.bias.copy_(rnd(Cc, seed=5) * 0.2)
+    fact = [lambda t: t, torch.relu, torch.tanh][act]
+    xr = x.clone().requires_grad_()
+    per = N // G
+    outs = [fact(bn(conv(xr[g * per:(g + 1) * per]))) for g in range(G)]   # sequential calls, like the reference
+    z_ref = torch.cat(outs, 0)
+    gz = rnd(N, Cc, T, seed=6)
+    z_ref.backward(gz)
+
+    P = lambda t: torch.nn.Parameter(dev(t.detach().clone()))
+    cw, cb, bw, bb = P(conv.weight), P(conv.bias), P(torch.ones(Cc)), P(torch.zeros(Cc))
+    with torch.no_grad():
+        bw.copy_(bn.weight)
+        bb.copy_(bn.bias)
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    xf = dev(to_frames(x)).requires_grad_()
+    z = ops.ConvBnActFn.apply(xf, cw, cb, bw, bb, rm, rv, nbt, None, N, G, act, True)
+    close(from_frames(z.detach().cpu(), N, T), z_ref, name="bn_fwd")
+    close(rm, bn.running_mean, rel=1e-4, name="running_mean")
+    close(rv, bn.running_var, rel=1e-4, name="running_var")
+    assert int(nbt.item()) == G
+    z.backward(dev(to_frames(gz)))
+    close(from_frames(xf.grad.cpu(), N, T), xr.grad, rel=5e-4, name="bn_dx")
+    close(cw.grad, conv.weight.grad, rel=5e-4, name="conv_w.grad")
+    close(bw.grad, bn.weight.grad, rel=5e-4, name="bn_w.grad")
+    close(bb.grad, bn.bias.grad, rel=5e-4, name="bn_b.grad")
+    assert float(cb.grad.abs().max()) < 1e-2 * max(1.0, float(gz.abs().sum()) ** 0.5)  # ~0 (cancels in BN)
+
+
+def test_bn_residual(ops):
+    N, T, Cc = 4, 16, 80
+    x = rnd(N, Cc, T, seed=1)
+    P = lambda t: torch.nn.Parameter(dev(t))
+    cw, cb = P(rnd(Cc, Cc, 5, seed=2) * 0.2), P(torch.zeros(Cc))
+    bw, bb = P(torch.ones(Cc)), P(torch.zeros(Cc))
+    xf = dev(to_frames(x)).requires_grad_()
+    nbt = torch.zeros((), dtype=torch.long, device="cuda")
+    z = ops.ConvBnActFn.apply(xf, cw, cb, bw, bb, torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda"),
+                              nbt, xf, N, 1, 0, True)
+    ref_in = x.clone().requires_grad_()
+    ref = ref_in + F.batch_norm(F.conv1d(ref_in, cw.detach().cpu(), None, padding=2), None, None, training=True)
+    close(from_frames(z.detach().cpu(), N, T), ref, name="residual_fwd")
+    gz = rnd(N, Cc, T, seed=3)
+    z.backward(dev(to_frames(gz)))
+    ref.backward(gz)
+    close(from_frames(xf.grad.cpu(), N, T), ref_in.grad, rel=5e-4, name="residual_dx")
+
+
+# ------------------------------------------------------------------ LSTM
+@pytest.mark.parametrize("N,T,In,H,bidir", [(8, 12, 512, 64, True), (128, 6, 128, 512, False), (6, 5, 512, 1024, False),
+                                            (20, 9, 128, 64, True)])
+def test_lstm_layer(ops, N, T, In, H, bidir):
+    ref = torch.nn.LSTM(In, H, 1, batch_first=True, bidirectional=bidir)
+    x = rnd(N, T, In, seed=1)
+    xr = x.clone().requires_grad_()
+    out_ref, _ = ref(xr)
+    gy = rnd(N, T, (2 if bidir else 1) * H, seed=2)
+    out_ref.backward(gy)
+
+    P = lambda t: torch.nn.Parameter(dev(t.detach().clone()))
+    names = ["weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"]
+    ps = [P(getattr(ref, n)) for n in names]
+    ps += [P(getattr(ref, n + "_reverse")) for n in names] if bidir else [None] * 4
+    xf = dev(x.permute(1, 0, 2).reshape(T * N, In)).requires_grad_()
+    h = ops.LstmLayerFn.apply(xf, T, N, *ps)
+    close(h.detach().cpu().reshape(T, N, -1).permute(1, 0, 2), out_ref, name="lstm_fwd")
+    h.backward(dev(gy.permute(1, 0, 2).reshape(T * N, -1)))
+    close(xf.grad.cpu().reshape(T, N, In).permute(1, 0, 2), xr.grad, rel=5e-4, name="lstm_dx")
+    for i, n in enumerate(names):
+        close(ps[i].grad, getattr(ref, n).grad, rel=5e-4, name=n)
+        if bidir:
+            close(ps[4 + i].grad, getattr(ref, n + "_reverse").grad, rel=5e-4, name=n + "_reverse")
+
+
+# ------------------------------------------------------------------ Linear
+@pytest.mark.parametrize("M,K,Nout,act", [(8, 8192, 2048, 1), (128, 2048, 56, 0), (8, 32, 2048, 0), (512, 1024, 80, 0)])
+def test_linear_fn(ops, M, K, Nout, act):
+    x = rnd(M, K, seed=1)
+    w, b = rnd(Nout, K, seed=2) * 0.05, rnd(Nout, seed=3)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y_ref = F.linear(xr, wr, br)
+    y_ref = torch.relu(y_ref) if act else y_ref
+    gy = rnd(M, Nout, seed=4)
+    y_ref.backward(gy)
+    xd = dev(x).requires_grad_()
+    wd, bd = torch.nn.Parameter(dev(w)), torch.nn.Parameter(dev(b))
+    y = ops.LinearFn.apply(xd, wd, bd, act)
+    close(y, y_ref, name="linear_fwd")
+    y.backward(dev(gy))
+    close(xd.grad, xr.grad, rel=5e-4, name="linear_dx")
+    close(wd.grad, wr.grad, rel=5e-4, name="linear_dw")
+    close(bd.grad, br.grad, rel=5e-4, name="linear_db")
+
+
+# ------------------------------------------------------------------ latent / KL / L1 / Adam / layout
+def test_latent_kl_l1(ops):
+    Bh, S, Cn = 5, 4, 28
+    style, content = rnd(2 * Bh, 2 * S, seed=1), rnd(2 * Bh, 2 * Cn, seed=2)
+    e1, e2, es = rnd(Bh, Cn, seed=3), rnd(Bh, Cn, seed=4), rnd(Bh, S, seed=5)
+    sr, cr = style.clone().requires_grad_(), content.clone().requires_grad_()
+    s_mu1, s_lv1, s_mu2, s_lv2 = sr[:Bh, :S], sr[:Bh, S:], sr[Bh:, :S].detach(), sr[Bh:, S:].detach()
+    smu, slv = (s_mu1 + s_mu2) / 2, (s_lv1 + s_lv2) / 2
+    zs = es * torch.exp(0.5 * slv) + smu
+    zc1 = e1 * torch.exp(0.5 * cr[:Bh, Cn:]) + cr[:Bh, :Cn]
+    zc2 = e2 * torch.exp(0.5 * cr[Bh:, Cn:]) + cr[Bh:, :Cn]
+    z_ref = torch.cat((torch.cat((zs, zc1), -1), torch.cat((zs, zc2), -1)), 0)
+    q1mu, q1lv = torch.cat((smu, cr[:Bh, :Cn]), -1), torch.cat((slv, cr[:Bh, Cn:]), -1)
+    q2mu, q2lv = torch.cat((smu, cr[Bh:, :Cn]), -1), torch.cat((slv, cr[Bh:, Cn:]), -1)
+    kl = lambda mu, lv: 1 + lv - mu.pow(2) - lv.exp()
+    wz = rnd(2 * Bh, S + Cn, seed=6)
+    loss_ref = (z_ref * wz).sum() + (-0.5) * kl(q1mu, q1lv).sum(-1).mean() + (-0.5) * kl(q2mu, q2lv).sum(-1).mean() \
+        + 3.0 * (-kl(smu, slv).sum() / 7.0)
+    loss_ref.backward()
+
+    sd, cd = dev(style).requires_grad_(), dev(content).requires_grad_()
+    z, q_mu, q_lv, s_mu, s_lv = ops.LatentFn.apply(sd, cd, dev(torch.cat((e1, e2), 0)), dev(es), Bh, S, Cn)
+    close(z, z_ref, name="z")
+    close(q_mu[:Bh], q1mu, name="q1mu")
+    close(q_lv[Bh:], q2lv, name="q2lv")
+    close(s_mu, smu, name="smu")
+    k1 = ops.KlFn.apply(q_mu[:Bh], q_lv[:Bh], -0.5 / Bh)
+    k2 = ops.KlFn.apply(q_mu[Bh:], q_lv[Bh:], -0.5 / Bh)
+    k3 = ops.KlFn.apply(s_mu, s_lv, -1.0 / 7.0)
+    loss = (z * dev(wz)).sum() + k1 + k2 + 3.0 * k3
+    close(loss, loss_ref, rel=1e-5, name="latent loss")
+    loss.backward()
+    close(sd.grad, sr.grad, rel=1e-4, name="dstyle")
+    close(cd.grad, cr.grad, rel=1e-4, name="dcontent")
+    assert float(sd.grad[Bh:].abs().max()) == 0.0   # x2 style head is detached
+
+
+@pytest.mark.parametrize("n", [655360, 1003, 4])
+def test_l1_sum(ops, n):
+    x, y = rnd(n, seed=1, lo=0, hi=1), rnd(n, seed=2)
+    yr = y.clone().requires_grad_()
+    ref = (x - yr).abs().sum() / 64.0
+    (ref * 10.0).backward()
+    yd = dev(y).requires_grad_()
+    out = ops.L1SumFn.apply(dev(x), yd, 1.0 / 64.0)
+    close(out, ref.double(), rel=1e-5, name="l1")
+    (out * 10.0).backward()
+    close(yd.grad, yr.grad, rel=1e-6, name="l1 grad")
+
+
+def test_adam_flat_matches_torch(ops):
+    from dvae_amd.optim import FlatAdam
+    ps = [torch.nn.Parameter(rnd(37, 5, seed=1)), torch.nn.Parameter(rnd(1001, seed=2)), torch.nn.Parameter(rnd(4, 4, seed=3))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    dps = [torch.nn.Parameter(dev(p.detach().clone())) for p in ps]
+    opt_ref = torch.optim.Adam(ref, lr=1e-3)
+    opt = FlatAdam(dps, lr=1e-3)
+    for it in range(3):
+        opt.zero_grad()
+        for k, (p, r) in enumerate(zip(dps, ref)):
+            g = rnd(*p.shape, seed=10 * it + k) * (10.0 ** (k - 1))
+            r.grad = g.clone()
+            p.grad.add_(dev(g))
+        opt_ref.step()
+        opt.step()
+    for p, r in zip(dps, ref):
+        close(p, r, rel=1e-5, name="adam")
+
+
+def test_layouts(ops):
+    from dvae_amd._lib import check, lib, ptr, stream
+    Bh, Cc, T = 3, 80, 50
+    x1, x2 = rnd(Bh, Cc, T, seed=1), rnd(Bh, Cc, T, seed=2)
+    X = ops.mel_to_frames(dev(x1), dev(x2))
+    ref = torch.cat((x1, x2), 0).permute(2, 0, 1).reshape(T * 2 * Bh, Cc)
+    close(X, ref, rel=0, name="mel_to_frames")
+    back = ops.FramesToMelFn.apply(X, 2 * Bh, Cc, T)
+    close(back, torch.cat((x1, x2), 0), rel=0, name="frames_to_mel")
+    a = rnd(7, 5, 128, seed=3)
+    out = ops.Permute102Fn.apply(dev(a), 7, 5, 128, (5, 7, 128))
+    close(out, a.permute(1, 0, 2), rel=0, name="permute")
+    t = rnd(100, 260, seed=4)
+    close(ops.transpose2d(dev(t)), t.t(), rel=0, name="transpose")
+    acc = torch.zeros(260, device="cuda")
+    ops.colsum_add(dev(t), acc)
+    close(acc, t.sum(0), rel=1e-5, name="colsum")
+
+
+def test_prof_hooks(ops):
+    ops.prof_enable(1)
+    x, w = dev(rnd(256, 64, seed=1)), dev(rnd(128, 64, seed=2))
+    y = torch.empty(256, 128, device="cuda")
+    for _ in range(3):
+        ops.gemm(x, w, y, None, 256, 128, 64, 64, 64, 128, True, True)
+    ms, n, fl = ops.prof_collect()
+    ops.prof_enable(0)
+    assert n == 3 and ms > 0 and fl == 3 * 2.0 * 256 * 128 * 64

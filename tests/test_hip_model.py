@@ -1,0 +1,182 @@
+"""Whole-path parity of the HIP DisentangledVAE / ConvolutionalMulVAE (through the C ABI) against
+(a) the golden vectors recorded from the real reference and (b) the CPU oracle on the same seeded
+inputs.  Tolerance on the 8 loss scalars: 1e-4 relative (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.dvae_ref import RefTrainer, loss_gvae2
+from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+LOSS_RTOL = 1e-4
+FW = ["recons_x1", "recons_x2", "recons_x1_hat", "recons_x2_hat", "q_z1_mu", "q_z1_logvar",
+      "q_z2_mu", "q_z2_logvar", "z_style_mu", "z_style_logvar"]
+
+
+def make(batch, n_frames, lr=1e-4):
+    import dvae_amd
+    w = dvae_amd.ConvolutionalMulVAE("VCTK", n_frames, 80, 32, lr, 0.01, 500, False, batch_size=batch,
+                                     speaker_size=4, device=torch.device("cuda"), latent_dim=32, mse_cof=10,
+                                     kl_cof=10)
+    w.model.load_state_dict(fill_state_dict(w.model.state_dict()))
+    assert w.optimizer.views_intact()
+    w.model.train()
+    return w
+
+
+def rel(a, b):
+    return abs(a - b) / max(1e-12, abs(b))
+
+
+@pytest.mark.parametrize("name", ["c0_b4_t64", "b3_t64", "b2_t128"])
+def test_against_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, T = int(g["batch"]), int(g["n_frames"])
+    w = make(B, T)
+    assert [n for n, _ in w.model.named_parameters()] == list(g["param_names"])
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, int(g["seed"])))
+    w.model.eps_override = tuple(torch.from_numpy(g[k]) for k in ("eps_c1", "eps_c2", "eps_s"))
+    w.optimizer.zero_grad()
+    outs = w.model(x1, x2)
+    losses = w.loss_functionGVAE2(x1, x2, *outs, train=True)
+    got = [float(v) for v in torch.stack([l.detach() for l in losses]).tolist()]
+    for i, (a, b) in enumerate(zip(got, g["losses_fwd"])):
+        assert rel(a, b) <= LOSS_RTOL, f"loss[{i}] {a} vs reference {b}"
+    for n, t in zip(FW, outs):
+        t = t.detach().cpu()
+        if "fw_" + n in g.files:
+            np.testing.assert_allclose(t.numpy(), g["fw_" + n], rtol=2e-3, atol=2e-4)
+        else:
+            assert rel(float(t.double().abs().sum()), float(g["fw_" + n + "_abs"])) <= 1e-4
+            np.testing.assert_allclose(t[:, ::16, ::8].numpy(), g["fw_" + n + "_slice"], rtol=5e-3, atol=5e-4)
+    losses[0].backward()
+    gn = np.array([float(p.grad.double().norm()) for _, p in w.model.named_parameters()])
+    ref = g["grad_norm"]
+    big = ref > 1e-3
+    np.testing.assert_allclose(gn[big], ref[big], rtol=5e-3)
+    assert np.all(gn[~big] < 5e-2)   # conv biases in front of BatchNorm: zero up to round-off on both sides
+    for k in g.files:
+        if k.startswith("g_"):
+            p = dict(w.model.named_parameters())[k[2:]]
+            scale = max(1e-6, float(np.abs(g[k]).max()))
+            assert float(np.abs(p.grad.cpu().numpy() - g[k]).max()) <= 5e-3 * scale, k
+        if k.startswith("bn_"):
+            v = w.model.state_dict()[k[3:]].cpu().numpy()
+            np.testing.assert_allclose(v, g[k], rtol=2e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["c0_b4_t64", "b2_t128"])
+def test_two_steps_against_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    B, T = int(g["batch"]), int(g["n_frames"])
+    w = make(B, T)
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, int(g["seed"])))
+    w.model.eps_override = tuple(torch.from_numpy(g[k]) for k in ("eps_c1", "eps_c2", "eps_s"))
+    s1 = w.step(x1, x2, None, train=True)
+    w.model.eps_override = tuple(torch.from_numpy(g[k]) for k in ("eps2_c1", "eps2_c2", "eps2_s"))
+    s2 = w.step(x2, x1, None, train=True)
+    for i in range(8):
+        assert rel(s1[i], g["step1"][i]) <= LOSS_RTOL, (i, s1[i], g["step1"][i])
+    # second step runs on Adam-updated weights (|update| = lr per weight, sign-driven): looser
+    for i in range(8):
+        assert rel(s2[i], g["step2"][i]) <= 5e-4, (i, s2[i], g["step2"][i])
+    pn = np.array([float(p.detach().double().norm()) for _, p in w.model.named_parameters()])
+    np.testing.assert_allclose(pn, g["param_norm_after2"], rtol=1e-3, atol=2e-3)
+
+
+def test_against_oracle_b8_t64_full_gradients():
+    """Every parameter gradient, elementwise, against the CPU oracle (B=8, T=64)."""
+    B, T = 8, 64
+    w = make(B, T)
+    tr = RefTrainer(B, n_frames=T)
+    tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
+    tr.model.train()
+    x1, x2 = synthetic_pair(B, T, 77)
+    eps = synthetic_eps(B, seed=5)
+    outs_ref = tr.model(x1, x2, eps)
+    l_ref = loss_gvae2(x1, x2, outs_ref, B)
+    l_ref[0].backward()
+    w.model.eps_override = eps
+    w.optimizer.zero_grad()
+    outs = w.model(x1.cuda(), x2.cuda())
+    l = w.loss_functionGVAE2(x1.cuda(), x2.cuda(), *outs, train=True)
+    l[0].backward()
+    for i in range(8):
+        assert rel(float(l[i]), float(l_ref[i])) <= LOSS_RTOL, (i, float(l[i]), float(l_ref[i]))
+    for a, b in zip(outs, outs_ref):
+        scale = max(1e-6, float(b.abs().max()))
+        assert float((a.detach().cpu() - b.detach()).abs().max()) <= 2e-3 * scale
+    ref_params = dict(tr.model.named_parameters())
+    bad = []
+    for n, p in w.model.named_parameters():
+        gr = ref_params[n].grad
+        scale = float(gr.abs().max())
+        err = float((p.grad.cpu() - gr).abs().max())
+        if scale < 1e-3:           # pre-BatchNorm conv biases: zero gradient up to round-off
+            if err > 5e-2:
+                bad.append((n, err, scale))
+        elif err > 5e-3 * scale:
+            bad.append((n, err, scale))
+    assert not bad, bad
+
+
+def test_full_size_properties_b64_t128():
+    """BASELINE config[1] size (B=64, T=128): properties that need no CPU oracle run.
+    * finite losses, loss decreases over a few Adam steps on a fixed batch;
+    * linearity of the loss normalisation: L1 terms scale with 1/batch_size (configured), KL terms do not;
+    * pair symmetry: swapping x1<->x2 (and the eps) swaps the per-utterance losses."""
+    B, T = 64, 128
+    w = make(B, T)
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 1234))
+    eps = synthetic_eps(B, seed=3)
+    w.model.eps_override = eps
+    with torch.no_grad():
+        w.model.eval()     # eval BatchNorm so the symmetry check is exact w.r.t. running-stat updates
+        outs = w.model(x1, x2)
+        la = [float(v) for v in w.loss_functionGVAE2(x1, x2, *outs)]
+        w.model.eps_override = (eps[1], eps[0], eps[2])
+        outs_s = w.model(x2, x1)
+        lb = [float(v) for v in w.loss_functionGVAE2(x2, x1, *outs_s)]
+    assert rel(la[1], lb[2]) < 1e-5 and rel(la[2], lb[1]) < 1e-5 and rel(la[3], lb[4]) < 1e-5
+    assert rel(la[5], lb[6]) < 1e-5
+    w.batch_size = 32
+    with torch.no_grad():
+        lc = [float(v) for v in w.loss_functionGVAE2(x2, x1, *outs_s)]
+    assert rel(lc[1], 2 * lb[1]) < 1e-6 and rel(lc[5], lb[5]) < 1e-6
+    w.batch_size = B
+    w.model.train()
+    w.model.eps_override = eps
+    hist = [w.step(x1, x2, None, train=True)[0] for _ in range(4)]
+    assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+
+
+def test_encode_decode_postnet_api():
+    """The standalone entry points voice conversion uses (variational_base_vae.py:278-293), eval mode."""
+    import dvae_amd
+    B, T = 3, 64
+    w = make(B, T)
+    tr = RefTrainer(B, n_frames=T)
+    tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
+    w.model.eval()
+    tr.model.eval()
+    x1, _ = synthetic_pair(B, T, 5)
+    with torch.no_grad():
+        a = w.model.encode(x1.cuda())
+        b = tr.model.encode(x1)
+        for u, v in zip(a, b):
+            np.testing.assert_allclose(u.cpu().numpy(), v.numpy(), rtol=2e-3, atol=2e-4)
+        z = torch.cat((b[0], b[2]), -1)
+        r, r_ref = w.model.decode(z.cuda()), tr.model.decode(z)
+        np.testing.assert_allclose(r.cpu().numpy(), r_ref.numpy(), rtol=2e-3, atol=2e-4)
+        p, p_ref = w.model.postnet(r_ref.cuda()), tr.model.postnet(r_ref)
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref.numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_cpu_input_fails_loudly():
+    w = make(2, 64)
+    x1, x2 = synthetic_pair(2, 64, 1)
+    with pytest.raises(RuntimeError):
+        w.model(x1, x2)
