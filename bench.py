@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterance pairs/sec of the disentangled-VAE TRAINING STEP
+(zero_grad + forward + loss + backward + [grad all-reduce] + Adam) on synthetic [B=64, 80-mel, T=128]
+per GPU, fp32, through the HIP path (BASELINE.json configs[1]; weak scaling for N > 1: B=64 per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant kernel family = the fp32-MFMA contraction kernel (gemm_f32_kernel: every Linear, LSTM input
+               projection, weight gradient and k5 conv).  achieved = algorithmic FLOPs of its launches / their summed
+               duration, measured with HIP events recorded on the launch stream around every launch INSIDE the
+               timed region (dvae_prof_*); peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline the CPU oracle (oracle/dvae_ref.py, the verified restatement of the reference's PyTorch-CPU step)
+               timed on this box's host cores on the same workload, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def algorithmic_flops_per_pair(T):
+    # 3 (fwd+bwd) * 2 segments * 2 FLOP/MAC * (28 090 368 * T + 196 608)
+    return 3 * 2 * 2 * (28090368 * T + 196608)
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def _cpu_baseline_child(batch, frames, steps, threads):
+    """Runs in a CHILD process (never touches the GPU): times the CPU oracle's train step."""
+    torch.set_num_threads(threads)
+    from oracle.dvae_ref import RefTrainer
+    from oracle.fill import synthetic_pair
+    tr = RefTrainer(batch, n_frames=frames)
+    x1, x2 = synthetic_pair(batch, frames, 1234)
+    g = torch.Generator().manual_seed(0)
+    tr.step(x1, x2, tr.draw_eps(batch, g), train=True)   # warm-up
+    ts = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tr.step(x1, x2, tr.draw_eps(batch, g), train=True)
+        ts.append(time.perf_counter() - t0)
+    print("CPU_BASELINE " + json.dumps({"times": ts, "threads": torch.get_num_threads()}), flush=True)
+
+
+def cpu_baseline(batch, frames, steps=2, timeout_s=240):
+    """The oracle (kind "port") on this box's host cores, in a child process with a hard timeout so that a slow
+    or oversubscribed host can never hang the benchmark.  Threads = physical cores available to the process,
+    capped at 64 (beyond that the oneDNN/MKL LSTM and conv kernels of this size stop scaling)."""
+    import subprocess
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--batch", str(batch), "--frames",
+           str(frames), "--steps", str(steps), "--threads", str(threads)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "utterances/sec", "cores": threads, "kind": "port",
+                "sample": f"timed out after {timeout_s}s (1 warm-up + {steps} steps of B={batch}, T={frames})"}
+    line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+    if not line:
+        return {"value": None, "unit": "utterances/sec", "cores": threads, "kind": "port",
+                "sample": "child failed: " + (r.stderr or "")[-300:]}
+    d = json.loads(line[-1][len("CPU_BASELINE "):])
+    best = sorted(d["times"])[len(d["times"]) // 2]
+    return {"value": batch / best, "unit": "utterances/sec", "cores": d["threads"], "kind": "port",
+            "sample": f"median of {steps} full train steps (B={batch}, T={frames}, fp32, PyTorch-CPU oracle) after "
+                      f"1 warm-up; {best * 1e3:.0f} ms/step; host has {cores} cores", "ms_per_step": best * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
+    ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_child:
+        _cpu_baseline_child(args.batch, args.frames, args.steps, args.threads)
+        return
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dvae_amd
+    from dvae_amd import ddp, ops
+    from dvae_amd.data import SyntheticPairs
+
+    B, T = args.batch, args.frames
+    torch.manual_seed(1234)
+    w = dvae_amd.ConvolutionalMulVAE("VCTK", T, 80, 32, 1e-4, 0.01, 500, False, batch_size=B, speaker_size=4,
+                                     device=dev, latent_dim=32, mse_cof=10, kl_cof=10)
+    w.model.train()
+    if world > 1:
+        ddp.broadcast_parameters(w.optimizer.flat_p, [b for b in w.model.buffers()])
+        red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets)
+        w.attach_reducer(red)
+    data = SyntheticPairs(B, T, n_speakers=10, seed=1234 + rank, device=dev)
+    x1, x2, spk = data.batch()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"rank {rank}/{world}: model built ({sum(p.numel() for p in w.model.parameters())} params), warm-up x{args.warmup}")
+    for _ in range(args.warmup):
+        w.step(x1, x2, spk, train=True)
+    barrier()
+    log("timed region start")
+    if not args.no_roofline:
+        ops.prof_enable(1)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = w.step(x1, x2, spk, train=True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
+    roof = None
+    if not args.no_roofline:
+        ms, launches, flops = ops.prof_collect()
+        ops.prof_enable(0)
+        if ms > 0:
+            ach = flops / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": None, "launches_per_step": launches / args.steps,
+                    "kernel_ms_per_step": ms / args.steps, "avg_launch_us": 1e3 * ms / max(1, launches),
+                    "flops_per_step": flops / args.steps}
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        value = world * B * args.steps / elapsed
+        step_flops = algorithmic_flops_per_pair(T) * B
+        out = {"metric": "utterances/sec (B=64, 80-mel, T=128) train step", "value": value, "unit": "utterances/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic U[0,1) mel pairs, random-init weights",
+               "config": {"workload": f"configs[1]: fp32 train step, B={B} pairs/GPU, 80-mel, T={T}, "
+                                      "10 synthetic speakers, speaker_size=4, latent=32, Adam lr=1e-4",
+                          "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
+                          "params": sum(p.numel() for p in w.model.parameters())},
+               "step_tflops_algorithmic": step_flops / 1e12,
+               "step_frac_of_fp32_mfma_peak": step_flops / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+               "final_loss": last[0] if last else None}
+        if roof:
+            out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            log("timing the CPU oracle on the host cores (child process, bounded)")
+            cb = cpu_baseline(B, T)
+            out["cpu_baseline"] = cb
+            if cb.get("value"):
+                out["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
