@@ -4,18 +4,28 @@
 // projections and weight gradients, and the k=5 Conv1d as an implicit GEMM over frame-major rows
 // (a tap is a row shift of +-N*(tap-2), so padding is a plain range check on the row index).
 //
-// Tile: 128x128x16 per 256-thread workgroup (4 waves as 2x2, each wave 2x2 MFMA tiles of 32x32,
-// 64 accumulator VGPRs).  Operands are staged global -> registers -> LDS in a k-major image
-// [BK][128+pad] so that one ds_read_b32 per lane feeds an MFMA operand: lanes 0-31 read 32
-// consecutive floats of k-row 2s, lanes 32-63 of k-row 2s+1 (the A[i][k]/B[k][j] lane map of
-// the 32x32x2 instruction) — conflict-free.  fp32 MFMA issues once per 64 cycles per SIMD, so
-// LDS bandwidth is far from critical and the structure stays simple: register prefetch of the
-// next tile, two LDS buffers, one barrier per k-tile.
+// Tile: 128 x (64*NTW) x BK per 256-thread workgroup (4 waves as 2x2, each wave 2 x NTW MFMA tiles of
+// 32x32, 32*NTW accumulator registers).  Operands go global -> registers -> LDS, with the next k-tile's
+// global loads in flight under the current tile's MFMAs, two LDS buffers, one barrier per k-tile.
+// Per-thread source pointers and tap-validity masks are computed once; a k-tile costs one pointer
+// increment per load, so the VALU stream between two MFMA blocks stays short.
+//
+// LDS images (chosen per operand by its memory layout, so staging never transposes):
+//   k-contiguous operand ([rows][K] in memory): image [rows][BK + 4 pad]; staged with ds_write_b128,
+//     read with BK/8 ds_read_b128 per 32-row MFMA tile per k-tile (row stride 20 or 36 floats: the
+//     16-lane groups of a b128 read hit 16 distinct 4-bank slots -> conflict-free).
+//   row-contiguous operand ([K][rows] in memory): image [BK][rows + 4 pad]; staged with ds_write_b128
+//     along rows, read with ds_read_b32 (32 consecutive floats per half-wave -> conflict-free).
+// Both reads use the SAME k order: MFMA step (c, e), e = 0..3, consumes k = 8c + 4*(lane>>5) + e
+// on both operands (a permutation of the k order inside the tile, identical for A and B, so the dot
+// product is unchanged).  All of a k-tile's fragments are fetched before its MFMAs are issued, so the
+// matrix pipe runs back to back instead of paying one LDS round trip per k-step.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, NTHR = 256;
+constexpr int BM = 128, NTHR = 256;   // BN = 64 * NTW (template): 128 or 64 ; BK (template): 16 or 32
 
 struct GemmParams {
   const float* A;
@@ -31,17 +41,25 @@ struct GemmParams {
   int64_t bk_row_shift;  // mode 2: B k-row offset per (tap-2)
   int64_t c_tap_stride;  // mode 2: elements between per-tap C matrices
   int split_k;
-  int k_per_split;       // multiple of BK
+  int k_per_split;       // multiple of the k-tile
   int act, epi;
   int tiles_m;
 };
 
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, int NTW, int BK>
 __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
-  constexpr int LDA = A_KC ? 129 : 132;
-  constexpr int LDB = B_KC ? 129 : 132;
-  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  constexpr int BN = 64 * NTW;           // NTW = 32-wide n-tiles per wave
+  constexpr int LD_KC = BK + 4;          // row stride of a k-contiguous image
+  constexpr int LDA = A_KC ? LD_KC : BM + 4;
+  constexpr int LDB = B_KC ? LD_KC : BN + 4;
+  constexpr int A_SZ = A_KC ? BM * LD_KC : BK * (BM + 4);
+  constexpr int B_SZ = B_KC ? BN * LD_KC : BK * (BN + 4);
+  constexpr int NLA = BM * BK / 4 / NTHR;   // float4 per thread per k-tile (A)
+  constexpr int NLB = BN * BK / 4 / NTHR;   // (B)
+  constexpr int KQ = BK / 4;                // float4 per row of a k-contiguous tile
+  constexpr int NC = BK / 8;                // 8-deep k groups per tile
+  __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs[2][B_SZ];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -59,64 +77,96 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
   }
   const int k_begin = ks * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int kiters = (k_end - k_begin + BK - 1) / BK;
+  const int klen = k_end - k_begin;
+  const int kiters = (klen + BK - 1) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
 
   float* __restrict__ C = p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
-  f32x4 ra[2], rb[2];
-
-  auto load_tiles = [&](int it) {
-    int tap = 0, kit = it;
-    if (p.tap_mode == 1) {
-      tap = it / kiters;
-      kit = it - tap * kiters;
-    }
-    const int k0 = k_begin + kit * BK;
-    // ---- A ----
+  // ---- per-thread source descriptors, computed once
+  const float* a_src[NLA];
+  unsigned a_ok[NLA];   // bit `tap` set: the (shifted) source row exists
+  int a_k[NLA];         // this load's k offset inside the tile (bound check against klen)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = t + NTHR * j;
+  for (int j = 0; j < NLA; ++j) {
+    const int idx = t + NTHR * j;
+    if (A_KC) {
+      const int row = idx / KQ, kq = idx % KQ;
+      const int64_t m = m0 + row;
+      a_k[j] = 4 * kq;
+      a_src[j] = p.A + m * p.lda + k_begin + 4 * kq;
+      unsigned ok = 0;
+      if (m < p.M) {
+        if (p.tap_mode == 1) {
+#pragma unroll
+          for (int tp = 0; tp < 5; ++tp) {
+            const int64_t ms = m + (int64_t)(tp - 2) * p.a_row_shift;
+            ok |= (ms >= 0 && ms < p.M) ? (1u << tp) : 0u;
+          }
+        } else {
+          ok = 1u;
+        }
+      }
+      a_ok[j] = ok;
+    } else {
+      const int kr = idx >> 5, m4 = idx & 31;
+      a_k[j] = kr;
+      a_src[j] = p.A + (int64_t)(k_begin + kr) * p.lda + m0 + 4 * m4;
+      a_ok[j] = (m0 + 4 * m4 < p.M) ? 1u : 0u;
+    }
+  }
+  const float* b_src[NLB];
+  unsigned b_ok[NLB];
+  int b_k[NLB];
+#pragma unroll
+  for (int j = 0; j < NLB; ++j) {
+    const int idx = t + NTHR * j;
+    if (B_KC) {
+      const int row = idx / KQ, kq = idx % KQ;
+      b_k[j] = 4 * kq;
+      b_src[j] = p.B + (int64_t)(n0 + row) * p.ldb + k_begin + 4 * kq;
+      b_ok[j] = (n0 + row < p.N) ? 1u : 0u;
+    } else {
+      const int kr = idx / (BN / 4), n4 = idx % (BN / 4);
+      b_k[j] = kr;
+      const int64_t shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
+      b_src[j] = p.B + ((int64_t)(k_begin + kr) + shift) * p.ldb + n0 + 4 * n4;
+      b_ok[j] = (n0 + 4 * n4 < p.N) ? 1u : 0u;
+    }
+  }
+  const int64_t b_shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
+
+  f32x4 ra[NLA], rb[NLB];
+
+  // (tap, kit) of the tile being fetched; uniform
+  auto load_tiles = [&](int tap, int kit) {
+    const int kofs = kit * BK;
+    const int64_t a_tap = (p.tap_mode == 1) ? (int64_t)(tap - 2) * p.a_row_shift * p.lda : 0;
+    const int64_t b_tap = (p.tap_mode == 1) ? (int64_t)tap * p.b_tap_stride : 0;
+#pragma unroll
+    for (int j = 0; j < NLA; ++j) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (A_KC) {
-        const int row = idx >> 2, kq = idx & 3;
-        const int k = k0 + 4 * kq;
-        int64_t m = m0 + row;
-        bool ok = (m < p.M) && (k < k_end);
-        if (p.tap_mode == 1) {
-          m += (int64_t)(tap - 2) * p.a_row_shift;
-          ok = ok && (m >= 0) && (m < p.M);
-        }
-        if (ok) v = *reinterpret_cast<const f32x4*>(p.A + m * p.lda + k);
+        if (((a_ok[j] >> tap) & 1u) && (kofs + a_k[j] < klen))
+          v = *reinterpret_cast<const f32x4*>(a_src[j] + a_tap + kofs);
       } else {
-        const int kr = idx >> 5, m4 = idx & 31;
-        const int k = k0 + kr;
-        const int m = m0 + 4 * m4;
-        if (k < k_end && m < p.M) v = *reinterpret_cast<const f32x4*>(p.A + (int64_t)k * p.lda + m);
+        if (a_ok[j] && (kofs + a_k[j] < klen))
+          v = *reinterpret_cast<const f32x4*>(a_src[j] + (int64_t)kofs * p.lda);
       }
       ra[j] = v;
     }
-    // ---- B ----
-    const float* __restrict__ Bp = p.B + (p.tap_mode == 1 ? (int64_t)tap * p.b_tap_stride : 0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int idx = t + NTHR * j;
+    for (int j = 0; j < NLB; ++j) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (B_KC) {
-        const int row = idx >> 2, kq = idx & 3;
-        const int k = k0 + 4 * kq;
-        const int n = n0 + row;
-        if (n < p.N && k < k_end) v = *reinterpret_cast<const f32x4*>(Bp + (int64_t)n * p.ldb + k);
+        if (b_ok[j] && (kofs + b_k[j] < klen)) v = *reinterpret_cast<const f32x4*>(b_src[j] + b_tap + kofs);
       } else {
-        const int kr = idx >> 5, n4 = idx & 31;
-        int64_t k = k0 + kr;
-        const int n = n0 + 4 * n4;
-        bool ok = (k < k_end) && (n < p.N);
+        bool ok = b_ok[j] && (kofs + b_k[j] < klen);
         if (p.tap_mode == 2) {
-          k += (int64_t)(tap_fixed - 2) * p.bk_row_shift;
-          ok = ok && (k >= 0) && (k < p.K);
+          const int64_t kk = (int64_t)k_begin + kofs + b_k[j] + b_shift;
+          ok = ok && (kk >= 0) && (kk < p.K);
         }
-        if (ok) v = *reinterpret_cast<const f32x4*>(Bp + k * p.ldb + n);
+        if (ok) v = *reinterpret_cast<const f32x4*>(b_src[j] + b_tap + (int64_t)kofs * p.ldb);
       }
       rb[j] = v;
     }
@@ -124,61 +174,107 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
 
   auto store_tiles = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NLA; ++j) {
       const int idx = t + NTHR * j;
       if (A_KC) {
-        const int row = idx >> 2, kq = idx & 3;
-        float* d = &As[buf][(4 * kq) * LDA + row];
-        d[0] = ra[j][0];
-        d[LDA] = ra[j][1];
-        d[2 * LDA] = ra[j][2];
-        d[3 * LDA] = ra[j][3];
+        const int row = idx / KQ, kq = idx % KQ;
+        *reinterpret_cast<f32x4*>(&As[buf][row * LDA + 4 * kq]) = ra[j];
       } else {
         const int kr = idx >> 5, m4 = idx & 31;
         *reinterpret_cast<f32x4*>(&As[buf][kr * LDA + 4 * m4]) = ra[j];
       }
+    }
+#pragma unroll
+    for (int j = 0; j < NLB; ++j) {
+      const int idx = t + NTHR * j;
       if (B_KC) {
-        const int row = idx >> 2, kq = idx & 3;
-        float* d = &Bs[buf][(4 * kq) * LDB + row];
-        d[0] = rb[j][0];
-        d[LDB] = rb[j][1];
-        d[2 * LDB] = rb[j][2];
-        d[3 * LDB] = rb[j][3];
+        const int row = idx / KQ, kq = idx % KQ;
+        *reinterpret_cast<f32x4*>(&Bs[buf][row * LDB + 4 * kq]) = rb[j];
       } else {
-        const int kr = idx >> 5, n4 = idx & 31;
+        const int kr = idx / (BN / 4), n4 = idx % (BN / 4);
         *reinterpret_cast<f32x4*>(&Bs[buf][kr * LDB + 4 * n4]) = rb[j];
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NTW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  int tap_n = 0, kit_n = 0;   // next tile to fetch
+  auto advance = [&]() {
+    if (++kit_n == kiters) {
+      kit_n = 0;
+      ++tap_n;
+    }
+  };
   if (n_iters > 0) {
-    load_tiles(0);
+    load_tiles(tap_n, kit_n);
+    advance();
     store_tiles(0);
   }
   __syncthreads();
 
+  // fragment read bases (constant across k-tiles)
+  const int a_frag = A_KC ? (wm * 64 + l31) * LDA + 4 * kh : (4 * kh) * LDA + wm * 64 + l31;
+  const int b_frag = B_KC ? (wn * 32 * NTW + l31) * LDB + 4 * kh : (4 * kh) * LDB + wn * 32 * NTW + l31;
+
   int cur = 0;
   for (int it = 0; it < n_iters; ++it) {
     const bool more = (it + 1 < n_iters);
-    if (more) load_tiles(it + 1);
-    const float* __restrict__ as = &As[cur][kh * LDA + wm * 64 + l31];
-    const float* __restrict__ bs = &Bs[cur][kh * LDB + wn * 64 + l31];
+    if (more) {
+      load_tiles(tap_n, kit_n);
+      advance();
+    }
+    // ---- all fragments of this k-tile: index c*4+e <-> k = 8c + 4*kh + e
+    float av[2][BK / 2], bv[NTW][BK / 2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (A_KC) {
+        const float* src = &As[cur][a_frag + mt * 32 * LDA];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[mt][4 * c + e] = v[e];
+        }
+      } else {
+        const float* src = &As[cur][a_frag + mt * 32];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[mt][4 * c + e] = src[(8 * c + e) * LDA];
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      if (B_KC) {
+        const float* src = &Bs[cur][b_frag + nt * 32 * LDB];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[nt][4 * c + e] = v[e];
+        }
+      } else {
+        const float* src = &Bs[cur][b_frag + nt * 32];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[nt][4 * c + e] = src[(8 * c + e) * LDB];
+      }
+    }
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      const float a0 = as[(2 * s) * LDA], a1 = as[(2 * s) * LDA + 32];
-      const float b0 = bs[(2 * s) * LDB], b1 = bs[(2 * s) * LDB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[nt][s], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[nt][s], acc[1][nt], 0, 0, 0);
+      }
     }
     if (more) store_tiles(cur ^ 1);
     __syncthreads();
@@ -187,28 +283,60 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
 
   // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
+  const int epi = p.epi, act = p.act;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = n0 + wn * 64 + nt * 32 + l31;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = n0 + wn * 32 * NTW + nt * 32 + l31;
       if (col >= p.N) continue;
-      const float bv = add_bias ? p.bias[col] : 0.f;
+      const float bias_v = add_bias ? p.bias[col] : 0.f;
+      const int row0 = m0 + wm * 64 + mt * 32 + 4 * kh;
+      float* cbase = C + (int64_t)row0 * p.ldc + col;
+      if (epi == DVAE_EPI_STORE) {
+        if (act == DVAE_ACT_NONE) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row >= p.M) continue;
-        float v = acc[mt][nt][r] + bv;
-        float* c = C + (int64_t)row * p.ldc + col;
-        if (p.epi == DVAE_EPI_STORE) {
-          *c = act_apply(v, p.act);
-        } else if (p.epi == DVAE_EPI_ACCUM) {
-          *c += v;
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (row0 + dr < p.M) cbase[(int64_t)dr * p.ldc] = acc[mt][nt][r] + bias_v;
+          }
         } else {
-          atomicAdd(c, v);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = (r & 3) + 8 * (r >> 2);
+            if (row0 + dr < p.M) cbase[(int64_t)dr * p.ldc] = act_apply(acc[mt][nt][r] + bias_v, act);
+          }
+        }
+      } else if (epi == DVAE_EPI_ACCUM) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < p.M) cbase[(int64_t)dr * p.ldc] += acc[mt][nt][r] + bias_v;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < p.M) atomicAdd(cbase + (int64_t)dr * p.ldc, acc[mt][nt][r] + bias_v);
         }
       }
     }
+  }
+}
+
+template <bool AK, bool BKC>
+void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk) {
+  dim3 block(NTHR);
+  if (bk == 32) {
+    if (narrow)
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32>), grid, block, 0, s, p);
+  } else {
+    if (narrow)
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16>), grid, block, 0, s, p);
   }
 }
 
@@ -223,23 +351,33 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   if (p.split_k < 1) p.split_k = 1;
   if (p.split_k > 1 && (p.epi != DVAE_EPI_ATOMIC || p.act != DVAE_ACT_NONE)) return DVAE_EINVAL;
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
+  // tuning knobs for experiments (scripts/one_shape.py); unset in production
+  static const int bk_env = getenv("DVAE_GEMM_BK") ? atoi(getenv("DVAE_GEMM_BK")) : 0;
+  static const int narrow_env = getenv("DVAE_GEMM_NARROW") ? atoi(getenv("DVAE_GEMM_NARROW")) : -1;
   int kps = (p.K + p.split_k - 1) / p.split_k;
-  kps = ((kps + BK - 1) / BK) * BK;
+  // k-tile 32 when the per-split K allows it without padding waste
+  int bk = (kps % 32 == 0 && kps >= 64) ? 32 : 16;
+  if (bk_env == 16 || bk_env == 32) bk = bk_env;
+  kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
   p.split_k = (p.K + kps - 1) / kps;
   p.tiles_m = (p.M + BM - 1) / BM;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid(p.tiles_m * tiles_n, 1, p.split_k * (p.tap_mode == 2 ? p.taps : 1));
-  dim3 block(NTHR);
+  const int zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
+  // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
+  const int tiles128 = p.tiles_m * ((p.N + 127) / 128) * zdim;
+  const bool narrow = narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32);
+  const int bn = narrow ? 64 : 128;
+  const int tiles_n = (p.N + bn - 1) / bn;
+  dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * (p.tap_mode ? p.taps : 1));
   if (a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, s, p);
+    launch_variant<true, true>(p, grid, s, narrow, bk);
   else if (a_kc && !b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, s, p);
+    launch_variant<true, false>(p, grid, s, narrow, bk);
   else if (!a_kc && b_kc)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, s, p);
+    launch_variant<false, true>(p, grid, s, narrow, bk);
   else
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, s, p);
+    launch_variant<false, false>(p, grid, s, narrow, bk);
   return dvae_check_launch();
 }
 

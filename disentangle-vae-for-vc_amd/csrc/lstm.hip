@@ -10,10 +10,17 @@
 // v_mfma_f32_16x16x4_f32; the four gate tiles meet in LDS for the fused pointwise update.
 // Backward: the contraction runs over K = 4H, wave w takes the quarter [w*H,(w+1)*H) and the four
 // partial tiles are summed in LDS before the fused gate-derivative epilogue.
-// Operands are k-contiguous in memory, so each lane fetches float4 fragments straight from
-// L2 (W_hh is re-read every frame and stays L2/MALL resident; the blockIdx -> tile map keeps all
-// row-tiles of one weight slice on one XCD).  The k order inside a 16-chunk is permuted
-// (lane group q takes k = 4q..4q+3) identically for A and B, which leaves the dot product intact.
+//
+// Data movement: per 64-deep k-chunk the workgroup stages its W_hh slice (64 rows) and its
+// H[t-1] / dG[t+1] rows through LDS with full-line coalesced 16-byte loads (each byte fetched once
+// per workgroup; the waves share the activation rows), register-prefetching chunk c+1 while the
+// MFMAs of chunk c run, two LDS buffers, one barrier per chunk.  Fragments are read with
+// ds_read_b128: lane (r, q) takes k = 4q..4q+3 of its row for both operands, which permutes the
+// k order inside a 16-chunk identically for A and B and leaves the dot product intact.
+// The operands of the pointwise epilogue (pre-activations, c[t-1], ...) are fetched at kernel
+// entry so their latency hides under the contraction.  W_hh is re-read every frame and stays
+// L2/MALL resident; the blockIdx -> tile map keeps all row-tiles of one weight slice on one XCD.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -32,13 +39,17 @@ struct StepArgs {
   StepDir d[2];
   int T, N, H;
   int64_t ldh;
+  int dbg;   // experiment bits (DVAE_LSTM_DBG): 1 skip in-loop global loads, 2 skip MFMAs, 4 naive block map
 };
+
+constexpr int KC = 64;   // k-chunk
+constexpr int LDS_LD = 68;  // floats per staged row (64 + 4 pad; 272 B keeps 16-B alignment)
 
 // XCD-aware decode of the linear block id into (j-block, m-block): consecutive ids go to
 // different XCDs (round-robin dispatch), ids equal mod 8 share one.  Put all m-blocks of a
 // j-block on one XCD so a W_hh slice lives in exactly one L2.
-__device__ __forceinline__ void decode_block(int bid, int n_j, int n_m, int& jb, int& mb) {
-  if ((n_j & 7) == 0) {
+__device__ __forceinline__ void decode_block(int bid, int n_j, int n_m, int& jb, int& mb, int dbg = 0) {
+  if ((n_j & 7) == 0 && !(dbg & 4)) {
     const int x = bid & 7;        // XCD label
     const int q = bid >> 3;       // index inside that XCD
     mb = q % n_m;
@@ -49,6 +60,36 @@ __device__ __forceinline__ void decode_block(int bid, int n_j, int n_m, int& jb,
   }
 }
 
+
+// Two-deep software pipeline of the k-chunks: chunk c is consumed from LDS while the global loads of
+// chunks c+1 AND c+2 are in flight in two named register sets (so a load has two chunk-times, ~1 us,
+// to come back from L2 before it is needed), two LDS buffers, one barrier per chunk.
+// gload(w, a, c): issue loads of chunk c into the register set; sstore(buf, w, a): write the set to
+// LDS buffer buf; compute(buf): MFMAs on LDS buffer buf.
+template <int NRW, int NRA, class GL, class SS, class CP>
+__device__ __forceinline__ void chunk_pipeline(int nchunks, GL gload, SS sstore, CP compute) {
+  // Loads and LDS stores are UNCONDITIONAL (chunk index clamped to the last chunk, a few redundant loads
+  // at the tail): with branch-free memory traffic hipcc keeps counted s_waitcnt vmcnt(N) in the loop, so
+  // one register set really stays in flight across the barrier; conditional loads made it drain to
+  // vmcnt(0) at the loop head.
+  f32x4 wA[NRW], aA[NRA], wB[NRW], aB[NRA];
+  const int last = nchunks - 1;
+  gload(wA, aA, 0);
+  gload(wB, aB, min(1, last));
+  sstore(0, wA, aA);
+  __syncthreads();
+  for (int c = 0; c < nchunks; c += 2) {
+    gload(wA, aA, min(c + 2, last));
+    compute(0);
+    sstore(1, wB, aB);
+    __syncthreads();
+    gload(wB, aB, min(c + 3, last));
+    if (c + 1 < nchunks) compute(1);
+    sstore(0, wA, aA);
+    __syncthreads();
+  }
+}
+
 template <int MT>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, int step, int n_j, int n_m) {
   const StepDir& d = a.d[blockIdx.z];
@@ -56,12 +97,27 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
   const int t = d.reverse ? (a.T - 1 - step) : step;
   const int tp = d.reverse ? t + 1 : t - 1;
   int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb);
+  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
   const int j0 = jb * 16, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
 
+  __shared__ __attribute__((aligned(16))) float Ws[2][64 * LDS_LD];
+  __shared__ __attribute__((aligned(16))) float As[2][16 * MT * LDS_LD];
   __shared__ float sm[4][MT * 16][17];
+
+  // ---- epilogue operands first (independent of the contraction)
+  float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+  float pre[MT][4], cp[MT];
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int idx = tid + 256 * e;
+    const int n = m0 + (idx >> 4), j = j0 + (idx & 15);
+    const bool ok = n < N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[e][g] = ok ? G[(int64_t)n * 4 * H + g * H + j] : 0.f;
+    cp[e] = (ok && step > 0) ? d.c_all[((int64_t)tp * N + n) * H + j] : 0.f;
+  }
 
   f32x4 acc[MT];
 #pragma unroll
@@ -69,42 +125,47 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
 
   if (step > 0) {
     const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
-    const float* __restrict__ wrow = d.w + ((int64_t)wave * H + j0 + r) * H + 4 * kq;
-    const float* arow[MT];
-    bool aok[MT];
+    // staging map: 16 lanes cover one 256-B row segment
+    const int srow = tid >> 4, sc4 = tid & 15;
+    auto gload = [&](f32x4 (&rw)[4], f32x4 (&ra)[MT], int c) {
+      if ((a.dbg & 1) && c > 1) return;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int row = m0 + mt * 16 + r;
-      aok[mt] = row < N;
-      arow[mt] = hp + (int64_t)(aok[mt] ? row : 0) * a.ldh + 4 * kq;
-    }
-    // two register buffers of 32 k each; H is a multiple of 64
-    f32x4 b0[2], b1[2], a0[MT][2], a1[MT][2];
-    auto ld = [&](f32x4 (&bb)[2], f32x4 (&aa)[MT][2], int k0) {
+      for (int i = 0; i < 4; ++i) {
+        const int row = srow + 16 * i;  // 0..63 : gate = row>>4, j = row&15
+        rw[i] = *reinterpret_cast<const f32x4*>(d.w + ((int64_t)(row >> 4) * H + j0 + (row & 15)) * H + c * KC + 4 * sc4);
+      }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        bb[c] = *reinterpret_cast<const f32x4*>(wrow + k0 + 16 * c);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          aa[mt][c] = aok[mt] ? *reinterpret_cast<const f32x4*>(arow[mt] + k0 + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < MT; ++i) {
+        const int n = min(m0 + srow + 16 * i, N - 1);   // rows >= N only feed output rows that are never stored
+        ra[i] = *reinterpret_cast<const f32x4*>(hp + (int64_t)n * a.ldh + c * KC + 4 * sc4);
       }
     };
-    auto mm = [&](f32x4 (&bb)[2], f32x4 (&aa)[MT][2]) {
+    auto sstore = [&](int buf, f32x4 (&rw)[4], f32x4 (&ra)[MT]) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Ws[buf][(srow + 16 * i) * LDS_LD + 4 * sc4]) = rw[i];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) *reinterpret_cast<f32x4*>(&As[buf][(srow + 16 * i) * LDS_LD + 4 * sc4]) = ra[i];
+    };
+    auto compute = [&](int buf) {
+      const float* __restrict__ wl = &Ws[buf][(wave * 16 + r) * LDS_LD + 4 * kq];
+      const float* __restrict__ al = &As[buf][r * LDS_LD + 4 * kq];
+      if (a.dbg & 2) return;
+      f32x4 bq[KC / 16], aq[MT][KC / 16];
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk) {
+        bq[kk] = *reinterpret_cast<const f32x4*>(wl + 16 * kk);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aq[mt][kk] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDS_LD + 16 * kk);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[mt][c][e], bb[c][e], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[mt][kk][e], bq[kk][e], acc[mt], 0, 0, 0);
     };
-    ld(b0, a0, 0);
-    for (int k0 = 0; k0 < H; k0 += 64) {
-      ld(b1, a1, k0 + 32);
-      mm(b0, a0);
-      if (k0 + 64 < H) ld(b0, a0, k0 + 64);
-      mm(b1, a1);
-    }
+    chunk_pipeline<4, MT>(H / KC, gload, sstore, compute);
   }
   // C/D map of the 16x16 tile: col = lane&15, row = (lane>>4)*4 + reg
 #pragma unroll
@@ -113,8 +174,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
     for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
   __syncthreads();
 
-  float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
-  const float* __restrict__ cprev = d.c_all + (int64_t)tp * N * H;
   float* __restrict__ cout = d.c_all + (int64_t)t * N * H;
   float* __restrict__ hout = d.h_out + (int64_t)t * N * a.ldh;
 #pragma unroll
@@ -125,12 +184,11 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
     if (n >= N) continue;
     const int j = j0 + col;
     float* g = G + (int64_t)n * 4 * H + j;
-    const float gi = sigmoidf_(sm[0][row][col] + g[0]);
-    const float gf = sigmoidf_(sm[1][row][col] + g[H]);
-    const float gg = tanhf(sm[2][row][col] + g[2 * H]);
-    const float go = sigmoidf_(sm[3][row][col] + g[3 * H]);
-    const float cp = (step > 0) ? cprev[(int64_t)n * H + j] : 0.f;
-    const float c = gf * cp + gi * gg;
+    const float gi = sigmoidf_(sm[0][row][col] + pre[e][0]);
+    const float gf = sigmoidf_(sm[1][row][col] + pre[e][1]);
+    const float gg = tanhf(sm[2][row][col] + pre[e][2]);
+    const float go = sigmoidf_(sm[3][row][col] + pre[e][3]);
+    const float c = gf * cp[e] + gi * gg;
     g[0] = gi;
     g[H] = gf;
     g[2 * H] = gg;
@@ -150,55 +208,83 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
   const int tn = d.reverse ? t - 1 : t + 1;                // frame processed AFTER t in the forward recurrence
   const int tp = d.reverse ? t + 1 : t - 1;                // frame processed BEFORE t
   int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb);
+  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
   const int j0 = jb * 16, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
 
+  __shared__ __attribute__((aligned(16))) float Bs[2][4 * 16 * LDS_LD];        // [k-quarter][j row]
+  __shared__ __attribute__((aligned(16))) float As[2][4 * 16 * MT * LDS_LD];   // [k-quarter][segment row]
   __shared__ float sm[4][MT * 16][17];
+
+  // ---- epilogue operands first
+  const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+  float gt[MT][4], cc[MT], cp[MT], dho[MT], dcar[MT];
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int idx = tid + 256 * e;
+    const int n = m0 + (idx >> 4), j = j0 + (idx & 15);
+    const bool ok = n < N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gt[e][g] = ok ? G[(int64_t)n * 4 * H + g * H + j] : 0.f;
+    cc[e] = ok ? d.c_all[((int64_t)t * N + n) * H + j] : 0.f;
+    cp[e] = (ok && fstep > 0) ? d.c_all[((int64_t)tp * N + n) * H + j] : 0.f;
+    dho[e] = ok ? d.dh_out[((int64_t)t * N + n) * a.ldh + j] : 0.f;
+    dcar[e] = (ok && step > 0) ? d.dc[(int64_t)n * H + j] : 0.f;
+  }
 
   f32x4 acc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (step > 0) {
-    // dHrec[n, j] = sum_k dG[tn][n, k] * W_hh[k, j] ; this wave: k in [wave*H, (wave+1)*H)
-    const float* __restrict__ dgn = d.dgates + (int64_t)tn * N * 4 * H + (int64_t)wave * H + 4 * kq;
-    const float* __restrict__ wrow = d.w + (int64_t)(j0 + r) * 4 * H + (int64_t)wave * H + 4 * kq;
-    const float* arow[MT];
-    bool aok[MT];
+    // dHrec[n, j] = sum_k dG[tn][n, k] * W_hh[k, j] ; wave w: k in [w*H, (w+1)*H)
+    const float* __restrict__ dgn = d.dgates + (int64_t)tn * N * 4 * H;
+    const int H4 = 4 * H;
+    const int srow = tid >> 4, sc4 = tid & 15;   // 16 rows x 16 float4 per pass
+    auto gload = [&](f32x4 (&rb)[4], f32x4 (&ra)[4 * MT], int c) {
+      if ((a.dbg & 1) && c > 1) return;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int row = m0 + mt * 16 + r;
-      aok[mt] = row < N;
-      arow[mt] = dgn + (int64_t)(aok[mt] ? row : 0) * 4 * H;
-    }
-    f32x4 b0[2], b1[2], a0[MT][2], a1[MT][2];
-    auto ld = [&](f32x4 (&bb)[2], f32x4 (&aa)[MT][2], int k0) {
+      for (int q = 0; q < 4; ++q)
+        rb[q] = *reinterpret_cast<const f32x4*>(d.w + (int64_t)(j0 + srow) * H4 + q * H + c * KC + 4 * sc4);
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        bb[c] = *reinterpret_cast<const f32x4*>(wrow + k0 + 16 * c);
+      for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          aa[mt][c] = aok[mt] ? *reinterpret_cast<const f32x4*>(arow[mt] + k0 + 16 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+        for (int i = 0; i < MT; ++i) {
+          const int n = min(m0 + srow + 16 * i, N - 1);
+          ra[q * MT + i] = *reinterpret_cast<const f32x4*>(dgn + (int64_t)n * H4 + q * H + c * KC + 4 * sc4);
+        }
     };
-    auto mm = [&](f32x4 (&bb)[2], f32x4 (&aa)[MT][2]) {
+    auto sstore = [&](int buf, f32x4 (&rb)[4], f32x4 (&ra)[4 * MT]) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(&Bs[buf][(q * 16 + srow) * LDS_LD + 4 * sc4]) = rb[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          *reinterpret_cast<f32x4*>(&As[buf][(q * 16 * MT + srow + 16 * i) * LDS_LD + 4 * sc4]) = ra[q * MT + i];
+    };
+    auto compute = [&](int buf) {
+      const float* __restrict__ bl = &Bs[buf][(wave * 16 + r) * LDS_LD + 4 * kq];
+      const float* __restrict__ al = &As[buf][(wave * 16 * MT + r) * LDS_LD + 4 * kq];
+      if (a.dbg & 2) return;
+      f32x4 bq[KC / 16], aq[MT][KC / 16];
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk) {
+        bq[kk] = *reinterpret_cast<const f32x4*>(bl + 16 * kk);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aq[mt][kk] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDS_LD + 16 * kk);
+      }
+#pragma unroll
+      for (int kk = 0; kk < KC / 16; ++kk)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[mt][c][e], bb[c][e], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[mt][kk][e], bq[kk][e], acc[mt], 0, 0, 0);
     };
-    ld(b0, a0, 0);
-    for (int k0 = 0; k0 < H; k0 += 64) {
-      ld(b1, a1, k0 + 32);
-      mm(b0, a0);
-      if (k0 + 64 < H) ld(b0, a0, k0 + 64);
-      mm(b1, a1);
-    }
+    chunk_pipeline<4, 4 * MT>(H / KC, gload, sstore, compute);
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -206,11 +292,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
     for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
   __syncthreads();
 
-  const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
   float* __restrict__ dG = d.dgates + (int64_t)t * N * 4 * H;
-  const float* __restrict__ ccur = d.c_all + (int64_t)t * N * H;
-  const float* __restrict__ cprev = d.c_all + (int64_t)tp * N * H;
-  const float* __restrict__ dho = d.dh_out + (int64_t)t * N * a.ldh;
 #pragma unroll
   for (int e = 0; e < MT; ++e) {
     const int idx = tid + 256 * e;
@@ -218,17 +300,13 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
     const int n = m0 + row;
     if (n >= N) continue;
     const int j = j0 + col;
-    const float dh = dho[(int64_t)n * a.ldh + j] + sm[0][row][col] + sm[1][row][col] + sm[2][row][col] + sm[3][row][col];
-    const float* g = G + (int64_t)n * 4 * H + j;
-    const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
-    const float c = ccur[(int64_t)n * H + j];
-    const float tc = tanhf(c);
-    const float cp = (fstep > 0) ? cprev[(int64_t)n * H + j] : 0.f;
-    const float dcar = (step > 0) ? d.dc[(int64_t)n * H + j] : 0.f;
-    const float dc = dcar + dh * go * (1.f - tc * tc);
+    const float dh = dho[e] + sm[0][row][col] + sm[1][row][col] + sm[2][row][col] + sm[3][row][col];
+    const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
+    const float tc = tanhf(cc[e]);
+    const float dc = dcar[e] + dh * go * (1.f - tc * tc);
     float* o = dG + (int64_t)n * 4 * H + j;
     o[0] = dc * gg * gi * (1.f - gi);
-    o[H] = dc * cp * gf * (1.f - gf);
+    o[H] = dc * cp[e] * gf * (1.f - gf);
     o[2 * H] = dc * gi * (1.f - gg * gg);
     o[3 * H] = dh * tc * go * (1.f - go);
     d.dc[(int64_t)n * H + j] = dc * gf;
@@ -247,11 +325,15 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
   }
   if (ndir == 1) a.d[1] = a.d[0];
   a.T = T; a.N = N; a.H = H; a.ldh = ldh;
+  static const int dbg_env = getenv("DVAE_LSTM_DBG") ? atoi(getenv("DVAE_LSTM_DBG")) : 0;
+  a.dbg = dbg_env;
   return DVAE_OK;
 }
 
 // rows per workgroup: prefer the largest MT that still yields >= 256 workgroups
 int pick_mt(int N, int H, int ndir) {
+  static const int mt_env = getenv("DVAE_LSTM_MT") ? atoi(getenv("DVAE_LSTM_MT")) : 0;
+  if (mt_env == 1 || mt_env == 2) return mt_env;
   const int n_j = H / 16;
   for (int mt = 2; mt >= 1; --mt) {
     const int n_m = (N + 16 * mt - 1) / (16 * mt);

@@ -84,8 +84,13 @@ def linear_dgrad(dy, w):
     """dx[M,K] = dy[M,Nout] @ w[Nout,K]"""
     M, Nout = dy.shape
     K = w.shape[1]
-    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-    gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False)
+    sk = _split_k(_tiles(M, K), Nout)
+    if sk > 1:
+        dx = torch.zeros((M, K), device=dy.device, dtype=torch.float32)
+        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, ACT_NONE, EPI_ATOMIC, sk)
+    else:
+        dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False)
     return dx
 
 
