@@ -1,0 +1,126 @@
+"""Data-parallel path on CPU: world_size 2, gloo backend, 127.0.0.1.
+
+Checks (a) the bucketed reducer over a flat gradient buffer reproduces the SUM of per-rank gradients whatever
+order parameters become ready in, and (b) the N-rank recipe used by bench.py / ddp.py — rank-local BatchNorm
+statistics, loss divided by the local batch, summed gradients scaled by 1/world — equals the single-process
+chunked step of the oracle.  The oracle supplies forward/backward here (tests may use it); the
+reducer, the flat packing and the sharding are the product code under test."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker_reducer(rank, world, port, q):
+    _init(rank, world, port)
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ddp, ops
+    from dvae_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ps = [(f"p{i}", torch.nn.Parameter(torch.zeros(n))) for i, n in enumerate((1000, 37, 4096, 5, 2048, 300))]
+    opt = FlatAdam(ps, lr=1e-3)
+    red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets, bucket_bytes=8192)
+    assert len(red.buckets) >= 3 and red.buckets[0][0] == 0 and red.buckets[-1][1] == opt.numel
+    for a, b in zip(red.buckets[:-1], red.buckets[1:]):
+        assert a[1] == b[0]
+    for trial in range(2):
+        opt.zero_grad()
+        red.begin()
+        order = list(range(len(ps))) if trial == 0 else [3, 0, 5, 1]      # trial 1: two params never report
+        for i in range(len(ps)):
+            ps[i][1].grad.add_(float(rank + 1) * (i + 1))
+        for i in order:
+            ops.grad_ready_hook(ps[i][1])
+        red.finish()
+        assert ops.grad_ready_hook is None
+        for i, (_, p) in enumerate(ps):
+            want = sum(float(r + 1) * (i + 1) for r in range(world))
+            assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (trial, i)
+    ddp.broadcast_parameters(opt.flat_p)
+    dist.barrier()
+    if rank == 0:
+        q.put("ok")
+    dist.destroy_process_group()
+
+
+def _worker_step_equivalence(rank, world, port, q):
+    _init(rank, world, port)
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ddp
+    from dvae_amd.optim import FlatAdam
+    from oracle.dvae_ref import RefTrainer, chunked_step_grads, loss_gvae2
+    from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+    Bg, T = 4, 64
+    per = Bg // world
+    x1, x2 = synthetic_pair(Bg, T, 21)
+    eps = synthetic_eps(Bg, seed=22)
+    tr = RefTrainer(per, n_frames=T)
+    tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
+    tr.model.train()
+    opt = FlatAdam(list(tr.model.named_parameters()), lr=1e-4)
+    red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets, bucket_bytes=32 << 20)
+    lo, hi = ddp.shard_range(Bg, rank, world)
+    opt.zero_grad()
+    red.begin()
+    outs = tr.model(x1[lo:hi], x2[lo:hi], tuple(e[lo:hi] for e in eps))
+    loss_gvae2(x1[lo:hi], x2[lo:hi], outs, per)[0].backward()      # rank-local BN stats, loss / local batch
+    red.finish()                                                    # SUM over ranks
+    assert opt.views_intact()
+    got = {n: p.grad.detach().clone() / world for n, p in tr.model.named_parameters()}   # Adam's grad_scale
+    if rank == 0:
+        ref_tr = RefTrainer(per, n_frames=T)
+        ref_tr.model.load_state_dict(fill_state_dict(ref_tr.model.state_dict()))
+        ref_tr.model.train()
+        want = chunked_step_grads(ref_tr, x1, x2, eps, world)
+        worst = 0.0
+        for n in want:
+            denom = float(want[n].norm()) + 1e-6
+            worst = max(worst, float((got[n] - want[n]).norm()) / denom if denom > 1e-3 else 0.0)
+        q.put(worst)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(fn, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for p in procs:
+        assert p.exitcode == 0, f"worker exit code {p.exitcode}"
+    return q.get()
+
+
+def test_bucketed_reducer_world2_gloo():
+    assert _run(_worker_reducer) == "ok"
+
+
+def test_two_rank_step_equals_chunked_oracle_step():
+    worst = _run(_worker_step_equivalence)
+    assert worst < 1e-4, worst

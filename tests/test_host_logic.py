@@ -1,0 +1,127 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, the model
+mirrors the reference's parameter tree, flat-buffer packing, the dataset semantics, checkpoint discovery,
+and that the product path refuses to run without the GPU (no compute calls are made here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    from dvae_amd import _lib
+    names = ge.declared_symbols()
+    assert len(names) >= 30
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    h = _lib.lib()
+    for n in names:
+        assert hasattr(h, n), n
+    assert h.dvae_version() >= 100
+    # pure-host helpers of the ABI (no device work)
+    assert h.dvae_bn_ws_bytes(16384, 512, 2) > 0 and h.dvae_l1_ws_bytes(1000) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from dvae_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.lib()
+
+
+def test_model_mirrors_reference_parameter_tree(golden_dir):
+    import dvae_amd
+    g = np.load(os.path.join(golden_dir, "c0_b4_t64.npz"))
+    m = dvae_amd.DisentangledVAE(speaker_size=4, latent_dim=32, batch_size=4)
+    assert [n for n, _ in m.named_parameters()] == list(g["param_names"])
+    assert sum(p.numel() for p in m.parameters()) == 61367680
+    keys = set(m.state_dict().keys())
+    for k in g.files:
+        if k.startswith("bn_"):
+            assert k[3:] in keys, k
+    m128 = dvae_amd.DisentangledVAE(speaker_size=4, latent_dim=32, n_frames=128)
+    assert sum(p.numel() for p in m128.parameters()) == 94930304
+    assert len(m.backward_param_order()) == 84
+
+
+def test_cpu_tensors_are_refused():
+    import dvae_amd
+    m = dvae_amd.DisentangledVAE(speaker_size=4, latent_dim=32)
+    x = torch.zeros(2, 80, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x, x)
+    with pytest.raises(RuntimeError):
+        m.decode(torch.zeros(2, 32))
+
+
+def test_flat_adam_packing():
+    from dvae_amd.optim import FlatAdam
+    ps = [("a", torch.nn.Parameter(torch.randn(3, 5))), ("b", torch.nn.Parameter(torch.randn(7))),
+          ("c", torch.nn.Parameter(torch.randn(2, 2, 2)))]
+    before = [p.detach().clone() for _, p in ps]
+    opt = FlatAdam(ps, lr=1e-3)
+    assert opt.offsets == {"a": 0, "b": 16, "c": 24} and opt.numel == 32   # 16-byte aligned views
+    assert opt.views_intact()
+    for (_, p), b in zip(ps, before):
+        assert torch.equal(p.detach(), b)
+    ps[1][1].grad.add_(1.0)
+    assert float(opt.flat_g[16:23].sum()) == 7.0 and float(opt.flat_g.sum()) == 7.0
+    opt.zero_grad()
+    assert float(opt.flat_g.abs().sum()) == 0.0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    assert opt.views_intact()
+
+
+def test_dataset_pairs_same_speaker_and_crops(tmp_path):
+    from dvae_amd.data import SpeechDatasetGVAE, write_synthetic_corpus
+    root = write_synthetic_corpus(str(tmp_path / "corpus"), n_speakers=2, n_utt=8, length=96, seed=0)
+    ds = SpeechDatasetGVAE(root, samples_length=64, seed=1)
+    assert len(ds) == 8                                 # 2 speakers x (8 // 2) pairs  (dataset.py:63-76)
+    for i in range(len(ds)):
+        u1, u2 = ds.utterance_fp[i]
+        assert os.path.dirname(u1) == os.path.dirname(u2) and u1 != u2
+        m1, m2, spk = ds[i]
+        assert m1.shape == (80, 64) and m2.shape == (80, 64) and m1.dtype == torch.float64
+        assert int(spk) == ds.speaker_ids.index(os.path.basename(os.path.dirname(u1)))
+    first = [tuple(p) for p in ds.utterance_fp]
+    ds.shuffle_data()
+    assert sorted(sum(([a, b] for a, b in first), [])) == sorted(sum(([a, b] for a, b in ds.utterance_fp), []))
+    # shorter than the crop -> right zero padding (dataset.py:100-101); exactly the crop -> offset 0
+    ds_pad = SpeechDatasetGVAE(root, samples_length=128, seed=1)
+    m1, _, _ = ds_pad[0]
+    assert m1.shape == (80, 128) and float(m1[:, 96:].abs().sum()) == 0.0
+    ds_eq = SpeechDatasetGVAE(root, samples_length=96, seed=1)
+    assert ds_eq[0][0].shape == (80, 96)
+
+
+def test_load_last_model_picks_latest(tmp_path):
+    import dvae_amd
+    from dvae_amd.model.variational_base_vae import VariationalBaseModelVAE
+
+    class Tiny(VariationalBaseModelVAE):
+        def __init__(self):
+            super().__init__("VCTK", 64, 80, 1, 32, 1e-4, torch.device("cpu"), 500, 4)
+            self.model = torch.nn.Linear(2, 2)
+            self.optimizer = None
+
+    t = Tiny()
+    assert t.load_last_model(str(tmp_path)) == 1
+    for ep, val in ((5, 1.0), (500, 2.0), (20, 3.0)):
+        sd = {k: torch.full_like(v, val) for k, v in t.model.state_dict().items()}
+        torch.save(sd, tmp_path / f"DisentangledVAE_VCTK_{ep}.pth")
+    assert t.load_last_model(str(tmp_path)) == 501      # variational_base_vae.py:144-149
+    assert float(t.model.weight[0, 0]) == 2.0
+
+
+def test_shard_range():
+    from dvae_amd.ddp import shard_range
+    assert [shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
+    with pytest.raises(ValueError):
+        shard_range(10, 0, 4)
