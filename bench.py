@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--frames", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph (N=1 only)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -132,12 +133,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    use_graph = bool(args.graph) and world == 1
+    if use_graph:
+        w.enable_graph(True)
     log(f"rank {rank}/{world}: model built ({sum(p.numel() for p in w.model.parameters())} params), warm-up x{args.warmup}")
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2 if use_graph else 0)):   # graph mode: call 1 eager, call 2 captures
         w.step(x1, x2, spk, train=True)
     barrier()
     log("timed region start")
-    if not args.no_roofline:
+    prof_live = (not args.no_roofline) and not use_graph
+    if prof_live:
         ops.prof_enable(1)
     t0 = time.perf_counter()
     last = None
@@ -148,15 +153,27 @@ def main():
     log(f"timed region done: {1e3 * elapsed / args.steps:.2f} ms/step")
     roof = None
     if not args.no_roofline:
+        prof_steps = args.steps
+        if not prof_live:
+            # graph replays carry no host-side hooks: time the SAME kernels with HIP events over eager steps
+            # run right after the timed region (identical shapes and launches; `value` is unaffected)
+            prof_steps = min(args.steps, 5)
+            w.enable_graph(False)
+            ops.prof_enable(1)
+            for _ in range(prof_steps):
+                w.step(x1, x2, spk, train=True)
+            torch.cuda.synchronize()
         ms, launches, flops = ops.prof_collect()
         ops.prof_enable(0)
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": None, "launches_per_step": launches / args.steps,
-                    "kernel_ms_per_step": ms / args.steps, "avg_launch_us": 1e3 * ms / max(1, launches),
-                    "flops_per_step": flops / args.steps}
+                    "traffic": None, "launches_per_step": launches / prof_steps,
+                    "kernel_ms_per_step": ms / prof_steps, "avg_launch_us": 1e3 * ms / max(1, launches),
+                    "flops_per_step": flops / prof_steps,
+                    "timed": "HIP events around every launch, " + ("inside the timed region" if prof_live else
+                             f"{prof_steps} eager steps right after the graph-replayed timed region")}
     if world > 1:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -173,6 +190,7 @@ def main():
                "config": {"workload": f"configs[1]: fp32 train step, B={B} pairs/GPU, 80-mel, T={T}, "
                                       "10 synthetic speakers, speaker_size=4, latent=32, Adam lr=1e-4",
                           "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
+                          "launch": "hipGraph replay" if use_graph else "eager",
                           "params": sum(p.numel() for p in w.model.parameters())},
                "step_tflops_algorithmic": step_flops / 1e12,
                "step_frac_of_fp32_mfma_peak": step_flops / (ms_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "dvae_l1_sum_fwd": (i32, [vp, vp, vp, vp, i64, f32, vp]),
     "dvae_l1_sum_bwd": (i32, [vp, vp, vp, vp, i64, f32, vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
+    "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
     "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "dvae_frames_to_mel": (i32, [vp, vp, i32, i32, i32, vp]),
     "dvae_permute_102": (i32, [vp, vp, i32, i32, i32, vp]),

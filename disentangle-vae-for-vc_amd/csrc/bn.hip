@@ -78,24 +78,51 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ part, float* __restrict__ mean,
-                                         float* __restrict__ rstd, float* __restrict__ rmean,
-                                         float* __restrict__ rvar, int64_t* __restrict__ nbt, int chunks, int R,
-                                         int N, int C, int G, float eps, float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// Finalize kernels: 16 channels x 16 chunk-lanes per 256-thread workgroup; the chunk partials are summed by the
+// 16 chunk-lanes in parallel and combined through LDS (a serial per-channel loop over 64 chunks was latency-bound).
+__device__ __forceinline__ void sum_partials(const double* __restrict__ part, int chunks, int C, int G, int c, int kl,
+                                             double (&o)[4], double (*red)[16][4]) {
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  if (c < C) {
+    for (int k = kl; k < chunks; k += 16) {
+      for (int g = 0; g < G; ++g) {
+        const double* p = part + (((int64_t)k * G + g) * C + c) * 2;
+        s[2 * g] += p[0];
+        s[2 * g + 1] += p[1];
+      }
+    }
+  }
+  const int cl = threadIdx.x & 15;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) red[kl][cl][q] = s[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double t = 0.0;
+    if (kl == 0)
+      for (int k = 0; k < 16; ++k) t += red[k][cl][q];
+    o[q] = t;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part,
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                int64_t* __restrict__ nbt, int chunks, int R, int N,
+                                                                int C, int G, float eps, float momentum) {
+  __shared__ double red[16][16][4];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double o[4];
+  sum_partials(part, chunks, C, G, c, kl, o, red);
+  if (kl != 0) return;
   if (c == 0 && nbt) *nbt += G;
   if (c >= C) return;
   const double cnt = (double)(R / N) * (double)(N / G);
   float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
   for (int g = 0; g < G; ++g) {
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-      const double* p = part + (((int64_t)k * G + g) * C + c) * 2;
-      s += p[0];
-      q += p[1];
-    }
-    const double m = s / cnt;
-    double var = q / cnt - m * m;
+    const double m = o[2 * g] / cnt;
+    double var = o[2 * g + 1] / cnt - m * m;
     if (var < 0.0) var = 0.0;
     mean[g * C + c] = (float)m;
     rstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -136,23 +163,21 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // s12[g][c][2] = (sum dU, sum dU*yhat) as float; dgamma += sum_g s2 ; dbeta += sum_g s1
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ s12,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int chunks, int C,
-                                       int G) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ s12,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int chunks, int C, int G) {
+  __shared__ double red[16][16][4];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double o[4];
+  sum_partials(part, chunks, C, G, c, kl, o, red);
+  if (kl != 0 || c >= C) return;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < G; ++g) {
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < chunks; ++k) {
-      const double* p = part + (((int64_t)k * G + g) * C + c) * 2;
-      s += p[0];
-      q += p[1];
-    }
-    s12[(g * C + c) * 2] = (float)s;
-    s12[(g * C + c) * 2 + 1] = (float)q;
-    tb += s;
-    tg += q;
+    s12[(g * C + c) * 2] = (float)o[2 * g];
+    s12[(g * C + c) * 2 + 1] = (float)o[2 * g + 1];
+    tb += o[2 * g];
+    tg += o[2 * g + 1];
   }
   if (dgamma) dgamma[c] += (float)tg;
   if (dbeta) dbeta[c] += (float)tb;
@@ -212,7 +237,7 @@ DVAE_API int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* 
   dim3 grid((C + 63) / 64, ch);
   hipLaunchKernelGGL((bn_partial_kernel<0>), grid, dim3(256), 0, s, Y, nullptr, nullptr, nullptr, nullptr, part, R, N,
                      C, G, 0);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, mean, rstd,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, mean, rstd,
                      running_mean, running_var, num_batches_tracked, ch, R, N, C, G, eps, momentum);
   return dvae_check_launch();
 }
@@ -238,7 +263,7 @@ DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const 
   float* s12 = (float*)((char*)ws + (int64_t)ch * G * C * 2 * sizeof(double));
   dim3 grid((C + 63) / 64, ch);
   hipLaunchKernelGGL((bn_partial_kernel<1>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, s, part, s12, dgamma, dbeta, ch, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, s12, dgamma, dbeta, ch, C,
                      G);
   const int64_t total4 = (int64_t)R * C / 4;
   const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);

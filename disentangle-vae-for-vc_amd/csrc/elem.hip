@@ -175,6 +175,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Device-resident step counter and bias corrections, so that a captured hipGraph replays a correct Adam step:
+// state[0] = t (as float), state[1] = 1 - beta1^t, state[2] = sqrt(1 - beta2^t)
+__global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double t = (double)state[0] + 1.0;
+    state[0] = (float)t;
+    state[1] = (float)(1.0 - pow((double)b1, t));
+    state[2] = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+}
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                       float lr, float b1, float b2, float eps, float gs,
+                                                       const float* __restrict__ state) {
+  const float bc1 = state[1], bc2s = state[2];
+  const int64_t n4 = n >> 2;
+  const float step_size = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 pp = *reinterpret_cast<f32x4*>(p + 4 * i);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + 4 * i);
+    f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gs;
+      mm[k] = mm[k] + (gr - mm[k]) * (1.f - b1);
+      vv[k] = vv[k] * b2 + (1.f - b2) * gr * gr;
+      pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) / bc2s + eps));
+    }
+    *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
+    *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
+    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+  }
+}
+
 // ------------------------------------------------------------------ layout
 // X[t][g*Bh+b][c] = x_g[b][c][t] ; tile-transpose through LDS over (c,t) per segment
 __global__ __launch_bounds__(256) void mel_to_frames_kernel(const float* __restrict__ x1,
@@ -365,6 +400,17 @@ DVAE_API int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk(n / 4 + 1, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
                      lr, beta1, beta2, eps, grad_scale, (float)bc1, (float)sqrt(bc2));
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float grad_scale, float* state, void* stream) {
+  if (!p || !g || !m || !v || !state || n < 4 || (n & 3)) return DVAE_EINVAL;
+  if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return DVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(nblk(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
+                     eps, grad_scale, state);
   return dvae_check_launch();
 }
 

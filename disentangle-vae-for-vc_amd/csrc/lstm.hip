@@ -313,6 +313,236 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
   }
 }
 
+
+// =====================================================================================================
+// v3 frame kernels: W_hh fragments go global -> registers directly (a W row is consumed by exactly one
+// wave, so staging it through LDS only cost ds_write bandwidth and a barrier per chunk); only the
+// activation rows that all four waves share (forward: H[t-1]) are staged through LDS, in a few large
+// rounds.  The backward kernel has no shared operand at all (each wave owns a k-quarter) and runs its
+// main loop without LDS or barriers.  Loads are unconditional (row / round indices clamped) so hipcc
+// keeps counted vmcnt waits; a whole round's fragments for the NEXT round are in flight while the
+// current round's MFMAs issue.
+// =====================================================================================================
+template <int MT, int KR>
+__global__ __launch_bounds__(256) void lstm_step_fwd_v3(const StepArgs a, int step, int n_j, int n_m) {
+  constexpr int NS = KR / 16;          // 16-deep MFMA groups per round
+  constexpr int LDA = KR + 4;          // staged row stride (floats)
+  constexpr int NST = MT * KR / 64;    // float4 per thread per round for the activation stage
+  const StepDir& d = a.d[blockIdx.z];
+  const int H = a.H, N = a.N;
+  const int t = d.reverse ? (a.T - 1 - step) : step;
+  const int tp = d.reverse ? t + 1 : t - 1;
+  int jb, mb;
+  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  const int j0 = jb * 16, m0 = mb * 16 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+
+  __shared__ __attribute__((aligned(16))) float As[2][16 * MT * LDA];
+  __shared__ float sm[4][MT * 16][17];
+
+  float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+  float pre[MT][4], cp[MT];
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int idx = tid + 256 * e;
+    const int n = m0 + (idx >> 4), j = j0 + (idx & 15);
+    const bool ok = n < N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[e][g] = ok ? G[(int64_t)n * 4 * H + g * H + j] : 0.f;
+    cp[e] = (ok && step > 0) ? d.c_all[((int64_t)tp * N + n) * H + j] : 0.f;
+  }
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (step > 0) {
+    const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
+    const float* __restrict__ wrow = d.w + ((int64_t)wave * H + j0 + r) * H + 4 * kq;
+    const int srow = tid >> 4, sc4 = tid & 15;
+    const int nr = H / KR, last = nr - 1;
+    auto loadW = [&](f32x4 (&w)[NS], int rd) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wrow + rd * KR + 16 * s);
+    };
+    auto loadA = [&](f32x4 (&st)[NST], int rd) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int n = min(m0 + srow + 16 * i, N - 1);
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q)
+          st[i * (KR / 64) + q] = *reinterpret_cast<const f32x4*>(hp + (int64_t)n * a.ldh + rd * KR + 64 * q + 4 * sc4);
+      }
+    };
+    auto storeA = [&](int buf, f32x4 (&st)[NST]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q)
+          *reinterpret_cast<f32x4*>(&As[buf][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) = st[i * (KR / 64) + q];
+    };
+    auto compute = [&](int buf, f32x4 (&w)[NS]) {
+      const float* __restrict__ al = &As[buf][r * LDA + 4 * kq];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        f32x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDA + 16 * s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w[s][e], acc[mt], 0, 0, 0);
+      }
+    };
+    f32x4 wA[NS], wB[NS], sA[NST], sB[NST];
+    loadA(sA, 0);
+    loadW(wA, 0);
+    storeA(0, sA);
+    __syncthreads();
+    for (int rd = 0; rd < nr; rd += 2) {
+      loadA(sB, min(rd + 1, last));
+      loadW(wB, min(rd + 1, last));
+      compute(0, wA);
+      storeA(1, sB);
+      __syncthreads();
+      loadA(sA, min(rd + 2, last));
+      loadW(wA, min(rd + 2, last));
+      if (rd + 1 < nr) compute(1, wB);
+      storeA(0, sA);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
+  __syncthreads();
+
+  float* __restrict__ cout = d.c_all + (int64_t)t * N * H;
+  float* __restrict__ hout = d.h_out + (int64_t)t * N * a.ldh;
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int idx = tid + 256 * e;
+    const int row = idx >> 4, col = idx & 15;
+    const int n = m0 + row;
+    if (n >= N) continue;
+    const int j = j0 + col;
+    float* g = G + (int64_t)n * 4 * H + j;
+    const float gi = sigmoidf_(sm[0][row][col] + pre[e][0]);
+    const float gf = sigmoidf_(sm[1][row][col] + pre[e][1]);
+    const float gg = tanhf(sm[2][row][col] + pre[e][2]);
+    const float go = sigmoidf_(sm[3][row][col] + pre[e][3]);
+    const float c = gf * cp[e] + gi * gg;
+    g[0] = gi;
+    g[H] = gf;
+    g[2 * H] = gg;
+    g[3 * H] = go;
+    cout[(int64_t)n * H + j] = c;
+    hout[(int64_t)n * a.ldh + j] = go * tanhf(c);
+  }
+}
+
+template <int MT, int KR>
+__global__ __launch_bounds__(256) void lstm_step_bwd_v3(const StepArgs a, int step, int n_j, int n_m) {
+  constexpr int NS = KR / 16;
+  const StepDir& d = a.d[blockIdx.z];
+  const int H = a.H, N = a.N;
+  const int fstep = a.T - 1 - step;
+  const int t = d.reverse ? (a.T - 1 - fstep) : fstep;
+  const int tn = d.reverse ? t - 1 : t + 1;
+  const int tp = d.reverse ? t + 1 : t - 1;
+  int jb, mb;
+  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  const int j0 = jb * 16, m0 = mb * 16 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, kq = lane >> 4;
+
+  __shared__ float sm[4][MT * 16][17];
+
+  const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+  float gt[MT][4], cc[MT], cp[MT], dho[MT], dcar[MT];
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int idx = tid + 256 * e;
+    const int n = m0 + (idx >> 4), j = j0 + (idx & 15);
+    const bool ok = n < N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gt[e][g] = ok ? G[(int64_t)n * 4 * H + g * H + j] : 0.f;
+    cc[e] = ok ? d.c_all[((int64_t)t * N + n) * H + j] : 0.f;
+    cp[e] = (ok && fstep > 0) ? d.c_all[((int64_t)tp * N + n) * H + j] : 0.f;
+    dho[e] = ok ? d.dh_out[((int64_t)t * N + n) * a.ldh + j] : 0.f;
+    dcar[e] = (ok && step > 0) ? d.dc[(int64_t)n * H + j] : 0.f;
+  }
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (step > 0) {
+    const int H4 = 4 * H;
+    const float* __restrict__ brow = d.w + (int64_t)(j0 + r) * H4 + (int64_t)wave * H + 4 * kq;
+    const float* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int n = min(m0 + mt * 16 + r, N - 1);
+      arow[mt] = d.dgates + ((int64_t)tn * N + n) * H4 + (int64_t)wave * H + 4 * kq;
+    }
+    const int nr = H / KR, last = nr - 1;
+    auto load = [&](f32x4 (&b)[NS], f32x4 (&av)[MT][NS], int rd) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        b[s] = *reinterpret_cast<const f32x4*>(brow + rd * KR + 16 * s);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt][s] = *reinterpret_cast<const f32x4*>(arow[mt] + rd * KR + 16 * s);
+      }
+    };
+    auto compute = [&](f32x4 (&b)[NS], f32x4 (&av)[MT][NS]) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s][e], b[s][e], acc[mt], 0, 0, 0);
+    };
+    f32x4 bA[NS], bB[NS], aA[MT][NS], aB[MT][NS];
+    load(bA, aA, 0);
+    for (int rd = 0; rd < nr; rd += 2) {
+      load(bB, aB, min(rd + 1, last));
+      compute(bA, aA);
+      load(bA, aA, min(rd + 2, last));
+      if (rd + 1 < nr) compute(bB, aB);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
+  __syncthreads();
+
+  float* __restrict__ dG = d.dgates + (int64_t)t * N * 4 * H;
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int idx = tid + 256 * e;
+    const int row = idx >> 4, col = idx & 15;
+    const int n = m0 + row;
+    if (n >= N) continue;
+    const int j = j0 + col;
+    const float dh = dho[e] + sm[0][row][col] + sm[1][row][col] + sm[2][row][col] + sm[3][row][col];
+    const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
+    const float tc = tanhf(cc[e]);
+    const float dc = dcar[e] + dh * go * (1.f - tc * tc);
+    float* o = dG + (int64_t)n * 4 * H + j;
+    o[0] = dc * gg * gi * (1.f - gi);
+    o[H] = dc * cp[e] * gf * (1.f - gf);
+    o[2 * H] = dc * gi * (1.f - gg * gg);
+    o[3 * H] = dh * tc * go * (1.f - go);
+    d.dc[(int64_t)n * H + j] = dc * gf;
+  }
+}
+
 int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, bool bwd) {
   if (!dirs || ndir < 1 || ndir > 2 || T < 1 || N < 1 || H < 64 || (H & 63) || (ldh & 3)) return DVAE_EINVAL;
   for (int i = 0; i < ndir; ++i) {
@@ -334,11 +564,9 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
 int pick_mt(int N, int H, int ndir) {
   static const int mt_env = getenv("DVAE_LSTM_MT") ? atoi(getenv("DVAE_LSTM_MT")) : 0;
   if (mt_env == 1 || mt_env == 2) return mt_env;
-  const int n_j = H / 16;
-  for (int mt = 2; mt >= 1; --mt) {
-    const int n_m = (N + 16 * mt - 1) / (16 * mt);
-    if (n_j * n_m * ndir >= 256 || mt == 1) return mt;
-  }
+  // measured on MI355X (scripts/lstm_shape.py): 16-row workgroups (two per CU at H=1024) beat 32-row ones
+  // at every H of this model -- the extra W_hh traffic costs less than the latency the second workgroup hides
+  (void)N; (void)H; (void)ndir;
   return 1;
 }
 
@@ -354,11 +582,19 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
+  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 2;
+  const bool big = (H % 256) == 0;
   for (int step = 0; step < T; ++step) {
-    if (mt == 2)
+    if (ver == 3) {
+      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_fwd_v3<2, 256>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (mt == 2) hipLaunchKernelGGL((lstm_step_fwd_v3<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (big) hipLaunchKernelGGL((lstm_step_fwd_v3<1, 256>), grid, block, 0, s, a, step, n_j, n_m);
+      else hipLaunchKernelGGL((lstm_step_fwd_v3<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
+    } else if (mt == 2) {
       hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, s, a, step, n_j, n_m);
-    else
+    } else {
       hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, s, a, step, n_j, n_m);
+    }
   }
   return dvae_check_launch();
 }
@@ -373,11 +609,19 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
+  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 2;
+  const bool big = (H % 128) == 0;
   for (int step = 0; step < T; ++step) {
-    if (mt == 2)
+    if (ver == 3) {
+      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_bwd_v3<2, 128>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (mt == 2) hipLaunchKernelGGL((lstm_step_bwd_v3<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (big) hipLaunchKernelGGL((lstm_step_bwd_v3<1, 128>), grid, block, 0, s, a, step, n_j, n_m);
+      else hipLaunchKernelGGL((lstm_step_bwd_v3<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
+    } else if (mt == 2) {
       hipLaunchKernelGGL((lstm_step_bwd_kernel<2>), grid, block, 0, s, a, step, n_j, n_m);
-    else
+    } else {
       hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), grid, block, 0, s, a, step, n_j, n_m);
+    }
   }
   return dvae_check_launch();
 }

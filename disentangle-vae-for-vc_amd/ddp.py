@@ -77,6 +77,7 @@ class GradReducer:
     def finish(self):
         """Enqueue whatever was not triggered (parameters without gradient this step) and join."""
         ops.grad_ready_hook = None
+        ops.join_side()
         self.active = False
         for b, left in enumerate(self.pending):
             if left > 0:

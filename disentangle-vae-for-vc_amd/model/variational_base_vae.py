@@ -37,6 +37,10 @@ class VariationalBaseModelVAE:
         self.optimizer = None
         self.batch_size = batch_size
         self.reducer = None     # ddp.GradReducer when data parallel
+        # hipGraph replay of the whole train step (single-GPU): ~1 400 launches become one graph launch
+        self._use_graph = False
+        self._graph = None
+        self._graph_calls = 0
 
     def loss_function(self):
         raise NotImplementedError
@@ -45,8 +49,57 @@ class VariationalBaseModelVAE:
     def attach_reducer(self, reducer):
         self.reducer = reducer
 
+    def enable_graph(self, flag: bool = True):
+        """Capture the train step into a hipGraph on its second call and replay it afterwards (fixed batch shape;
+        ignored under data parallelism).  The first call runs eagerly (it is a real step and warms everything up)."""
+        self._use_graph = flag
+        self._graph = None
+        self._graph_calls = 0
+
+    def _eager_train_step(self, data1, data2):
+        self.optimizer.zero_grad()
+        outs = self.model(data1, data2)
+        losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
+        losses[0].backward()
+        self.optimizer.step()
+        return torch.stack([l.detach() for l in losses])
+
+    def _step_graph(self, data1, data2):
+        m = self.model
+        dev = data1.device
+        Bh = data1.shape[0]
+        S, Cn = m.speaker_size, m.latent_dim - m.speaker_size
+        self._graph_calls += 1
+        if self._graph_calls == 1:
+            return tuple(self._eager_train_step(data1, data2).tolist())
+        if self._graph is None:
+            self._g_x1, self._g_x2 = torch.empty_like(data1), torch.empty_like(data2)
+            self._g_eps = (torch.empty((Bh, Cn), device=dev), torch.empty((Bh, Cn), device=dev),
+                           torch.empty((Bh, S), device=dev))
+        if tuple(data1.shape) != tuple(self._g_x1.shape):
+            raise ValueError("graph mode needs a fixed batch shape; call enable_graph() again to re-capture")
+        self._g_x1.copy_(data1)
+        self._g_x2.copy_(data2)
+        user_eps = m.eps_override
+        for dst, src in zip(self._g_eps, user_eps if user_eps is not None else (None, None, None)):
+            dst.copy_(src.to(dev)) if src is not None else dst.normal_()
+        m.eps_override = self._g_eps
+        try:
+            if self._graph is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._g_losses = self._eager_train_step(self._g_x1, self._g_x2)
+                self._graph = g
+            self._graph.replay()
+        finally:
+            m.eps_override = user_eps
+        return tuple(self._g_losses.tolist())
+
     # ---- variational_base_vae.py:58-70
     def step(self, data1, data2, speaker_ids, train=False):
+        if train and self._use_graph and self.reducer is None:
+            return self._step_graph(data1, data2)
         if train:
             self.optimizer.zero_grad()
         outs = self.model(data1, data2)

@@ -46,7 +46,7 @@ class FlatAdam:
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.t = 0
+        self.dev_state = torch.zeros(4, device=dev, dtype=torch.float32)   # [t, 1-b1^t, sqrt(1-b2^t), -]
         # torch.optim-compatible surface used by callers of the reference wrapper
         self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps}]
 
@@ -66,11 +66,17 @@ class FlatAdam:
     def step(self, grad_scale: float = 1.0):
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdam.step runs only on the HIP device (no CPU fallback)")
-        self.t += 1
+        from . import ops
+        ops.join_side()     # weight-gradient work may still be running on the side stream
         lr = self.param_groups[0]["lr"]
-        check(lib().dvae_adam_flat(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                   self.numel, lr, self.betas[0], self.betas[1], self.eps, grad_scale, self.t,
-                                   stream()), "dvae_adam_flat")
+        check(lib().dvae_adam_flat_dev(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                       self.numel, lr, self.betas[0], self.betas[1], self.eps, grad_scale,
+                                       ptr(self.dev_state), stream()), "dvae_adam_flat_dev")
+
+    @property
+    def t(self) -> int:
+        """Number of optimiser steps taken (kept on the device so a captured graph can advance it)."""
+        return int(self.dev_state[0].item())
 
     def state_dict(self):
         return {"t": self.t, "lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps,
@@ -80,7 +86,8 @@ class FlatAdam:
     def load_state_dict(self, sd):
         if list(sd["names"]) != self.names:
             raise ValueError("optimizer state was saved for a different parameter layout")
-        self.t = int(sd["t"])
+        self.dev_state.zero_()
+        self.dev_state[0] = float(sd["t"])
         self.param_groups[0]["lr"] = float(sd["lr"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])

@@ -149,6 +149,11 @@ int dvae_l1_sum_bwd(const float* x, const float* y, const float* gout, float* dy
 int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float grad_scale, int step, void* stream);
 
+/* Same update with the step counter and bias corrections kept ON THE DEVICE (state[0]=t, state[1]=1-beta1^t,
+ * state[2]=sqrt(1-beta2^t); zero-initialised by the caller): replayable from a captured hipGraph.  n % 4 == 0. */
+int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                       float beta2, float eps, float grad_scale, float* state, void* stream);
+
 /* ---- layout plumbing ----
  * dvae_mel_to_frames: x1,x2 [Bh,C,T] (torch layout, variational_base_vae.py:81-82) -> X[T, 2*Bh, C]; x2 may be
  *   null (then N = Bh).  dvae_frames_to_mel is the inverse ([T,N,C] -> out[N,C,T]).

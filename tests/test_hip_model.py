@@ -192,3 +192,36 @@ def test_cpu_input_fails_loudly():
     x1, x2 = synthetic_pair(2, 64, 1)
     with pytest.raises(RuntimeError):
         w.model(x1, x2)
+
+
+def test_graph_replay_matches_eager():
+    """The hipGraph-captured step (device-resident Adam counter, static input/eps buffers) reproduces the eager one.
+    lr = 0 keeps the weights fixed, so both trainers see identical states and must agree to round-off on every
+    step (with lr > 0 two runs of the SAME code drift apart through Adam's sign(g) updates of ~0 gradients);
+    Adam moments, BatchNorm running statistics and counters still evolve and are compared."""
+    B, T = 4, 64
+    a, b = make(B, T, lr=0.0), make(B, T, lr=0.0)
+    b.enable_graph(True)
+    for i in range(4):
+        x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 100 + i))
+        eps = synthetic_eps(B, seed=200 + i)
+        a.model.eps_override = eps
+        b.model.eps_override = eps
+        la = a.step(x1, x2, None, train=True)
+        lb = b.step(x1, x2, None, train=True)
+        for k in range(8):
+            assert rel(lb[k], la[k]) <= 1e-5, (i, k, la[k], lb[k])
+    assert b._graph is not None and b.optimizer.t == 4 and a.optimizer.t == 4
+    for x, y in ((a.optimizer.exp_avg, b.optimizer.exp_avg), (a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)):
+        assert float((x - y).norm()) <= 1e-2 * float(x.norm())   # gradient flip noise, ~1e-3 per step
+    for (n1, v1), (n2, v2) in zip(a.model.named_buffers(), b.model.named_buffers()):
+        if n1.endswith("num_batches_tracked"):
+            assert int(v1) == int(v2) == 8
+        else:
+            assert float((v1 - v2).abs().max()) <= 1e-4 * max(1.0, float(v1.abs().max())), n1
+    # and with a real learning rate the replayed steps train: loss goes down
+    c = make(B, T)
+    c.enable_graph(True)
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 7))
+    hist = [c.step(x1, x2, None, train=True)[0] for _ in range(5)]
+    assert hist[-1] < hist[0], hist
