@@ -44,6 +44,7 @@ struct GemmParams {
   int k_per_split;       // multiple of the k-tile
   int act, epi;
   int tiles_m;
+  int prio_mode;         // experiment knob DVAE_GEMM_PRIO
 };
 
 template <bool A_KC, bool B_KC, int NTW, int BK>
@@ -223,6 +224,10 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
   const int a_frag = A_KC ? (wm * 64 + l31) * LDA + 4 * kh : (4 * kh) * LDA + wm * 64 + l31;
   const int b_frag = B_KC ? (wn * 32 * NTW + l31) * LDB + 4 * kh : (4 * kh) * LDB + wn * 32 * NTW + l31;
 
+  if (p.prio_mode) {
+    const int sh = p.prio_mode == 1 ? 8 : (p.prio_mode == 2 ? 0 : (p.prio_mode == 3 ? 3 : 9));
+    if (__builtin_amdgcn_readfirstlane((blockIdx.x >> sh) & 1)) __builtin_amdgcn_s_setprio(2);
+  }
   int cur = 0;
   for (int it = 0; it < n_iters; ++it) {
     const bool more = (it + 1 < n_iters);
@@ -353,6 +358,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
   // tuning knobs for experiments (scripts/one_shape.py); unset in production
   static const int bk_env = getenv("DVAE_GEMM_BK") ? atoi(getenv("DVAE_GEMM_BK")) : 0;
+  static const int prio_env = getenv("DVAE_GEMM_PRIO") ? atoi(getenv("DVAE_GEMM_PRIO")) : 0;
+  p.prio_mode = prio_env;
   static const int narrow_env = getenv("DVAE_GEMM_NARROW") ? atoi(getenv("DVAE_GEMM_NARROW")) : -1;
   int kps = (p.K + p.split_k - 1) / p.split_k;
   // k-tile 32 when the per-split K allows it without padding waste

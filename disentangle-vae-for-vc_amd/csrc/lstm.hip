@@ -28,6 +28,7 @@ namespace {
 struct StepDir {
   float* gates;         // [T,N,4H]
   const float* w;       // fwd [4H,H] ; bwd W_hh^T [H,4H]
+  const float* wp;      // fragment-packed weights for the v4 kernels (dvae_lstm_pack_w), or null
   float* h_out;         // [T,N,ldh] (column offset already applied)
   float* c_all;         // [T,N,H]
   const float* dh_out;  // [T,N,ldh]
@@ -315,16 +316,17 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
 
 
 // =====================================================================================================
-// v3 frame kernels: W_hh fragments go global -> registers directly (a W row is consumed by exactly one
-// wave, so staging it through LDS only cost ds_write bandwidth and a barrier per chunk); only the
-// activation rows that all four waves share (forward: H[t-1]) are staged through LDS, in a few large
-// rounds.  The backward kernel has no shared operand at all (each wave owns a k-quarter) and runs its
-// main loop without LDS or barriers.  Loads are unconditional (row / round indices clamped) so hipcc
-// keeps counted vmcnt waits; a whole round's fragments for the NEXT round are in flight while the
-// current round's MFMAs issue.
+// v4 frame kernels.  A W_hh row is consumed by exactly one wave, so staging it through LDS only costs
+// ds_write bandwidth and barriers; but fragment-shaped global loads (16 rows x 64 B per instruction) are
+// slow on the texture path.  So the weights are RE-PACKED once per training step into fragment order
+// (dvae_lstm_pack_w): the 64 lanes of a wave then read one contiguous 1-KiB burst per 16-deep k-chunk,
+// straight into registers, a whole round ahead.  Only activation rows go through LDS: forward H[t-1]
+// (shared by the four gate waves) in a few large block-level rounds; backward dG[t+1] in WAVE-PRIVATE
+// staging (each wave owns a k-quarter), so the backward main loop has no workgroup barrier at all.
+// Loads are unconditional (row / round indices clamped) so hipcc keeps counted vmcnt waits.
 // =====================================================================================================
 template <int MT, int KR>
-__global__ __launch_bounds__(256) void lstm_step_fwd_v3(const StepArgs a, int step, int n_j, int n_m) {
+__global__ __launch_bounds__(256) void lstm_step_fwd_v4(const StepArgs a, int step, int n_j, int n_m) {
   constexpr int NS = KR / 16;          // 16-deep MFMA groups per round
   constexpr int LDA = KR + 4;          // staged row stride (floats)
   constexpr int NST = MT * KR / 64;    // float4 per thread per round for the activation stage
@@ -359,12 +361,13 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_v3(const StepArgs a, int st
 
   if (step > 0) {
     const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
-    const float* __restrict__ wrow = d.w + ((int64_t)wave * H + j0 + r) * H + 4 * kq;
+    // packed layout: [(gate*n_j + jb)][k-chunk of 16][lane][4]
+    const float* __restrict__ wpk = d.wp + ((int64_t)wave * n_j + jb) * (H / 16) * 256 + lane * 4;
     const int srow = tid >> 4, sc4 = tid & 15;
     const int nr = H / KR, last = nr - 1;
     auto loadW = [&](f32x4 (&w)[NS], int rd) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wrow + rd * KR + 16 * s);
+      for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS + s) * 256);
     };
     auto loadA = [&](f32x4 (&st)[NST], int rd) {
 #pragma unroll
@@ -445,8 +448,9 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_v3(const StepArgs a, int st
 }
 
 template <int MT, int KR>
-__global__ __launch_bounds__(256) void lstm_step_bwd_v3(const StepArgs a, int step, int n_j, int n_m) {
+__global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int step, int n_j, int n_m) {
   constexpr int NS = KR / 16;
+  constexpr int LDA = KR + 4;
   const StepDir& d = a.d[blockIdx.z];
   const int H = a.H, N = a.N;
   const int fstep = a.T - 1 - step;
@@ -459,6 +463,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v3(const StepArgs a, int st
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
 
+  __shared__ __attribute__((aligned(16))) float Ast[4][2 * 16 * MT * LDA];   // per wave, two buffers
   __shared__ float sm[4][MT * 16][17];
 
   const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
@@ -482,38 +487,67 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v3(const StepArgs a, int st
 
   if (step > 0) {
     const int H4 = 4 * H;
-    const float* __restrict__ brow = d.w + (int64_t)(j0 + r) * H4 + (int64_t)wave * H + 4 * kq;
-    const float* arow[MT];
+    // packed layout: [(jb*4 + quarter)][k-chunk of 16][lane][4]
+    const float* __restrict__ bpk = d.wp + ((int64_t)jb * 4 + wave) * (H / 16) * 256 + lane * 4;
+    // wave-private staging of this wave's dG[t+1] quarter: 4 rows x 256 B per load instruction
+    float* __restrict__ stg = &Ast[wave][0];
+    const int lrow = lane >> 4, lc4 = lane & 15;
+    const float* arow[4 * MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int n = min(m0 + mt * 16 + r, N - 1);
-      arow[mt] = d.dgates + ((int64_t)tn * N + n) * H4 + (int64_t)wave * H + 4 * kq;
+    for (int i = 0; i < 4 * MT; ++i) {
+      const int n = min(m0 + lrow + 4 * i, N - 1);
+      arow[i] = d.dgates + ((int64_t)tn * N + n) * H4 + (int64_t)wave * H + 4 * lc4;
     }
     const int nr = H / KR, last = nr - 1;
-    auto load = [&](f32x4 (&b)[NS], f32x4 (&av)[MT][NS], int rd) {
+    auto loadA = [&](f32x4 (&st)[4 * MT][KR / 64], int rd) {
+#pragma unroll
+      for (int i = 0; i < 4 * MT; ++i)
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q) st[i][q] = *reinterpret_cast<const f32x4*>(arow[i] + rd * KR + 64 * q);
+    };
+    auto storeA = [&](int buf, f32x4 (&st)[4 * MT][KR / 64]) {
+#pragma unroll
+      for (int i = 0; i < 4 * MT; ++i)
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q)
+          *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
+    };
+    auto loadB = [&](f32x4 (&b)[NS], int rd) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS + s) * 256);
+    };
+    auto compute = [&](int buf, f32x4 (&b)[NS]) {
+      const float* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 4 * kq;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        b[s] = *reinterpret_cast<const f32x4*>(brow + rd * KR + 16 * s);
+        f32x4 av[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt][s] = *reinterpret_cast<const f32x4*>(arow[mt] + rd * KR + 16 * s);
-      }
-    };
-    auto compute = [&](f32x4 (&b)[NS], f32x4 (&av)[MT][NS]) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDA + 16 * s);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s][e], b[s][e], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], b[s][e], acc[mt], 0, 0, 0);
+      }
     };
-    f32x4 bA[NS], bB[NS], aA[MT][NS], aB[MT][NS];
-    load(bA, aA, 0);
+    f32x4 bA[NS], bB[NS], sA[4 * MT][KR / 64], sB[4 * MT][KR / 64];
+    loadA(sA, 0);
+    loadB(bA, 0);
+    storeA(0, sA);
+    __builtin_amdgcn_wave_barrier();
     for (int rd = 0; rd < nr; rd += 2) {
-      load(bB, aB, min(rd + 1, last));
-      compute(bA, aA);
-      load(bA, aA, min(rd + 2, last));
-      if (rd + 1 < nr) compute(bB, aB);
+      loadA(sB, min(rd + 1, last));
+      loadB(bB, min(rd + 1, last));
+      compute(0, bA);
+      __builtin_amdgcn_wave_barrier();
+      storeA(1, sB);
+      __builtin_amdgcn_wave_barrier();
+      loadA(sA, min(rd + 2, last));
+      loadB(bA, min(rd + 2, last));
+      if (rd + 1 < nr) compute(1, bB);
+      __builtin_amdgcn_wave_barrier();
+      storeA(0, sA);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #pragma unroll
@@ -543,6 +577,33 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v3(const StepArgs a, int st
   }
 }
 
+// W_hh [4H,H] -> fragment-packed copies.  fwd: [(g*n_j+jb)][kc][lane][4] <- W[g*H + jb*16 + r][kc*16 + 4q + e];
+// bwd: [(jb*4+w)][kc][lane][4] <- W[w*H + kc*16 + 4q + e][jb*16 + r]   (lane = q*16 + r)
+__global__ __launch_bounds__(256) void lstm_pack_w_kernel(const float* __restrict__ W, float* __restrict__ pf,
+                                                          float* __restrict__ pb, int H) {
+  const int n_j = H / 16, nkc = H / 16;
+  const int64_t total = (int64_t)4 * n_j * nkc * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const int64_t c = i >> 6;
+    const int kc = (int)(c % nkc);
+    const int64_t gj = c / nkc;
+    const int r = lane & 15, q = lane >> 4;
+    if (pf) {
+      const int g = (int)(gj / n_j), jb = (int)(gj % n_j);
+      reinterpret_cast<f32x4*>(pf)[i] =
+          *reinterpret_cast<const f32x4*>(W + ((int64_t)g * H + jb * 16 + r) * H + kc * 16 + 4 * q);
+    }
+    if (pb) {
+      const int jb = (int)(gj / 4), w = (int)(gj % 4);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = W[((int64_t)w * H + kc * 16 + 4 * q + e) * H + jb * 16 + r];
+      reinterpret_cast<f32x4*>(pb)[i] = v;
+    }
+  }
+}
+
 int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, bool bwd) {
   if (!dirs || ndir < 1 || ndir > 2 || T < 1 || N < 1 || H < 64 || (H & 63) || (ldh & 3)) return DVAE_EINVAL;
   for (int i = 0; i < ndir; ++i) {
@@ -550,7 +611,7 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
     if (!s.gates || !s.w_hh || !s.c_all) return DVAE_EINVAL;
     if (bwd ? (!s.dh_out || !s.dgates || !s.dc_ws) : (!s.h_out)) return DVAE_EINVAL;
     if ((((uintptr_t)s.w_hh) | ((uintptr_t)s.h_out) | ((uintptr_t)s.dgates)) & 15) return DVAE_EINVAL;
-    a.d[i].gates = s.gates; a.d[i].w = s.w_hh; a.d[i].h_out = s.h_out; a.d[i].c_all = s.c_all;
+    a.d[i].gates = s.gates; a.d[i].w = s.w_hh; a.d[i].wp = s.w_packed; a.d[i].h_out = s.h_out; a.d[i].c_all = s.c_all;
     a.d[i].dh_out = s.dh_out; a.d[i].dgates = s.dgates; a.d[i].dc = s.dc_ws; a.d[i].reverse = s.reverse;
   }
   if (ndir == 1) a.d[1] = a.d[0];
@@ -572,6 +633,15 @@ int pick_mt(int N, int H, int ndir) {
 
 }  // namespace
 
+DVAE_API int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream) {
+  if (!w_hh || (!packed_fwd && !packed_bwd) || H < 64 || (H & 63)) return DVAE_EINVAL;
+  const int64_t total = (int64_t)4 * (H / 16) * (H / 16) * 64;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(lstm_pack_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hh, packed_fwd, packed_bwd, H);
+  return dvae_check_launch();
+}
+
 DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
                                void* stream) {
   StepArgs a{};
@@ -582,14 +652,15 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
-  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 2;
+  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 4;
   const bool big = (H % 256) == 0;
+  const bool v4 = (ver == 4) && a.d[0].wp && a.d[ndir - 1].wp;
   for (int step = 0; step < T; ++step) {
-    if (ver == 3) {
-      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_fwd_v3<2, 256>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (mt == 2) hipLaunchKernelGGL((lstm_step_fwd_v3<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (big) hipLaunchKernelGGL((lstm_step_fwd_v3<1, 256>), grid, block, 0, s, a, step, n_j, n_m);
-      else hipLaunchKernelGGL((lstm_step_fwd_v3<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
+    if (v4) {
+      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_fwd_v4<2, 256>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (mt == 2) hipLaunchKernelGGL((lstm_step_fwd_v4<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (big) hipLaunchKernelGGL((lstm_step_fwd_v4<1, 256>), grid, block, 0, s, a, step, n_j, n_m);
+      else hipLaunchKernelGGL((lstm_step_fwd_v4<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
     } else if (mt == 2) {
       hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, s, a, step, n_j, n_m);
     } else {
@@ -609,14 +680,15 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
-  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 2;
+  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 4;
   const bool big = (H % 128) == 0;
+  const bool v4 = (ver == 4) && a.d[0].wp && a.d[ndir - 1].wp;
   for (int step = 0; step < T; ++step) {
-    if (ver == 3) {
-      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_bwd_v3<2, 128>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (mt == 2) hipLaunchKernelGGL((lstm_step_bwd_v3<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (big) hipLaunchKernelGGL((lstm_step_bwd_v3<1, 128>), grid, block, 0, s, a, step, n_j, n_m);
-      else hipLaunchKernelGGL((lstm_step_bwd_v3<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
+    if (v4) {
+      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_bwd_v4<2, 128>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (mt == 2) hipLaunchKernelGGL((lstm_step_bwd_v4<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
+      else if (big) hipLaunchKernelGGL((lstm_step_bwd_v4<1, 128>), grid, block, 0, s, a, step, n_j, n_m);
+      else hipLaunchKernelGGL((lstm_step_bwd_v4<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
     } else if (mt == 2) {
       hipLaunchKernelGGL((lstm_step_bwd_kernel<2>), grid, block, 0, s, a, step, n_j, n_m);
     } else {

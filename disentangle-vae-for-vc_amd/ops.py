@@ -312,21 +312,29 @@ class LstmLayerFn(torch.autograd.Function):
         h_out = torch.empty((R, ldh), device=dev, dtype=torch.float32)
         params = [(w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r)][:ndir]
         dirs = (_lib.LstmDir * ndir)()
-        gates, cells = [], []
+        gates, cells, packs_b, keep = [], [], [], []
         for d, (wi, wh, bi, bh) in enumerate(params):
             g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
             gemm(x, wi, g, bi + bh, R, 4 * H, In, In, In, 4 * H, True, True)
             c = torch.empty((R, H), device=dev, dtype=torch.float32)
+            # W_hh re-packed in MFMA fragment order (forward copy used now, backward copy saved)
+            wp_f = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
+            wp_b = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
+            check(L.dvae_lstm_pack_w(ptr(wh), ptr(wp_f), ptr(wp_b), H, st), "dvae_lstm_pack_w")
             gates.append(g)
             cells.append(c)
+            packs_b.append(wp_b)
+            keep.append(wp_f)
             dirs[d].gates = ptr(g)
             dirs[d].w_hh = ptr(wh)
+            dirs[d].w_packed = ptr(wp_f)
             dirs[d].h_out = h_out.data_ptr() + 4 * d * H
             dirs[d].c_all = ptr(c)
             dirs[d].reverse = d
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
-        ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
+        ctx.save_for_backward(x, h_out, *gates, *cells, *packs_b, *[p for ps in params for p in ps])
         ctx.cfg = (T, N, H, ndir)
+        del keep
         return h_out
 
     @staticmethod
@@ -336,7 +344,8 @@ class LstmLayerFn(torch.autograd.Function):
         x, h_out = sv[0], sv[1]
         gates = sv[2:2 + ndir]
         cells = sv[2 + ndir:2 + 2 * ndir]
-        flat = sv[2 + 2 * ndir:]
+        packs_b = sv[2 + 2 * ndir:2 + 3 * ndir]
+        flat = sv[2 + 3 * ndir:]
         params = [flat[4 * d:4 * d + 4] for d in range(ndir)]
         L = lib()
         st = stream()
@@ -355,6 +364,7 @@ class LstmLayerFn(torch.autograd.Function):
             dgs.append(dg)
             dirs[d].gates = ptr(gates[d])
             dirs[d].w_hh = ptr(wht)
+            dirs[d].w_packed = ptr(packs_b[d])
             dirs[d].c_all = ptr(cells[d])
             dirs[d].dh_out = dh.data_ptr() + 4 * d * H
             dirs[d].dgates = ptr(dg)

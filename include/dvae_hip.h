@@ -112,9 +112,13 @@ typedef struct {
   const float* dh_out;/* bwd only: [T,N,ldh] */
   float* dgates;      /* bwd only: [T,N,4H] */
   float* dc_ws;       /* bwd only: [N,H] */
+  const float* w_packed; /* optional: weights re-packed in MFMA fragment order by dvae_lstm_pack_w (fwd: packed_fwd,
+                            bwd: packed_bwd); when given, the faster 1-KiB-burst frame kernels are used */
   int reverse;        /* 0: t = 0..T-1, 1: t = T-1..0 */
   int pad_;
 } dvae_lstm_dir_t;
+/* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
+int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 
