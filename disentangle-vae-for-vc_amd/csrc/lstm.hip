@@ -404,17 +404,27 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_v4(const StepArgs a, int st
     loadW(wA, 0);
     storeA(0, sA);
     __syncthreads();
-    for (int rd = 0; rd < nr; rd += 2) {
-      loadA(sB, min(rd + 1, last));
-      loadW(wB, min(rd + 1, last));
+    if (nr == 1) {
       compute(0, wA);
-      storeA(1, sB);
-      __syncthreads();
-      loadA(sA, min(rd + 2, last));
-      loadW(wA, min(rd + 2, last));
-      if (rd + 1 < nr) compute(1, wB);
-      storeA(0, sA);
-      __syncthreads();
+    } else {
+      // nr is even (H is a multiple of 2*KR): both halves unconditional, so every load and its use sit in ONE
+      // basic block and hipcc cannot sink the prefetch loads down to their consumers
+      for (int rd = 0; rd < nr; rd += 2) {
+        loadA(sB, rd + 1);
+        loadW(wB, rd + 1);
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks it below)
+        compute(0, wA);
+        __builtin_amdgcn_sched_barrier(0);
+        storeA(1, sB);
+        __syncthreads();
+        loadA(sA, min(rd + 2, last));
+        loadW(wA, min(rd + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, wB);
+        __builtin_amdgcn_sched_barrier(0);
+        storeA(0, sA);
+        __syncthreads();
+      }
     }
   }
 #pragma unroll
@@ -535,19 +545,27 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int st
     loadB(bA, 0);
     storeA(0, sA);
     __builtin_amdgcn_wave_barrier();
-    for (int rd = 0; rd < nr; rd += 2) {
-      loadA(sB, min(rd + 1, last));
-      loadB(bB, min(rd + 1, last));
+    if (nr == 1) {
       compute(0, bA);
-      __builtin_amdgcn_wave_barrier();
-      storeA(1, sB);
-      __builtin_amdgcn_wave_barrier();
-      loadA(sA, min(rd + 2, last));
-      loadB(bA, min(rd + 2, last));
-      if (rd + 1 < nr) compute(1, bB);
-      __builtin_amdgcn_wave_barrier();
-      storeA(0, sA);
-      __builtin_amdgcn_wave_barrier();
+    } else {
+      for (int rd = 0; rd < nr; rd += 2) {      // nr even, see the forward kernel
+        loadA(sB, rd + 1);
+        loadB(bB, rd + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_wave_barrier();
+        storeA(1, sB);
+        __builtin_amdgcn_wave_barrier();
+        loadA(sA, min(rd + 2, last));
+        loadB(bA, min(rd + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_wave_barrier();
+        storeA(0, sA);
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 #pragma unroll
@@ -574,6 +592,266 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int st
     o[2 * H] = dc * gi * (1.f - gg * gg);
     o[3 * H] = dh * tc * go * (1.f - go);
     d.dc[(int64_t)n * H + j] = dc * gf;
+  }
+}
+
+
+// =====================================================================================================
+// v5 frame kernels: v4's data movement with EIGHT waves per workgroup over a 16-unit x 32-segment tile.
+// Measured on MI355X: a 32-row tile halves the W_hh re-read traffic but leaves one wave per SIMD
+// (latency-bound, 21 us/frame); a 16-row tile gives two waves per SIMD but doubles the traffic (18 us).
+// Eight waves = 4 gates (fwd) / k-quarters (bwd) x 2 k-halves give both: two waves per SIMD AND the
+// small traffic; the k-halves meet in the LDS reduction that the epilogue needs anyway.
+// =====================================================================================================
+template <int KR>
+__global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int step, int n_j, int n_m) {
+  constexpr int MT = 2, NW = 8;
+  constexpr int NS = KR / 16, LDA = KR + 4;
+  constexpr int NST = MT * KR / 64;     // float4 per thread per round (activation stage, both k-halves together)
+  const StepDir& d = a.d[blockIdx.z];
+  const int H = a.H, N = a.N;
+  const int t = d.reverse ? (a.T - 1 - step) : step;
+  const int tp = d.reverse ? t + 1 : t - 1;
+  int jb, mb;
+  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  const int j0 = jb * 16, m0 = mb * 16 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gate = wave & 3, kh = wave >> 2;
+  const int r = lane & 15, kq = lane >> 4;
+
+  __shared__ __attribute__((aligned(16))) float As[2][2][16 * MT * LDA];   // [buffer][k-half]
+  __shared__ float sm[NW][MT * 16][17];
+
+  // epilogue operands: one (segment, unit) element per thread
+  float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+  const int en = m0 + (tid >> 4), ej = j0 + (tid & 15);
+  const bool eok = en < N;
+  float pre[4], cp;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pre[g] = eok ? G[(int64_t)en * 4 * H + g * H + ej] : 0.f;
+  cp = (eok && step > 0) ? d.c_all[((int64_t)tp * N + en) * H + ej] : 0.f;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (step > 0) {
+    const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
+    const int nr = H / KR / 2, last = nr - 1;           // rounds per k-half
+    // packed W: [(gate*n_j + jb)][k-chunk of 16][lane][4]; this wave's chunks start at kh*(H/32)
+    const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / 16) + (int64_t)kh * (H / 32)) * 256 + lane * 4;
+    // staging: threads 0..255 stage k-half 0, 256..511 k-half 1; 16 lanes per 256-B row segment
+    const int skh = tid >> 8, srow = (tid & 255) >> 4, sc4 = tid & 15;
+    auto loadW = [&](f32x4 (&w)[NS], int rd) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS + s) * 256);
+    };
+    auto loadA = [&](f32x4 (&st)[NST], int rd) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int n = min(m0 + srow + 16 * i, N - 1);
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q)
+          st[i * (KR / 64) + q] = *reinterpret_cast<const f32x4*>(hp + (int64_t)n * a.ldh + (skh * nr + rd) * KR + 64 * q + 4 * sc4);
+      }
+    };
+    auto storeA = [&](int buf, f32x4 (&st)[NST]) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q)
+          *reinterpret_cast<f32x4*>(&As[buf][skh][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) = st[i * (KR / 64) + q];
+    };
+    auto compute = [&](int buf, f32x4 (&w)[NS]) {
+      const float* __restrict__ al = &As[buf][kh][r * LDA + 4 * kq];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        f32x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDA + 16 * s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w[s][e], acc[mt], 0, 0, 0);
+      }
+    };
+    f32x4 wA[NS], wB[NS], sA[NST], sB[NST];
+    loadA(sA, 0);
+    loadW(wA, 0);
+    storeA(0, sA);
+    __syncthreads();
+    if (nr == 1) {
+      compute(0, wA);
+    } else {
+      for (int rd = 0; rd < nr; rd += 2) {   // nr even
+        loadA(sB, rd + 1);
+        loadW(wB, rd + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0, wA);
+        __builtin_amdgcn_sched_barrier(0);
+        storeA(1, sB);
+        __syncthreads();
+        loadA(sA, min(rd + 2, last));
+        loadW(wA, min(rd + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, wB);
+        __builtin_amdgcn_sched_barrier(0);
+        storeA(0, sA);
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
+  __syncthreads();
+
+  if (eok) {
+    const int row = tid >> 4, col = tid & 15;
+    float* g = G + (int64_t)en * 4 * H + ej;
+    const float gi = sigmoidf_(sm[0][row][col] + sm[4][row][col] + pre[0]);
+    const float gf = sigmoidf_(sm[1][row][col] + sm[5][row][col] + pre[1]);
+    const float gg = tanhf(sm[2][row][col] + sm[6][row][col] + pre[2]);
+    const float go = sigmoidf_(sm[3][row][col] + sm[7][row][col] + pre[3]);
+    const float c = gf * cp + gi * gg;
+    g[0] = gi;
+    g[H] = gf;
+    g[2 * H] = gg;
+    g[3 * H] = go;
+    d.c_all[((int64_t)t * N + en) * H + ej] = c;
+    d.h_out[((int64_t)t * N + en) * a.ldh + ej] = go * tanhf(c);
+  }
+}
+
+template <int KR>
+__global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int step, int n_j, int n_m) {
+  constexpr int MT = 2, NW = 8;
+  constexpr int NS = KR / 16, LDA = KR + 4;
+  const StepDir& d = a.d[blockIdx.z];
+  const int H = a.H, N = a.N;
+  const int fstep = a.T - 1 - step;
+  const int t = d.reverse ? (a.T - 1 - fstep) : fstep;
+  const int tn = d.reverse ? t - 1 : t + 1;
+  const int tp = d.reverse ? t + 1 : t - 1;
+  int jb, mb;
+  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  const int j0 = jb * 16, m0 = mb * 16 * MT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quarter = wave >> 1, part = wave & 1;      // k range: [quarter*H + part*H/2, +H/2)
+  const int r = lane & 15, kq = lane >> 4;
+
+  __shared__ __attribute__((aligned(16))) float Ast[NW][2 * 16 * MT * LDA];   // per wave, two buffers
+  __shared__ float sm[NW][MT * 16][17];
+
+  const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+  const int en = m0 + (tid >> 4), ej = j0 + (tid & 15);
+  const bool eok = en < N;
+  float gt[4], cc, cp, dho, dcar;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) gt[g] = eok ? G[(int64_t)en * 4 * H + g * H + ej] : 0.f;
+  cc = eok ? d.c_all[((int64_t)t * N + en) * H + ej] : 0.f;
+  cp = (eok && fstep > 0) ? d.c_all[((int64_t)tp * N + en) * H + ej] : 0.f;
+  dho = eok ? d.dh_out[((int64_t)t * N + en) * a.ldh + ej] : 0.f;
+  dcar = (eok && step > 0) ? d.dc[(int64_t)en * H + ej] : 0.f;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (step > 0) {
+    const int H4 = 4 * H;
+    const int koff = quarter * H + part * (H / 2);
+    // packed W^T: [(jb*4 + quarter)][k-chunk of 16 inside the quarter][lane][4]
+    const float* __restrict__ bpk = d.wp + (((int64_t)jb * 4 + quarter) * (H / 16) + (int64_t)part * (H / 32)) * 256 + lane * 4;
+    float* __restrict__ stg = &Ast[wave][0];
+    const int lrow = lane >> 4, lc4 = lane & 15;
+    const float* arow[4 * MT];
+#pragma unroll
+    for (int i = 0; i < 4 * MT; ++i) {
+      const int n = min(m0 + lrow + 4 * i, N - 1);
+      arow[i] = d.dgates + ((int64_t)tn * N + n) * H4 + koff + 4 * lc4;
+    }
+    const int nr = H / 2 / KR, last = nr - 1;
+    auto loadA = [&](f32x4 (&st)[4 * MT][KR / 64], int rd) {
+#pragma unroll
+      for (int i = 0; i < 4 * MT; ++i)
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q) st[i][q] = *reinterpret_cast<const f32x4*>(arow[i] + rd * KR + 64 * q);
+    };
+    auto storeA = [&](int buf, f32x4 (&st)[4 * MT][KR / 64]) {
+#pragma unroll
+      for (int i = 0; i < 4 * MT; ++i)
+#pragma unroll
+        for (int q = 0; q < KR / 64; ++q)
+          *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
+    };
+    auto loadB = [&](f32x4 (&b)[NS], int rd) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS + s) * 256);
+    };
+    auto compute = [&](int buf, f32x4 (&b)[NS]) {
+      const float* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 4 * kq;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        f32x4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDA + 16 * s);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], b[s][e], acc[mt], 0, 0, 0);
+      }
+    };
+    f32x4 bA[NS], bB[NS], sA[4 * MT][KR / 64], sB[4 * MT][KR / 64];
+    loadA(sA, 0);
+    loadB(bA, 0);
+    storeA(0, sA);
+    __builtin_amdgcn_wave_barrier();
+    if (nr == 1) {
+      compute(0, bA);
+    } else {
+      for (int rd = 0; rd < nr; rd += 2) {   // nr even
+        loadA(sB, rd + 1);
+        loadB(bB, rd + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0, bA);
+        __builtin_amdgcn_sched_barrier(0);
+        storeA(1, sB);
+        __builtin_amdgcn_wave_barrier();
+        loadA(sA, min(rd + 2, last));
+        loadB(bA, min(rd + 2, last));
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1, bB);
+        __builtin_amdgcn_sched_barrier(0);
+        storeA(0, sA);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
+  __syncthreads();
+
+  if (eok) {
+    const int row = tid >> 4, col = tid & 15;
+    float rec = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) rec += sm[w][row][col];
+    const float dh = dho + rec;
+    const float gi = gt[0], gf = gt[1], gg = gt[2], go = gt[3];
+    const float tc = tanhf(cc);
+    const float dc = dcar + dh * go * (1.f - tc * tc);
+    float* o = d.dgates + ((int64_t)t * N + en) * 4 * H + ej;
+    o[0] = dc * gg * gi * (1.f - gi);
+    o[H] = dc * cp * gf * (1.f - gf);
+    o[2 * H] = dc * gi * (1.f - gg * gg);
+    o[3 * H] = dh * tc * go * (1.f - go);
+    d.dc[(int64_t)en * H + ej] = dc * gf;
   }
 }
 
@@ -652,9 +930,17 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
-  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 4;
+  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
   const bool big = (H % 256) == 0;
-  const bool v4 = (ver == 4) && a.d[0].wp && a.d[ndir - 1].wp;
+  const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
+  const bool v5 = v4 && (ver == 5) && H >= 1024 && (H % 512) == 0;   // eight-wave kernels (win at H = 1024, lose at 512: too few workgroups)
+  if (v5) {
+    const int n_m5 = (N + 31) / 32;
+    dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
+    for (int step = 0; step < T; ++step)
+      hipLaunchKernelGGL((lstm_step_fwd_v5<128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+    return dvae_check_launch();
+  }
   for (int step = 0; step < T; ++step) {
     if (v4) {
       if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_fwd_v4<2, 256>), grid, block, 0, s, a, step, n_j, n_m);
@@ -680,9 +966,17 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
-  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 4;
+  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
   const bool big = (H % 128) == 0;
-  const bool v4 = (ver == 4) && a.d[0].wp && a.d[ndir - 1].wp;
+  const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
+  const bool v5 = v4 && (ver == 5) && H >= 1024 && (H % 256) == 0;
+  if (v5) {
+    const int n_m5 = (N + 31) / 32;
+    dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
+    for (int step = 0; step < T; ++step)
+      hipLaunchKernelGGL((lstm_step_bwd_v5<64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+    return dvae_check_launch();
+  }
   for (int step = 0; step < T; ++step) {
     if (v4) {
       if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_bwd_v4<2, 128>), grid, block, 0, s, a, step, n_j, n_m);
