@@ -61,3 +61,7 @@ __device__ __forceinline__ float act_grad_from_out(float z, int act) {
   return 1.f;
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate non-linearities of the LSTM frame kernels: v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of the libm
+// routines (tens of instructions with branches; at H = 64 they were 60 % of a frame).  Absolute error ~1e-7.
+__device__ __forceinline__ float gate_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float gate_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }

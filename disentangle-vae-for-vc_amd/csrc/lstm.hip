@@ -185,17 +185,17 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
     if (n >= N) continue;
     const int j = j0 + col;
     float* g = G + (int64_t)n * 4 * H + j;
-    const float gi = sigmoidf_(sm[0][row][col] + pre[e][0]);
-    const float gf = sigmoidf_(sm[1][row][col] + pre[e][1]);
-    const float gg = tanhf(sm[2][row][col] + pre[e][2]);
-    const float go = sigmoidf_(sm[3][row][col] + pre[e][3]);
+    const float gi = gate_sigmoid(sm[0][row][col] + pre[e][0]);
+    const float gf = gate_sigmoid(sm[1][row][col] + pre[e][1]);
+    const float gg = gate_tanh(sm[2][row][col] + pre[e][2]);
+    const float go = gate_sigmoid(sm[3][row][col] + pre[e][3]);
     const float c = gf * cp[e] + gi * gg;
     g[0] = gi;
     g[H] = gf;
     g[2 * H] = gg;
     g[3 * H] = go;
     cout[(int64_t)n * H + j] = c;
-    hout[(int64_t)n * a.ldh + j] = go * tanhf(c);
+    hout[(int64_t)n * a.ldh + j] = go * gate_tanh(c);
   }
 }
 
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
     const int j = j0 + col;
     const float dh = dho[e] + sm[0][row][col] + sm[1][row][col] + sm[2][row][col] + sm[3][row][col];
     const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
-    const float tc = tanhf(cc[e]);
+    const float tc = gate_tanh(cc[e]);
     const float dc = dcar[e] + dh * go * (1.f - tc * tc);
     float* o = dG + (int64_t)n * 4 * H + j;
     o[0] = dc * gg * gi * (1.f - gi);
@@ -443,17 +443,17 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_v4(const StepArgs a, int st
     if (n >= N) continue;
     const int j = j0 + col;
     float* g = G + (int64_t)n * 4 * H + j;
-    const float gi = sigmoidf_(sm[0][row][col] + pre[e][0]);
-    const float gf = sigmoidf_(sm[1][row][col] + pre[e][1]);
-    const float gg = tanhf(sm[2][row][col] + pre[e][2]);
-    const float go = sigmoidf_(sm[3][row][col] + pre[e][3]);
+    const float gi = gate_sigmoid(sm[0][row][col] + pre[e][0]);
+    const float gf = gate_sigmoid(sm[1][row][col] + pre[e][1]);
+    const float gg = gate_tanh(sm[2][row][col] + pre[e][2]);
+    const float go = gate_sigmoid(sm[3][row][col] + pre[e][3]);
     const float c = gf * cp[e] + gi * gg;
     g[0] = gi;
     g[H] = gf;
     g[2 * H] = gg;
     g[3 * H] = go;
     cout[(int64_t)n * H + j] = c;
-    hout[(int64_t)n * a.ldh + j] = go * tanhf(c);
+    hout[(int64_t)n * a.ldh + j] = go * gate_tanh(c);
   }
 }
 
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int st
     const int j = j0 + col;
     const float dh = dho[e] + sm[0][row][col] + sm[1][row][col] + sm[2][row][col] + sm[3][row][col];
     const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
-    const float tc = tanhf(cc[e]);
+    const float tc = gate_tanh(cc[e]);
     const float dc = dcar[e] + dh * go * (1.f - tc * tc);
     float* o = dG + (int64_t)n * 4 * H + j;
     o[0] = dc * gg * gi * (1.f - gi);
@@ -711,17 +711,17 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
   if (eok) {
     const int row = tid >> 4, col = tid & 15;
     float* g = G + (int64_t)en * 4 * H + ej;
-    const float gi = sigmoidf_(sm[0][row][col] + sm[4][row][col] + pre[0]);
-    const float gf = sigmoidf_(sm[1][row][col] + sm[5][row][col] + pre[1]);
-    const float gg = tanhf(sm[2][row][col] + sm[6][row][col] + pre[2]);
-    const float go = sigmoidf_(sm[3][row][col] + sm[7][row][col] + pre[3]);
+    const float gi = gate_sigmoid(sm[0][row][col] + sm[4][row][col] + pre[0]);
+    const float gf = gate_sigmoid(sm[1][row][col] + sm[5][row][col] + pre[1]);
+    const float gg = gate_tanh(sm[2][row][col] + sm[6][row][col] + pre[2]);
+    const float go = gate_sigmoid(sm[3][row][col] + sm[7][row][col] + pre[3]);
     const float c = gf * cp + gi * gg;
     g[0] = gi;
     g[H] = gf;
     g[2 * H] = gg;
     g[3 * H] = go;
     d.c_all[((int64_t)t * N + en) * H + ej] = c;
-    d.h_out[((int64_t)t * N + en) * a.ldh + ej] = go * tanhf(c);
+    d.h_out[((int64_t)t * N + en) * a.ldh + ej] = go * gate_tanh(c);
   }
 }
 
@@ -844,7 +844,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
     for (int w = 0; w < NW; ++w) rec += sm[w][row][col];
     const float dh = dho + rec;
     const float gi = gt[0], gf = gt[1], gg = gt[2], go = gt[3];
-    const float tc = tanhf(cc);
+    const float tc = gate_tanh(cc);
     const float dc = dcar + dh * go * (1.f - tc * tc);
     float* o = d.dgates + ((int64_t)t * N + en) * 4 * H + ej;
     o[0] = dc * gg * gi * (1.f - gi);
@@ -852,6 +852,208 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
     o[2 * H] = dc * gi * (1.f - gg * gg);
     o[3 * H] = dh * tc * go * (1.f - go);
     d.dc[(int64_t)en * H + ej] = dc * gf;
+  }
+}
+
+
+// =====================================================================================================
+// H = 64 (the encoder BiLSTM): the recurrence of a mel segment depends only on that segment's own rows, and at
+// H = 64 one workgroup can hold W_hh in registers and do a whole frame's gate GEMM in ~1 us.  So a workgroup
+// owns 16 segments of one direction and walks ALL T frames inside ONE launch -- no inter-workgroup dependency,
+// no grid barrier, 2 launches per layer instead of 2*T.  (At H >= 512 a row-split would stream all of W_hh per
+// workgroup per frame, so those sizes keep the one-launch-per-frame kernels above.)
+// =====================================================================================================
+__global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
+  constexpr int H = 64;
+  const StepDir& d = a.d[blockIdx.y];
+  const int N = a.N, T = a.T;
+  const int m0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gate = wave & 3, half = wave >> 2;
+  const int r = lane & 15, kq = lane >> 4;
+
+  __shared__ __attribute__((aligned(16))) float hs[16][68];     // h[t-1] rows, k-contiguous
+  __shared__ float gs[4][16][65];                                // recurrent pre-activation [gate][row][unit]
+
+  f32x4 wf[2][4];   // this wave's W_hh fragments: 2 n-tiles x 4 k-chunks, resident for the whole sequence
+#pragma unroll
+  for (int ntl = 0; ntl < 2; ++ntl)
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+      wf[ntl][kc] = *reinterpret_cast<const f32x4*>(d.w + ((int64_t)(gate * H + (half * 2 + ntl) * 16 + r)) * H + kc * 16 + 4 * kq);
+
+  int erow[2], ej[2];
+  bool eok[2];
+  float creg[2] = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 512 * e;
+    erow[e] = idx >> 6;
+    ej[e] = idx & 63;
+    eok[e] = (m0 + erow[e]) < N;
+    hs[erow[e]][ej[e]] = 0.f;
+  }
+  __syncthreads();
+
+  // the pre-activations of frame step+1 are fetched while frame step computes (their latency, ~1 us from L2,
+  // is several times one frame's work here)
+  float xn[2][4];
+  auto fetch = [&](int step_, float (&x)[2][4]) {
+    const int t_ = d.reverse ? (T - 1 - step_) : step_;
+    const float* __restrict__ G_ = d.gates + (int64_t)t_ * N * 4 * H;
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) x[e][g] = eok[e] ? G_[(int64_t)(m0 + erow[e]) * 4 * H + g * H + ej[e]] : 0.f;
+  };
+  fetch(0, xn);
+  for (int step = 0; step < T; ++step) {
+    const int t = d.reverse ? (T - 1 - step) : step;
+    float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+    float xp[2][4];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xp[e][g] = xn[e][g];
+    fetch(min(step + 1, T - 1), xn);
+
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&hs[r][kc * 16 + 4 * kq]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[0][kc][e], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[1][kc][e], acc[1], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ntl = 0; ntl < 2; ++ntl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gs[gate][kq * 4 + q][(half * 2 + ntl) * 16 + r] = acc[ntl][q];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int row = erow[e], j = ej[e];
+      const float gi = gate_sigmoid(gs[0][row][j] + xp[e][0]);
+      const float gf = gate_sigmoid(gs[1][row][j] + xp[e][1]);
+      const float gg = gate_tanh(gs[2][row][j] + xp[e][2]);
+      const float go = gate_sigmoid(gs[3][row][j] + xp[e][3]);
+      const float c = gf * creg[e] + gi * gg;
+      const float h = go * gate_tanh(c);
+      creg[e] = c;
+      hs[row][j] = eok[e] ? h : 0.f;
+      if (eok[e]) {
+        const int64_t n = m0 + row;
+        float* g = G + n * 4 * H + j;
+        g[0] = gi;
+        g[H] = gf;
+        g[2 * H] = gg;
+        g[3 * H] = go;
+        d.c_all[((int64_t)t * N + n) * H + j] = c;
+        d.h_out[((int64_t)t * N + n) * a.ldh + j] = h;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
+  constexpr int H = 64;
+  const StepDir& d = a.d[blockIdx.y];   // d.w = W_hh^T [H][4H]
+  const int N = a.N, T = a.T;
+  const int m0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = wave & 3, khalf = wave >> 2;
+  const int r = lane & 15, kq = lane >> 4;
+
+  __shared__ __attribute__((aligned(16))) float dgs[16][260];   // dG[t+1] rows (k = gate*64 + unit)
+  __shared__ float rs[2][16][65];                               // partial dHrec per k-half
+
+  f32x4 wf[8];
+#pragma unroll
+  for (int kc = 0; kc < 8; ++kc)
+    wf[kc] = *reinterpret_cast<const f32x4*>(d.w + (int64_t)(nt * 16 + r) * 4 * H + khalf * 128 + kc * 16 + 4 * kq);
+
+  int erow[2], ej[2];
+  bool eok[2];
+  float dcreg[2] = {0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + 512 * e;
+    erow[e] = idx >> 6;
+    ej[e] = idx & 63;
+    eok[e] = (m0 + erow[e]) < N;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dgs[erow[e]][g * H + ej[e]] = 0.f;
+  }
+  __syncthreads();
+
+  float gtn[2][4], ccn[2], cpn[2], dhon[2];
+  auto fetch = [&](int step_, float (&g_)[2][4], float (&cc_)[2], float (&cp_)[2], float (&dh_)[2]) {
+    const int fs = T - 1 - step_;
+    const int t_ = d.reverse ? (T - 1 - fs) : fs;
+    const int tp_ = d.reverse ? t_ + 1 : t_ - 1;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int64_t n = m0 + erow[e];
+      const int j = ej[e];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) g_[e][g] = eok[e] ? d.gates[((int64_t)t_ * N + n) * 4 * H + g * H + j] : 0.f;
+      cc_[e] = eok[e] ? d.c_all[((int64_t)t_ * N + n) * H + j] : 0.f;
+      cp_[e] = (eok[e] && fs > 0) ? d.c_all[((int64_t)tp_ * N + n) * H + j] : 0.f;
+      dh_[e] = eok[e] ? d.dh_out[((int64_t)t_ * N + n) * a.ldh + j] : 0.f;
+    }
+  };
+  fetch(0, gtn, ccn, cpn, dhon);
+  for (int step = 0; step < T; ++step) {
+    const int fstep = T - 1 - step;
+    const int t = d.reverse ? (T - 1 - fstep) : fstep;
+    float gt[2][4], cc[2], cp[2], dho[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gt[e][g] = gtn[e][g];
+      cc[e] = ccn[e];
+      cp[e] = cpn[e];
+      dho[e] = dhon[e];
+    }
+    fetch(min(step + 1, T - 1), gtn, ccn, cpn, dhon);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(&dgs[r][khalf * 128 + kc * 16 + 4 * kq]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[kc][e], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rs[khalf][kq * 4 + q][nt * 16 + r] = acc[q];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int row = erow[e], j = ej[e];
+      const float dh = dho[e] + rs[0][row][j] + rs[1][row][j];
+      const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
+      const float tc = gate_tanh(cc[e]);
+      const float dc = dcreg[e] + dh * go * (1.f - tc * tc);
+      const float o0 = dc * gg * gi * (1.f - gi);
+      const float o1 = dc * cp[e] * gf * (1.f - gf);
+      const float o2 = dc * gi * (1.f - gg * gg);
+      const float o3 = dh * tc * go * (1.f - go);
+      dcreg[e] = dc * gf;
+      dgs[row][j] = eok[e] ? o0 : 0.f;
+      dgs[row][H + j] = eok[e] ? o1 : 0.f;
+      dgs[row][2 * H + j] = eok[e] ? o2 : 0.f;
+      dgs[row][3 * H + j] = eok[e] ? o3 : 0.f;
+      if (eok[e]) {
+        float* o = d.dgates + ((int64_t)t * N + m0 + row) * 4 * H + j;
+        o[0] = o0;
+        o[H] = o1;
+        o[2 * H] = o2;
+        o[3 * H] = o3;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -932,6 +1134,10 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
   static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
   const bool big = (H % 256) == 0;
+  if (H == 64 && ver >= 4) {   // whole sequence in one launch (row-split, no inter-workgroup dependency)
+    hipLaunchKernelGGL(lstm_seq_fwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    return dvae_check_launch();
+  }
   const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
   const bool v5 = v4 && (ver == 5) && H >= 1024 && (H % 512) == 0;   // eight-wave kernels (win at H = 1024, lose at 512: too few workgroups)
   if (v5) {
@@ -968,6 +1174,10 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
   static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
   const bool big = (H % 128) == 0;
+  if (H == 64 && ver >= 4) {
+    hipLaunchKernelGGL(lstm_seq_bwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    return dvae_check_launch();
+  }
   const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
   const bool v5 = v4 && (ver == 5) && H >= 1024 && (H % 256) == 0;
   if (v5) {
