@@ -108,9 +108,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_ddp = os.environ.get("DVAE_FORCE_DDP", "0") == "1"      # exercise the RCCL path with one rank (testing)
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     import dvae_amd
     from dvae_amd import ddp, ops
@@ -121,19 +123,20 @@ def main():
     w = dvae_amd.ConvolutionalMulVAE("VCTK", T, 80, 32, 1e-4, 0.01, 500, False, batch_size=B, speaker_size=4,
                                      device=dev, latent_dim=32, mse_cof=10, kl_cof=10)
     w.model.train()
-    if world > 1:
+    if world > 1 or force_ddp:
         ddp.broadcast_parameters(w.optimizer.flat_p, [b for b in w.model.buffers()])
         red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets)
+        red.force = force_ddp
         w.attach_reducer(red)
     data = SyntheticPairs(B, T, n_speakers=10, seed=1234 + rank, device=dev)
     x1, x2, spk = data.batch()
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph) and world == 1 and not force_ddp
     if use_graph:
         w.enable_graph(True)
     log(f"rank {rank}/{world}: model built ({sum(p.numel() for p in w.model.parameters())} params), warm-up x{args.warmup}")
@@ -174,7 +177,7 @@ def main():
                     "flops_per_step": flops / prof_steps,
                     "timed": "HIP events around every launch, " + ("inside the timed region" if prof_live else
                              f"{prof_steps} eager steps right after the graph-replayed timed region")}
-    if world > 1:
+    if world > 1 or force_ddp:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -204,7 +207,7 @@ def main():
             if cb.get("value"):
                 out["speedup_vs_cpu_baseline"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
 
