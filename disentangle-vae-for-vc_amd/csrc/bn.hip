@@ -11,69 +11,86 @@
 
 namespace {
 
-constexpr int ROWS_PER_CHUNK = 256;
+constexpr int ROWS_PER_CHUNK = 128;
 
 __host__ __device__ inline int n_chunks(int R) { return (R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK; }
 
 // partial[chunk][g][c][2] (fp64): sum and sum of squares (MODE 0), or sum(dU) and sum(dU*yhat) (MODE 1)
+// 64 channel-quads x 4 row lanes per workgroup, 16-byte loads; fp64 accumulation per thread.
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ Y, const float* __restrict__ dZ,
                                                          const float* __restrict__ Z, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, double* __restrict__ part,
                                                          int R, int N, int C, int G, int act) {
-  // block: 64 channel lanes x 4 row lanes ; grid: (ceil(C/64), chunks)
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = (blockIdx.x * 64 + cl) * 4;       // C % 4 == 0
   const int r0 = blockIdx.y * ROWS_PER_CHUNK;
   const int r1 = min(R, r0 + ROWS_PER_CHUNK);
   const int per = N / G;
-  double s00 = 0.0, s01 = 0.0, s10 = 0.0, s11 = 0.0;
+  double s[2][2][4];   // [group][stat][lane-of-quad]; indices are compile-time after unrolling
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s[g][q][k] = 0.0;
   if (c < C) {
-    float mu0 = 0.f, mu1 = 0.f, rs0 = 1.f, rs1 = 1.f;
+    f32x4 mu0 = {0.f, 0.f, 0.f, 0.f}, mu1 = mu0, rs0 = {1.f, 1.f, 1.f, 1.f}, rs1 = rs0;
     if (MODE == 1) {
-      mu0 = mean[c];
-      rs0 = rstd[c];
+      mu0 = *reinterpret_cast<const f32x4*>(mean + c);
+      rs0 = *reinterpret_cast<const f32x4*>(rstd + c);
       if (G > 1) {
-        mu1 = mean[C + c];
-        rs1 = rstd[C + c];
+        mu1 = *reinterpret_cast<const f32x4*>(mean + C + c);
+        rs1 = *reinterpret_cast<const f32x4*>(rstd + C + c);
       }
     }
     for (int r = r0 + rl; r < r1; r += 4) {
-      const int g = (r % N) / per;
-      const float y = Y[(int64_t)r * C + c];
-      double v0, v1;
-      if (MODE == 0) {
-        v0 = (double)y;
-        v1 = (double)y * (double)y;
-      } else {
-        const float du = dZ[(int64_t)r * C + c] * act_grad_from_out(Z[(int64_t)r * C + c], act);
-        const float yh = (y - (g ? mu1 : mu0)) * (g ? rs1 : rs0);
-        v0 = (double)du;
-        v1 = (double)du * (double)yh;
+      const bool g1 = ((r % N) / per) != 0;
+      const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (int64_t)r * C + c);
+      f32x4 dz = y, z = y;
+      if (MODE == 1) {
+        dz = *reinterpret_cast<const f32x4*>(dZ + (int64_t)r * C + c);
+        z = *reinterpret_cast<const f32x4*>(Z + (int64_t)r * C + c);
       }
-      if (g == 0) {
-        s00 += v0;
-        s01 += v1;
-      } else {
-        s10 += v0;
-        s11 += v1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double v0, v1;
+        if (MODE == 0) {
+          v0 = (double)y[k];
+          v1 = (double)y[k] * (double)y[k];
+        } else {
+          const float du = dz[k] * act_grad_from_out(z[k], act);
+          const float yh = (y[k] - (g1 ? mu1[k] : mu0[k])) * (g1 ? rs1[k] : rs0[k]);
+          v0 = (double)du;
+          v1 = (double)du * (double)yh;
+        }
+        if (g1) {
+          s[1][0][k] += v0;
+          s[1][1][k] += v1;
+        } else {
+          s[0][0][k] += v0;
+          s[0][1][k] += v1;
+        }
       }
     }
   }
-  __shared__ double red[4][64][4];
-  red[rl][cl][0] = s00;
-  red[rl][cl][1] = s01;
-  red[rl][cl][2] = s10;
-  red[rl][cl][3] = s11;
-  __syncthreads();
-  if (rl == 0 && c < C) {
-    double o[4];
+  __shared__ double red[4][64][4];   // reused per (group, stat)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
-    for (int g = 0; g < G; ++g) {
-      double* p = part + (((int64_t)blockIdx.y * G + g) * C + c) * 2;
-      p[0] = o[2 * g];
-      p[1] = o[2 * g + 1];
+  for (int g = 0; g < 2; ++g) {
+    if (g >= G) break;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[rl][cl][k] = s[g][q][k];
+      __syncthreads();
+      if (rl == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double tot = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
+          part[(((int64_t)blockIdx.y * G + g) * C + c + k) * 2 + q] = tot;
+        }
+      }
     }
   }
 }
@@ -234,7 +251,7 @@ DVAE_API int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* 
   hipStream_t s = (hipStream_t)stream;
   const int ch = n_chunks(R);
   double* part = (double*)ws;
-  dim3 grid((C + 63) / 64, ch);
+  dim3 grid((C + 255) / 256, ch);
   hipLaunchKernelGGL((bn_partial_kernel<0>), grid, dim3(256), 0, s, Y, nullptr, nullptr, nullptr, nullptr, part, R, N,
                      C, G, 0);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, mean, rstd,
@@ -261,7 +278,7 @@ DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const 
   const int ch = n_chunks(R);
   double* part = (double*)ws;
   float* s12 = (float*)((char*)ws + (int64_t)ch * G * C * 2 * sizeof(double));
-  dim3 grid((C + 63) / 64, ch);
+  dim3 grid((C + 255) / 256, ch);
   hipLaunchKernelGGL((bn_partial_kernel<1>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, s12, dgamma, dbeta, ch, C,
                      G);

@@ -262,22 +262,34 @@ __global__ __launch_bounds__(256) void permute_102_kernel(const float* __restric
   }
 }
 
-constexpr int CS_ROWS = 512;
+constexpr int CS_ROWS = 128;
+// out[c] += sum_r X[r][c]: 64 column-quads x 4 row lanes per workgroup, 16-byte loads (1 KiB per wave per row)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ o1,
                                                      float* __restrict__ o2, int R, int C, int64_t ld) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  const int c = (blockIdx.x * 64 + cl) * 4;
   const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
-  float s = 0.f;
-  if (c < C)
-    for (int r = r0 + rl; r < r1; r += 4) s += X[(int64_t)r * ld + c];
-  __shared__ float red[4][64];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c + 3 < C) {
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ld + c);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+  } else if (c < C) {
+    for (int r = r0 + rl; r < r1; r += 4)
+      for (int k = 0; k < 4 && c + k < C; ++k) s[k] += X[(int64_t)r * ld + c + k];
+  }
+  __shared__ f32x4 red[4][64];
   red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < C) {
-    const float tot = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
-    atomicAdd(o1 + c, tot);
-    if (o2) atomicAdd(o2 + c, tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c + k >= C) break;
+      const float tot = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
+      atomicAdd(o1 + c + k, tot);
+      if (o2) atomicAdd(o2 + c + k, tot);
+    }
   }
 }
 
@@ -438,7 +450,8 @@ DVAE_API int dvae_permute_102(const float* in, float* out, int A, int B, int C, 
 
 DVAE_API int dvae_colsum_add(const float* X, float* out1, float* out2, int R, int C, int64_t ld, void* stream) {
   if (!X || !out1 || R < 1 || C < 1) return DVAE_EINVAL;
-  dim3 grid((C + 63) / 64, (R + CS_ROWS - 1) / CS_ROWS);
+  if ((ld & 3) || (((uintptr_t)X) & 15)) return DVAE_EINVAL;
+  dim3 grid((C + 255) / 256, (R + CS_ROWS - 1) / CS_ROWS);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld);
   return dvae_check_launch();
 }
