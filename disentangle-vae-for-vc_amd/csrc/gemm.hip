@@ -235,54 +235,61 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
       load_tiles(tap_n, kit_n);
       advance();
     }
-    // ---- all fragments of this k-tile: index c*4+e <-> k = 8c + 4*kh + e
-    float av[2][BK / 2], bv[NTW][BK / 2];
+    // ---- fragments in 8-deep k groups: group c, element e <-> k = 8c + 4*kh + e.  The reads of group c+1 are
+    // issued BEFORE the 4*2*NTW MFMAs of group c (two register sets, order pinned with sched_barrier), so the LDS
+    // round trip runs under the matrix pipe instead of between MFMA bursts (measured: the burst structure hipcc
+    // picks on its own leaves the pipe idle ~20 % of the time even without any barrier).
+    auto read_group = [&](int c, float (&av)[2][4], float (&bv)[NTW][4]) {
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (A_KC) {
-        const float* src = &As[cur][a_frag + mt * 32 * LDA];
+      for (int mt = 0; mt < 2; ++mt) {
+        if (A_KC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&As[cur][a_frag + mt * 32 * LDA + 8 * c]);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * c);
+          for (int e = 0; e < 4; ++e) av[mt][e] = v[e];
+        } else {
+          const float* src = &As[cur][a_frag + mt * 32];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) av[mt][4 * c + e] = v[e];
+          for (int e = 0; e < 4; ++e) av[mt][e] = src[(8 * c + e) * LDA];
         }
-      } else {
-        const float* src = &As[cur][a_frag + mt * 32];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) av[mt][4 * c + e] = src[(8 * c + e) * LDA];
       }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      if (B_KC) {
-        const float* src = &Bs[cur][b_frag + nt * 32 * LDB];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 8 * c);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[nt][4 * c + e] = v[e];
-        }
-      } else {
-        const float* src = &Bs[cur][b_frag + nt * 32];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bv[nt][4 * c + e] = src[(8 * c + e) * LDB];
-      }
-    }
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
 #pragma unroll
       for (int nt = 0; nt < NTW; ++nt) {
-        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][s], bv[nt][s], acc[0][nt], 0, 0, 0);
-        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][s], bv[nt][s], acc[1][nt], 0, 0, 0);
+        if (B_KC) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[cur][b_frag + nt * 32 * LDB + 8 * c]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[nt][e] = v[e];
+        } else {
+          const float* src = &Bs[cur][b_frag + nt * 32];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[nt][e] = src[(8 * c + e) * LDB];
+        }
       }
+    };
+    auto mfma_group = [&](float (&av)[2][4], float (&bv)[NTW][4]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][e], bv[nt][e], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][e], bv[nt][e], acc[1][nt], 0, 0, 0);
+        }
+      }
+    };
+    float a0[2][4], b0[NTW][4], a1[2][4], b1[NTW][4];
+    read_group(0, a0, b0);
+#pragma unroll
+    for (int c = 0; c < NC; c += 2) {
+      if (c + 1 < NC) read_group(c + 1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < NC) read_group(c + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < NC) mfma_group(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) store_tiles(cur ^ 1);
-    __syncthreads();
+    if (more && !(p.prio_mode & 16)) store_tiles(cur ^ 1);
+    if (!(p.prio_mode & 8)) __syncthreads();
     cur ^= 1;
   }
 
@@ -332,16 +339,17 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
 template <bool AK, bool BKC>
 void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk) {
   dim3 block(NTHR);
+  static const int dyn = getenv("DVAE_GEMM_DYNLDS") ? atoi(getenv("DVAE_GEMM_DYNLDS")) : 0;   // experiment: cap occupancy
   if (bk == 32) {
     if (narrow)
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32>), grid, block, dyn, s, p);
     else
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32>), grid, block, dyn, s, p);
   } else {
     if (narrow)
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16>), grid, block, dyn, s, p);
     else
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16>), grid, block, dyn, s, p);
   }
 }
 

@@ -247,3 +247,20 @@ def test_config0_run_training_and_resume(tmp_path):
     assert "enc_lstm.weight_hh_l1_reverse" in sd and "dec_modules.2.0.weight" in sd     # reference key names
     hist2 = cli.main(argv[:7] + ["--epochs=1"] + argv[8:])                               # resumes at epoch 5
     assert [h["epoch"] for h in hist2] == [5]
+
+
+@pytest.mark.parametrize("B,T", [(2, 256), (1, 512)])
+def test_long_segments_against_oracle(B, T):
+    """The frame counts of BASELINE configs[2] / configs[4] (T = 256 / 512, fp32 here): losses vs the CPU oracle."""
+    w = make(B, T)
+    tr = RefTrainer(B, n_frames=T)
+    tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
+    tr.model.train()
+    x1, x2 = synthetic_pair(B, T, 31)
+    eps = synthetic_eps(B, seed=32)
+    with torch.no_grad():
+        l_ref = loss_gvae2(x1, x2, tr.model(x1, x2, eps), B)
+    w.model.eps_override = eps
+    got = w.step(x1.cuda(), x2.cuda(), None, train=True)
+    for i in range(8):
+        assert rel(got[i], float(l_ref[i])) <= LOSS_RTOL, (i, got[i], float(l_ref[i]))
