@@ -603,9 +603,9 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int st
 // Eight waves = 4 gates (fwd) / k-quarters (bwd) x 2 k-halves give both: two waves per SIMD AND the
 // small traffic; the k-halves meet in the LDS reduction that the epilogue needs anyway.
 // =====================================================================================================
-template <int KR>
+template <int MT, int KR>
 __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int step, int n_j, int n_m) {
-  constexpr int MT = 2, NW = 8;
+  constexpr int NW = 8;
   constexpr int NS = KR / 16, LDA = KR + 4;
   constexpr int NST = MT * KR / 64;     // float4 per thread per round (activation stage, both k-halves together)
   const StepDir& d = a.d[blockIdx.z];
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
   // epilogue operands: one (segment, unit) element per thread
   float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
   const int en = m0 + (tid >> 4), ej = j0 + (tid & 15);
-  const bool eok = en < N;
+  const bool eok = (tid < MT * 256) && (en < N);
   float pre[4], cp;
 #pragma unroll
   for (int g = 0; g < 4; ++g) pre[g] = eok ? G[(int64_t)en * 4 * H + g * H + ej] : 0.f;
@@ -725,9 +725,9 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
   }
 }
 
-template <int KR>
+template <int MT, int KR>
 __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int step, int n_j, int n_m) {
-  constexpr int MT = 2, NW = 8;
+  constexpr int NW = 8;
   constexpr int NS = KR / 16, LDA = KR + 4;
   const StepDir& d = a.d[blockIdx.z];
   const int H = a.H, N = a.N;
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
 
   const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
   const int en = m0 + (tid >> 4), ej = j0 + (tid & 15);
-  const bool eok = en < N;
+  const bool eok = (tid < MT * 256) && (en < N);
   float gt[4], cc, cp, dho, dcar;
 #pragma unroll
   for (int g = 0; g < 4; ++g) gt[g] = eok ? G[(int64_t)en * 4 * H + g * H + ej] : 0.f;
@@ -1139,12 +1139,16 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     return dvae_check_launch();
   }
   const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
-  const bool v5 = v4 && (ver == 5) && H >= 1024 && (H % 512) == 0;   // eight-wave kernels (win at H = 1024, lose at 512: too few workgroups)
+  const bool v5 = v4 && (ver == 5) && (H % 512) == 0;   // eight-wave kernels
   if (v5) {
-    const int n_m5 = (N + 31) / 32;
+    // 32-row tiles when that still gives every CU a workgroup, else 16-row tiles: either way two waves per SIMD
+    const int mt5 = (n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1;
+    const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
-    for (int step = 0; step < T; ++step)
-      hipLaunchKernelGGL((lstm_step_fwd_v5<128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+    for (int step = 0; step < T; ++step) {
+      if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+    }
     return dvae_check_launch();
   }
   for (int step = 0; step < T; ++step) {
@@ -1179,12 +1183,15 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     return dvae_check_launch();
   }
   const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
-  const bool v5 = v4 && (ver == 5) && H >= 1024 && (H % 256) == 0;
+  const bool v5 = v4 && (ver == 5) && (H % 256) == 0;
   if (v5) {
-    const int n_m5 = (N + 31) / 32;
+    const int mt5 = (n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1;
+    const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
-    for (int step = 0; step < T; ++step)
-      hipLaunchKernelGGL((lstm_step_bwd_v5<64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+    for (int step = 0; step < T; ++step) {
+      if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+    }
     return dvae_check_launch();
   }
   for (int step = 0; step < T; ++step) {
