@@ -337,6 +337,55 @@ __global__ __launch_bounds__(256) void conv_unpack_add_kernel(const float* __res
   }
 }
 
+// ---- inference-side layout helpers (mel -> mel conversion, variational_base_vae.py:269-298, 335-348)
+__global__ __launch_bounds__(256) void mel_to_chunks_kernel(const float* __restrict__ mel, float* __restrict__ out,
+                                                            int C, int L, int T, int n) {
+  const int64_t total = (int64_t)n * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    const int c = (int)((i / T) % C);
+    const int k = (int)(i / ((int64_t)T * C));
+    const int64_t src = (int64_t)k * T + t;
+    out[i] = src < L ? mel[(int64_t)c * L + src] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void chunks_to_mel_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int n, int C, int T, float lo, float hi, int clamp) {
+  const int64_t W = (int64_t)n * T, total = (int64_t)C * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i / W);
+    const int64_t col = i % W;
+    float v = in[((col / T) * C + c) * T + col % T];
+    if (clamp) v = fminf(fmaxf(v, lo), hi);
+    out[i] = v;
+  }
+}
+// z_src[k] = [mean_rows(src_style_mu) | src_content_mu[k]] ; z_conv[k] = [mean_rows(trg_style_mu) | src_content_mu[k]]
+__global__ void conversion_latents_kernel(const float* __restrict__ ss, const float* __restrict__ sc,
+                                          const float* __restrict__ ts, float* __restrict__ zs, float* __restrict__ zc,
+                                          int n, int m, int S, int Cn) {
+  const int D = S + Cn;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * D) return;
+  const int k = idx / D, d = idx % D;
+  if (d < S) {
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < n; ++r) a += ss[r * 2 * S + d];
+    for (int r = 0; r < m; ++r) b += ts[r * 2 * S + d];
+    zs[idx] = a / (float)n;
+    zc[idx] = b / (float)m;
+  } else {
+    const float v = sc[k * 2 * Cn + (d - S)];
+    zs[idx] = v;
+    zc[idx] = v;
+  }
+}
+__global__ __launch_bounds__(256) void mul_div_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ c, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = a[i] * (b[i] / c[i]);
+}
+
 inline int nblk(int64_t n, int per = 256, int cap = 2048) {
   int64_t b = (n + per - 1) / per;
   if (b < 1) b = 1;
@@ -423,6 +472,34 @@ DVAE_API int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, in
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(nblk(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
                      eps, grad_scale, state);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_mel_to_chunks(const float* mel, float* out, int C, int L, int T, int n, void* stream) {
+  if (!mel || !out || C < 1 || L < 0 || T < 1 || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(mel_to_chunks_kernel, dim3(nblk((int64_t)n * C * T)), dim3(256), 0, (hipStream_t)stream, mel, out,
+                     C, L, T, n);
+  return dvae_check_launch();
+}
+DVAE_API int dvae_chunks_to_mel(const float* in, float* out, int n, int C, int T, float lo, float hi, int clamp,
+                                void* stream) {
+  if (!in || !out || n < 1 || C < 1 || T < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(chunks_to_mel_kernel, dim3(nblk((int64_t)n * C * T)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     n, C, T, lo, hi, clamp);
+  return dvae_check_launch();
+}
+DVAE_API int dvae_conversion_latents(const float* src_style, const float* src_content, const float* trg_style,
+                                     float* z_src, float* z_conv, int n, int m, int S, int Cn, void* stream) {
+  if (!src_style || !src_content || !trg_style || !z_src || !z_conv || n < 1 || m < 1 || S < 1 || Cn < 1)
+    return DVAE_EINVAL;
+  const int total = n * (S + Cn);
+  hipLaunchKernelGGL(conversion_latents_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src_style,
+                     src_content, trg_style, z_src, z_conv, n, m, S, Cn);
+  return dvae_check_launch();
+}
+DVAE_API int dvae_mul_div(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
+  if (!a || !b || !c || !out || n < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(mul_div_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n);
   return dvae_check_launch();
 }
 

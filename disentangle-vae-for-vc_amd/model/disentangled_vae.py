@@ -146,6 +146,12 @@ class Postnet(nn.Module):
         y = self.forward_frames(mel_to_frames(x.contiguous()), B, 1)
         return FramesToMelFn.apply(y, B, C, T)
 
+    def forward_plus_input(self, x):
+        """x + postnet(x) with the residual fused into the last BatchNorm apply (variational_base_vae.py:292-293)."""
+        B, C, T = x.shape
+        xf = mel_to_frames(x.contiguous())
+        return FramesToMelFn.apply(self.forward_frames(xf, B, 1, residual=xf), B, C, T)
+
 
 class DisentangledVAE(nn.Module):
     """reference: disentangled_vae.py:124-286."""
@@ -256,6 +262,12 @@ class DisentangledVAE(nn.Module):
         style, content = self._encode_frames(mel_to_frames(x.contiguous()), T, B, 1)
         s, c = self.speaker_size, self.latent_dim - self.speaker_size
         return style[:, :s], style[:, s:], content[:, :c], content[:, c:]
+
+    def encode_heads(self, x):
+        """x [B,80,T] -> (style [B, 2S] = mu|logvar, content [B, 2Cn] = mu|logvar): encode() without the column split."""
+        self._check(x)
+        B, _, T = x.shape
+        return self._encode_frames(mel_to_frames(x.contiguous()), T, B, 1)
 
     def _reparameterize(self, mu, logvar, train=True):
         """API-compatible standalone form (disentangled_vae.py:222-228).  The training path does not call it:

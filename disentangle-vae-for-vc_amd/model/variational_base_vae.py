@@ -21,6 +21,18 @@ from pathlib import Path
 import torch
 
 
+def chunking_mel(melspectrogram, n_frames: int = 64, device="cuda"):
+    """[80, L] (numpy or tensor) -> device tensor [L//T + 1, 80, T], tail zero-padded — the reference's chunking_mel
+    (variational_base_vae.py:335-348), done by a HIP kernel."""
+    from .._lib import check, lib, ptr, stream
+    mel = torch.as_tensor(melspectrogram).to(device=device, dtype=torch.float32).contiguous()
+    C, L = mel.shape
+    n = L // n_frames + 1
+    out = torch.empty((n, C, n_frames), device=mel.device, dtype=torch.float32)
+    check(lib().dvae_mel_to_chunks(ptr(mel), ptr(out), C, L, n_frames, n, stream()), "dvae_mel_to_chunks")
+    return out
+
+
 class VariationalBaseModelVAE:
     def __init__(self, dataset, width, height, channels, latent_sz, learning_rate, device, log_interval, batch_size,
                  normalize=False, flatten=True):
@@ -156,6 +168,44 @@ class VariationalBaseModelVAE:
 
     def update_(self):
         pass
+
+    # ---- tensor part of voice_conversion_mel (variational_base_vae.py:269-301); file I/O, plots and the WaveNet
+    # vocoder of the reference stay outside
+    @torch.no_grad()
+    def convert_mel(self, source_mel, target_mel):
+        """source_mel, target_mel: [80, L] -> dict(source, recons, converted, spectral_detail), each [80, n*T].
+        Content of the source, style (mean style_mu over chunks) of the target; eval-mode BatchNorm."""
+        from .._lib import check, lib, ptr, stream
+        m = self.model
+        was_training = m.training
+        m.eval()
+        try:
+            T, S, Cn = m.n_frames, m.speaker_size, m.latent_dim - m.speaker_size
+            src = chunking_mel(source_mel, T, self.device)
+            trg = chunking_mel(target_mel, T, self.device)
+            n, k = src.shape[0], trg.shape[0]
+            src_style, src_content = m.encode_heads(src)      # [n, 2S], [n, 2Cn] (mu | logvar)
+            trg_style, _ = m.encode_heads(trg)
+            z_src = torch.empty((n, S + Cn), device=src.device, dtype=torch.float32)
+            z_conv = torch.empty_like(z_src)
+            L = lib()
+            check(L.dvae_conversion_latents(ptr(src_style), ptr(src_content), ptr(trg_style), ptr(z_src), ptr(z_conv),
+                                            n, k, S, Cn, stream()), "dvae_conversion_latents")
+            recons = m.decode(z_src)
+            conv = m.postnet.forward_plus_input(m.decode(z_conv))
+
+            def cat(x, clamp):
+                out = torch.empty((x.shape[1], n * T), device=x.device, dtype=torch.float32)
+                check(L.dvae_chunks_to_mel(ptr(x.contiguous()), ptr(out), n, x.shape[1], T, 0.0, 1.0, int(clamp),
+                                           stream()), "dvae_chunks_to_mel")
+                return out
+            source, recons_v, conv_v = cat(src, False), cat(recons, False), cat(conv, True)
+            detail = torch.empty_like(source)
+            check(L.dvae_mul_div(ptr(source), ptr(recons_v), ptr(conv_v), ptr(detail), source.numel(), stream()),
+                  "dvae_mul_div")
+            return {"source": source, "recons": recons_v, "converted": conv_v, "spectral_detail": detail}
+        finally:
+            m.train(was_training)
 
     def _is_rank0(self):
         return self.reducer is None or self.reducer.rank == 0

@@ -175,6 +175,17 @@ int dvae_transpose(const float* in, float* out, int R, int C, void* stream);
 int dvae_act_fwd(float* Y, int64_t n, int act, void* stream);
 int dvae_act_bwd(const float* dZ, const float* Z, float* dU, int64_t n, int act, void* stream);
 
+/* ---- inference: mel -> mel conversion plumbing (voice_conversion_mel, variational_base_vae.py:269-298; chunking_mel :335-348)
+ * dvae_mel_to_chunks: mel[C,L] -> out[n,C,T], n = L/T + 1, tail zero-padded (an all-zero chunk when L % T == 0).
+ * dvae_chunks_to_mel: in[n,C,T] -> out[C, n*T] (torch.cat of the chunks along time), optional clamp to [lo,hi] (:296).
+ * dvae_conversion_latents: z_src[k] = [mean_k style_mu(src) | content_mu(src)[k]], z_conv[k] = [mean style_mu(trg) | same] (:281-285).
+ * dvae_mul_div: out = a * (b / c)  (spectral detail, :301). */
+int dvae_mel_to_chunks(const float* mel, float* out, int C, int L, int T, int n, void* stream);
+int dvae_chunks_to_mel(const float* in, float* out, int n, int C, int T, float lo, float hi, int clamp, void* stream);
+int dvae_conversion_latents(const float* src_style, const float* src_content, const float* trg_style,
+                            float* z_src, float* z_conv, int n, int m, int S, int Cn, void* stream);
+int dvae_mul_div(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
+
 /* ---- opt-in per-family kernel timing with HIP events on the launch stream (bench.py roofline) ----
  * family: 0 = off, 1 = GEMM/conv contraction kernel, 2 = LSTM step kernels.
  * dvae_prof_collect: synchronises the recorded events, returns total ms, launch count and algorithmic FLOPs. */

@@ -231,3 +231,37 @@ def chunked_step_grads(tr: RefTrainer, x1, x2, eps, n_chunks: int):
             g = p.grad.detach().clone() / n_chunks
             acc[n] = g if n not in acc else acc[n] + g
     return acc
+
+
+# ------------------------------------------------------------------------------------------------
+# Mel -> mel conversion (inference), tensor part of voice_conversion_mel
+# (/root/reference/model/variational_base_vae.py:269-298) and chunking_mel (:335-348).
+def chunk_mel(mel: torch.Tensor, n_frames: int = 64) -> torch.Tensor:
+    """[80, L] -> [L//T + 1, 80, T]; the last chunk is right-padded with zeros (when L % T == 0 that is one
+    extra all-zero chunk, as in the reference)."""
+    n = mel.shape[1] // n_frames + 1
+    out = torch.zeros((n, mel.shape[0], n_frames), dtype=mel.dtype)
+    for i in range(n):
+        part = mel[:, i * n_frames:(i + 1) * n_frames]
+        out[i, :, :part.shape[1]] = part
+    return out
+
+
+@torch.no_grad()
+def convert_mel_ref(model: "RefDVAE", source_mel: torch.Tensor, target_mel: torch.Tensor):
+    """Eval-mode conversion of one utterance: content of the source, style (mean style_mu over chunks) of the target.
+    Returns dict(source, recons, converted, spectral_detail), each [80, n_chunks*T] (converted clamped to [0,1])."""
+    model.eval()
+    T = model.n_frames
+    src, trg = chunk_mel(source_mel.float(), T), chunk_mel(target_mel.float(), T)
+    s_mu, _, c_mu, _ = model.encode(src)
+    t_mu, _, _, _ = model.encode(trg)
+    n = src.shape[0]
+    src_style = s_mu.mean(0, keepdim=True).repeat(n, 1)
+    trg_style = t_mu.mean(0, keepdim=True).repeat(n, 1)
+    recons = model.decode(torch.cat((src_style, c_mu), -1))
+    conv = model.decode(torch.cat((trg_style, c_mu), -1))
+    conv = conv + model.postnet(conv)
+    cat = lambda x: torch.cat([x[i] for i in range(x.shape[0])], 1)
+    recons, conv, source = cat(recons), torch.clamp(cat(conv), 0.0, 1.0), cat(src)
+    return {"source": source, "recons": recons, "converted": conv, "spectral_detail": source * (recons / conv)}

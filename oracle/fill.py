@@ -27,8 +27,9 @@ def _uniform(key, salt, shape, lo, hi) -> torch.Tensor:
     return torch.from_numpy(a)
 
 
-def fill_state_dict(sd: Dict[str, torch.Tensor], salt: int = 0) -> Dict[str, torch.Tensor]:
-    """Return a new state dict with the same keys/shapes/dtypes and deterministic values."""
+def fill_state_dict(sd: Dict[str, torch.Tensor], salt: int = 0, random_running_stats: bool = False) -> Dict[str, torch.Tensor]:
+    """Return a new state dict with the same keys/shapes/dtypes and deterministic values.
+    `random_running_stats` gives BatchNorm non-trivial running statistics (for eval-mode tests)."""
     out = {}
     for k, v in sd.items():
         shape = tuple(v.shape)
@@ -36,9 +37,9 @@ def fill_state_dict(sd: Dict[str, torch.Tensor], salt: int = 0) -> Dict[str, tor
         if leaf == "num_batches_tracked":
             out[k] = torch.zeros((), dtype=torch.long)
         elif leaf == "running_mean":
-            out[k] = torch.zeros(shape)
+            out[k] = _uniform(k, salt, shape, -0.3, 0.3) if random_running_stats else torch.zeros(shape)
         elif leaf == "running_var":
-            out[k] = torch.ones(shape)
+            out[k] = _uniform(k, salt, shape, 0.5, 2.0) if random_running_stats else torch.ones(shape)
         elif "lstm" in k:
             hidden = shape[0] // 4
             b = 1.0 / math.sqrt(hidden)

@@ -129,6 +129,40 @@ def run_case(name, batch, n_frames, seed, eps_seed):
     print(name, "losses", out["step1"], "step2", out["step2"][0])
 
 
+def run_conversion_case():
+    """Tensor part of voice_conversion_mel (variational_base_vae.py:269-298) on the real reference model + its own
+    chunking_mel (:335-348), eval mode, non-trivial BatchNorm running statistics."""
+    import model.variational_base_vae as vb
+    w = build(4, 64)
+    w.model.load_state_dict(fill_state_dict(w.model.state_dict(), salt=3, random_running_stats=True))
+    w.model.eval()
+    rs = np.random.RandomState(5)
+    source = rs.uniform(0, 1, size=(80, 150))     # float64, as the .npy files of the reference
+    target = rs.uniform(0, 1, size=(80, 128))     # multiple of 64: chunking appends an all-zero chunk
+    with torch.no_grad():
+        src = vb.chunking_mel(source).float()
+        trg = vb.chunking_mel(target).float()
+        s_mu, _, c_mu, _ = w.model.encode(src)
+        t_mu, _, _, _ = w.model.encode(trg)
+        src_style = torch.mean(s_mu, axis=0, keepdim=True).repeat(src.shape[0], 1)
+        trg_style = torch.mean(t_mu, axis=0, keepdim=True).repeat(src.shape[0], 1)
+        recons = w.model.decode(torch.cat([src_style, c_mu], dim=-1))
+        conv = w.model.decode(torch.cat([trg_style, c_mu], dim=-1))
+        conv = conv + w.model.postnet(conv)
+        recons_voice = torch.cat([recons[i] for i in range(recons.shape[0])], 1).numpy()
+        conv_voice = torch.clamp(torch.cat([conv[i] for i in range(conv.shape[0])], 1), min=0, max=1.0).numpy()
+        src_cat = torch.cat([src[i] for i in range(src.shape[0])], 1).numpy()
+    np.savez_compressed(os.path.join(HERE, "conversion_t64.npz"), source=source, target=target,
+                        src_chunks_shape=np.array(src.shape), trg_chunks_shape=np.array(trg.shape),
+                        recons=recons_voice, converted=conv_voice, source_cat=src_cat,
+                        src_style=src_style[0].numpy(), trg_style=trg_style[0].numpy())
+    print("conversion", src.shape, trg.shape, float(conv_voice.mean()), float(recons_voice.mean()))
+
+
 if __name__ == "__main__":
-    for c in CASES:
-        run_case(*c)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "steps"):
+        for c in CASES:
+            run_case(*c)
+    if only in ("", "conversion"):
+        run_conversion_case()

@@ -264,3 +264,27 @@ def test_long_segments_against_oracle(B, T):
     got = w.step(x1.cuda(), x2.cuda(), None, train=True)
     for i in range(8):
         assert rel(got[i], float(l_ref[i])) <= LOSS_RTOL, (i, got[i], float(l_ref[i]))
+
+
+def test_conversion_path(golden_dir):
+    """Inference row: chunking, eval-mode encode/decode/postnet, style swap, clamp — HIP path vs the
+    vectors recorded from the real reference and vs the oracle."""
+    from oracle.dvae_ref import RefDVAE, convert_mel_ref
+    from dvae_amd.model.variational_base_vae import chunking_mel
+    g = np.load(os.path.join(golden_dir, "conversion_t64.npz"))
+    w = make(4, 64)
+    w.model.load_state_dict(fill_state_dict(w.model.state_dict(), salt=3, random_running_stats=True))
+    ch = chunking_mel(g["target"], 64)
+    assert tuple(ch.shape) == tuple(g["trg_chunks_shape"]) and float(ch[-1].abs().sum()) == 0.0
+    out = w.convert_mel(g["source"], g["target"])
+    np.testing.assert_allclose(out["source"].cpu().numpy(), g["source_cat"], rtol=0, atol=1e-7)
+    for k in ("recons", "converted"):
+        err = float(np.abs(out[k].cpu().numpy() - g[k]).max())
+        assert err <= 2e-3 * max(1.0, float(np.abs(g[k]).max())), (k, err)
+    m = RefDVAE(4, 32, 64)
+    m.load_state_dict(fill_state_dict(m.state_dict(), salt=3, random_running_stats=True))
+    ref = convert_mel_ref(m, torch.from_numpy(g["source"]), torch.from_numpy(g["target"]))
+    d_hip, d_ref = out["spectral_detail"].cpu(), ref["spectral_detail"]
+    ok = ref["converted"] > 1e-3                       # the ratio is ill-conditioned where the clamp hits 0
+    assert float((d_hip[ok] - d_ref[ok]).abs().max()) <= 5e-2 * float(d_ref[ok].abs().max())
+    assert w.model.training                             # convert_mel restores the mode

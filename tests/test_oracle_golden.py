@@ -84,3 +84,18 @@ def test_two_train_steps(golden_dir, name):
     np.testing.assert_allclose(np.array(s2), g["step2"], rtol=2e-4)
     pn = np.array([float(p.detach().double().norm()) for _, p in tr.model.named_parameters()])
     np.testing.assert_allclose(pn, g["param_norm_after2"], rtol=1e-3, atol=2e-3)
+
+
+def test_conversion_path_against_reference(golden_dir):
+    """Oracle restatement of the tensor part of voice_conversion_mel / chunking_mel vs the real reference."""
+    from oracle.dvae_ref import RefDVAE, chunk_mel, convert_mel_ref
+    g = _load(golden_dir, "conversion_t64")
+    src, trg = torch.from_numpy(g["source"]), torch.from_numpy(g["target"])
+    assert tuple(chunk_mel(src.float()).shape) == tuple(g["src_chunks_shape"])
+    assert tuple(chunk_mel(trg.float()).shape) == tuple(g["trg_chunks_shape"])     # L % 64 == 0 -> extra zero chunk
+    m = RefDVAE(4, 32, 64)
+    m.load_state_dict(fill_state_dict(m.state_dict(), salt=3, random_running_stats=True))
+    out = convert_mel_ref(m, src, trg)
+    np.testing.assert_allclose(out["source"].numpy(), g["source_cat"], rtol=0, atol=0)
+    np.testing.assert_allclose(out["recons"].numpy(), g["recons"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["converted"].numpy(), g["converted"], rtol=1e-4, atol=1e-5)
