@@ -57,6 +57,7 @@ SIGNATURES = {
     "dvae_transpose": (i32, [vp, vp, i32, i32, vp]),
     "dvae_act_fwd": (i32, [vp, i64, i32, vp]),
     "dvae_act_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "dvae_gather_crop": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_mel_to_chunks": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "dvae_chunks_to_mel": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, vp]),
     "dvae_conversion_latents": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),

@@ -386,6 +386,22 @@ __global__ __launch_bounds__(256) void mul_div_kernel(const float* __restrict__ 
     out[i] = a[i] * (b[i] / c[i]);
 }
 
+// out[i][c][t] = mels[utt[i]][c][off[i] + t] if off[i] + t < len[utt[i]] else 0   (random crop / right zero pad of
+// preprocessing/dataset.py:100-109 for a whole batch, from a device-resident padded store [n_utt, C, Lmax])
+__global__ __launch_bounds__(256) void gather_crop_kernel(const float* __restrict__ mels, const int* __restrict__ lens,
+                                                          const int* __restrict__ utt, const int* __restrict__ off,
+                                                          float* __restrict__ out, int n, int C, int T, int Lmax) {
+  const int64_t total = (int64_t)n * C * T;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int t = (int)(i % T);
+    const int c = (int)((i / T) % C);
+    const int k = (int)(i / ((int64_t)T * C));
+    const int u = utt[k];
+    const int src = off[k] + t;
+    out[i] = (src < lens[u]) ? mels[((int64_t)u * C + c) * Lmax + src] : 0.f;
+  }
+}
+
 inline int nblk(int64_t n, int per = 256, int cap = 2048) {
   int64_t b = (n + per - 1) / per;
   if (b < 1) b = 1;
@@ -472,6 +488,14 @@ DVAE_API int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, in
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(nblk(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
                      eps, grad_scale, state);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_gather_crop(const float* mels, const int* lens, const int* utt, const int* off, float* out, int n,
+                              int C, int T, int Lmax, void* stream) {
+  if (!mels || !lens || !utt || !off || !out || n < 1 || C < 1 || T < 1 || Lmax < 1) return DVAE_EINVAL;
+  hipLaunchKernelGGL(gather_crop_kernel, dim3(nblk((int64_t)n * C * T)), dim3(256), 0, (hipStream_t)stream, mels, lens,
+                     utt, off, out, n, C, T, Lmax);
   return dvae_check_launch();
 }
 

@@ -86,3 +86,67 @@ class SyntheticPairs:
 
     def batch(self):
         return self.x1, self.x2, self.spk
+
+
+class GpuPairLoader:
+    """Device-resident replacement for `DataLoader(SpeechDatasetGVAE, shuffle=True)` (train.py:55-56).
+
+    With a ~36 ms step the reference's loader (num_workers=0, two np.load + a host->device copy per item) would
+    dominate, so the whole corpus is uploaded ONCE as a padded [n_utt, 80, Lmax] fp32 tensor (VCTK mels are a few
+    GB: trivial against 288 GB of HBM) and a batch is produced by one HIP gather kernel.  Pairing, per-epoch
+    re-pairing (`dataset.shuffle_data()`), random crop / right zero-pad and the speaker label are those of
+    SpeechDatasetGVAE — the pair list IS the dataset's; only where the bytes live and who crops changes.
+    Yields (x1 [B,80,T], x2 [B,80,T], speaker_ids [B]) on the device."""
+
+    def __init__(self, dataset: SpeechDatasetGVAE, batch_size: int, device="cuda", seed: Optional[int] = None,
+                 drop_last: bool = True, shuffle: bool = True):
+        self.dataset = dataset
+        self.batch_size, self.drop_last, self.shuffle = batch_size, drop_last, shuffle
+        self.rng = np.random.RandomState(seed) if seed is not None else np.random
+        self.T = dataset.samples_length
+        files = sorted({f for utts in dataset.spk_utt for f in utts})
+        self.index = {f: i for i, f in enumerate(files)}
+        arrs = [np.load(f) for f in files]
+        self.C = arrs[0].shape[0]
+        self.lengths = np.array([a.shape[1] for a in arrs], dtype=np.int32)
+        self.Lmax = int(self.lengths.max())
+        host = np.zeros((len(arrs), self.C, self.Lmax), dtype=np.float32)
+        for i, a in enumerate(arrs):
+            host[i, :, :a.shape[1]] = a
+        self.device = torch.device(device)
+        self.mels = torch.from_numpy(host).to(self.device)
+        self.lens_dev = torch.from_numpy(self.lengths).to(self.device)
+        self.last_meta = None       # (utt1, utt2, off1, off2) of the last batch, for tests
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def _offset(self, L):
+        # same rule as SpeechDatasetGVAE._crop: random start if longer, 0 (and zero padding) otherwise
+        return int(self.rng.randint(0, L - self.T)) if L > self.T else 0
+
+    def gather(self, utt, off):
+        """Crop batch on the device: utt, off int arrays [n] -> [n, 80, T]."""
+        from ._lib import check, lib, ptr, stream
+        n = len(utt)
+        u = torch.as_tensor(np.asarray(utt, dtype=np.int32)).to(self.device)
+        o = torch.as_tensor(np.asarray(off, dtype=np.int32)).to(self.device)
+        out = torch.empty((n, self.C, self.T), device=self.device, dtype=torch.float32)
+        check(lib().dvae_gather_crop(ptr(self.mels), ptr(self.lens_dev), ptr(u), ptr(o), ptr(out), n, self.C, self.T,
+                                     self.Lmax, stream()), "dvae_gather_crop")
+        return out
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = self.rng.permutation(n) if self.shuffle else np.arange(n)
+        for b in range(len(self)):
+            sel = order[b * self.batch_size:(b + 1) * self.batch_size]
+            pairs = self.dataset.utterance_fp[sel]
+            u1 = np.array([self.index[p[0]] for p in pairs], dtype=np.int32)
+            u2 = np.array([self.index[p[1]] for p in pairs], dtype=np.int32)
+            o1 = np.array([self._offset(int(self.lengths[u])) for u in u1], dtype=np.int32)
+            o2 = np.array([self._offset(int(self.lengths[u])) for u in u2], dtype=np.int32)
+            spk = np.array([self.dataset.speaker_ids.index(os.path.basename(os.path.dirname(p[0]))) for p in pairs])
+            self.last_meta = (u1, u2, o1, o2)
+            yield self.gather(u1, o1), self.gather(u2, o2), torch.from_numpy(spk).to(self.device)

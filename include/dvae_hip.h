@@ -175,6 +175,12 @@ int dvae_transpose(const float* in, float* out, int R, int C, void* stream);
 int dvae_act_fwd(float* Y, int64_t n, int act, void* stream);
 int dvae_act_bwd(const float* dZ, const float* Z, float* dU, int64_t n, int act, void* stream);
 
+/* ---- input pipeline on the device (SpeechDatasetGVAE.__getitem__, preprocessing/dataset.py:93-114, for a whole batch)
+ * mels[n_utt, C, Lmax] padded store, lens[n_utt]; out[i] = crop of utterance utt[i] at frame off[i], T frames,
+ * right-zero-padded when the utterance is shorter (:100-101). */
+int dvae_gather_crop(const float* mels, const int* lens, const int* utt, const int* off, float* out, int n,
+                     int C, int T, int Lmax, void* stream);
+
 /* ---- inference: mel -> mel conversion plumbing (voice_conversion_mel, variational_base_vae.py:269-298; chunking_mel :335-348)
  * dvae_mel_to_chunks: mel[C,L] -> out[n,C,T], n = L/T + 1, tail zero-padded (an all-zero chunk when L % T == 0).
  * dvae_chunks_to_mel: in[n,C,T] -> out[C, n*T] (torch.cat of the chunks along time), optional clamp to [lo,hi] (:296).

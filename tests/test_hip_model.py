@@ -288,3 +288,35 @@ def test_conversion_path(golden_dir):
     ok = ref["converted"] > 1e-3                       # the ratio is ill-conditioned where the clamp hits 0
     assert float((d_hip[ok] - d_ref[ok]).abs().max()) <= 5e-2 * float(d_ref[ok].abs().max())
     assert w.model.training                             # convert_mel restores the mode
+
+
+def test_gpu_pair_loader_matches_dataset_semantics(tmp_path):
+    """Input-pipeline row: device-resident corpus + HIP gather/crop vs the CPU dataset rules."""
+    from dvae_amd.data import GpuPairLoader, SpeechDatasetGVAE, write_synthetic_corpus
+    root = write_synthetic_corpus(str(tmp_path / "corpus"), n_speakers=3, n_utt=6, length=96, seed=1)
+    short = np.random.RandomState(2).uniform(0, 1, size=(80, 40))          # shorter than the crop: zero padding
+    np.save(os.path.join(root, "spk000", "utt000_mel.npy"), short)
+    ds = SpeechDatasetGVAE(root, samples_length=64, seed=4)
+    loader = GpuPairLoader(ds, batch_size=3, seed=5)
+    assert len(loader) == len(ds) // 3
+    files = sorted(loader.index, key=loader.index.get)
+    seen = 0
+    for x1, x2, spk in loader:
+        u1, u2, o1, o2 = loader.last_meta
+        assert x1.shape == (3, 80, 64) and x1.is_cuda and spk.shape == (3,)
+        for x, us, os_ in ((x1, u1, o1), (x2, u2, o2)):
+            for i, (u, o) in enumerate(zip(us, os_)):
+                mel = np.load(files[u]).astype(np.float32)
+                ref = np.zeros((80, 64), dtype=np.float32)
+                part = mel[:, o:o + 64]
+                ref[:, :part.shape[1]] = part
+                np.testing.assert_array_equal(x[i].cpu().numpy(), ref)
+                assert 0 <= o <= max(0, mel.shape[1] - 64)
+        for i in range(3):   # same-speaker pairs, label = speaker directory index
+            d1, d2 = os.path.dirname(files[u1[i]]), os.path.dirname(files[u2[i]])
+            assert d1 == d2 and int(spk[i]) == ds.speaker_ids.index(os.path.basename(d1))
+        seen += 1
+    assert seen == len(loader)
+    w = make(3, 64)
+    vals = w.train(loader, 1, logging_func=lambda *a: None)     # the trainer consumes it like a DataLoader
+    assert all(np.isfinite(v) for v in vals)
