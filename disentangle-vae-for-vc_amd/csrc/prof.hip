@@ -55,3 +55,18 @@ DVAE_API int dvae_prof_collect(double* total_ms, int64_t* launches, double* flop
   g_flops = 0.0;
   return DVAE_OK;
 }
+
+
+// ---- launch-floor probe (experiments only): n back-to-back launches of a kernel that does nothing / touches LDS
+namespace {
+__global__ void probe_kernel(float* sink, int lds_words) {
+  extern __shared__ float dyn[];
+  if (lds_words > 0 && threadIdx.x == 0) dyn[0] = 1.f;
+  if (sink && blockIdx.x == 0 && threadIdx.x == 0 && lds_words < 0) sink[0] = 1.f;
+}
+}  // namespace
+DVAE_API int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream) {
+  for (int i = 0; i < n; ++i)
+    hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, sink, lds_bytes / 4);
+  return dvae_check_launch();
+}

@@ -197,6 +197,8 @@ int dvae_mul_div(const float* a, const float* b, const float* c, float* out, int
  * dvae_prof_collect: synchronises the recorded events, returns total ms, launch count and algorithmic FLOPs. */
 int dvae_prof_enable(int family);
 int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
+/* experiments: n back-to-back launches of an empty kernel (launch-floor probe, scripts/launch_floor.py) */
+int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
 
 #ifdef __cplusplus
 }
