@@ -382,6 +382,7 @@ class LstmLayerFn(torch.autograd.Function):
             for d, (wi, wh, bi, bh) in enumerate(params):
                 dg = dgs[d]
                 linear_wgrad_acc(dg, x, _grad_buf(wi))
+                gw = _grad_buf(wh)      # exists (zero) even when T == 1 leaves W_hh without a gradient
                 if T > 1:
                     rows = R - N
                     # h_prev of frame t is h[t-1] (forward) / h[t+1] (reverse)
@@ -389,7 +390,6 @@ class LstmLayerFn(torch.autograd.Function):
                         a_ptr, b_ptr = dg.data_ptr() + 4 * N * 4 * H, h_out.data_ptr()
                     else:
                         a_ptr, b_ptr = dg.data_ptr(), h_out.data_ptr() + 4 * (N * ldh + H)
-                    gw = _grad_buf(wh)
                     sk = _split_k(_tiles(4 * H, H), rows)
                     check(L.dvae_gemm_f32(a_ptr, b_ptr, ptr(gw), None, 4 * H, H, rows, 4 * H, ldh, H, 0, 0, ACT_NONE,
                                           EPI_ATOMIC, sk, st2), "dvae_gemm_f32(dW_hh)")

@@ -328,3 +328,67 @@ def test_prof_hooks(ops):
     ms, n, fl = ops.prof_collect()
     ops.prof_enable(0)
     assert n == 3 and ms > 0 and fl == 3 * 2.0 * 256 * 128 * 64
+
+
+# ------------------------------------------------------------------ edge cases / error behaviour
+@pytest.mark.parametrize("N,T,In,H,bidir", [(1, 1, 128, 64, True), (17, 3, 128, 512, False), (33, 2, 512, 1024, False)])
+def test_lstm_ragged_sizes(ops, N, T, In, H, bidir):
+    """Segment counts that are not multiples of the 16-row MFMA tile, single frame, single segment."""
+    test_lstm_layer(ops, N, T, In, H, bidir)
+
+
+@pytest.mark.parametrize("N,T", [(1, 1), (1, 3), (2, 2), (5, 7)])
+def test_conv_block_tiny(ops, N, T):
+    """Fewer rows than one tile; every tap partly or wholly in the zero padding."""
+    test_conv5_fwd_dgrad_wgrad(ops, N, T, 80, 80)
+
+
+def test_gemm_degenerate_shapes(ops):
+    for M, N, K in [(1, 4, 4), (3, 8, 36), (128, 4, 16), (7, 132, 20)]:
+        x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+        y = torch.empty(M, N, device="cuda")
+        ops.gemm(dev(x), dev(w), y, None, M, N, K, K, K, N, True, True)
+        close(y, x.double() @ w.double().t(), name=f"gemm {M}x{N}x{K}")
+
+
+def test_abi_rejects_bad_arguments_without_crashing():
+    """Error behaviour of the C ABI: negative code, no exception across the boundary, no device fault."""
+    from dvae_amd._lib import lib, stream
+    L = lib()
+    a = torch.zeros(64, 64, device="cuda")
+    p, st = a.data_ptr(), stream()
+    assert L.dvae_gemm_f32(None, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, st) == -1          # null A
+    assert L.dvae_gemm_f32(p + 4, p, p, None, 64, 64, 60, 64, 64, 64, 1, 1, 0, 0, 1, st) == -1         # misaligned
+    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 62, 64, 64, 1, 1, 0, 0, 1, st) == -1             # lda % 4
+    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 1, 2, 4, st) == -1             # act + split-K
+    assert L.dvae_gemm_f32(p, p, p, None, 0, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, st) == -1              # empty
+    assert L.dvae_bn_stats_fwd(p, p, p, None, None, None, p, 64, 8, 63, 2, 1e-5, 0.1, st) == -1        # C % 4
+    assert L.dvae_bn_stats_fwd(p, p, p, None, None, None, p, 64, 7, 64, 2, 1e-5, 0.1, st) == -1        # R % N, N % G
+    assert L.dvae_lstm_seq_fwd(None, 1, 4, 8, 64, 64, st) == -1
+    assert L.dvae_adam_flat(p, p, p, p, 64, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0, st) == -1                  # step < 1
+    assert L.dvae_l1_sum_fwd(p, p + 4, p, p, 64, 1.0, st) == -1                                        # misaligned
+    assert L.dvae_mel_to_frames(None, None, p, 4, 80, 64, st) == -1
+    torch.cuda.synchronize()
+    assert float(a.abs().sum()) == 0.0
+
+
+def test_bn_one_group_equals_two_separate_calls(ops):
+    """G=2 over a concatenated batch == two G=1 calls on the halves (the reference's two encode() calls)."""
+    N, T, Cc = 8, 16, 512
+    x = rnd(N, 80, T, seed=1)
+    P = lambda t: torch.nn.Parameter(dev(t))
+    cw, cb = P(rnd(Cc, 80, 5, seed=2) * 0.2), P(rnd(Cc, seed=3))
+    bw, bb = P(rnd(Cc, seed=4, lo=0.5, hi=1.5)), P(rnd(Cc, seed=5) * 0.1)
+    def run(xs, G, rm, rv, nbt):
+        return ops.ConvBnActFn.apply(dev(to_frames(xs)), cw, cb, bw, bb, rm, rv, nbt, None, xs.shape[0], G, 2, True)
+    rm2, rv2 = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    nb2 = torch.zeros((), dtype=torch.long, device="cuda")
+    z2 = from_frames(run(x, 2, rm2, rv2, nb2).detach().cpu(), N, T)
+    rm1, rv1 = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    nb1 = torch.zeros((), dtype=torch.long, device="cuda")
+    za = from_frames(run(x[:4], 1, rm1, rv1, nb1).detach().cpu(), 4, T)
+    zb = from_frames(run(x[4:], 1, rm1, rv1, nb1).detach().cpu(), 4, T)
+    close(z2, torch.cat((za, zb), 0), rel=1e-5, name="groups")
+    close(rm2, rm1, rel=1e-5, name="running_mean order")
+    close(rv2, rv1, rel=1e-5, name="running_var order")
+    assert int(nb2) == int(nb1) == 2
