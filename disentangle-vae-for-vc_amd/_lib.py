@@ -63,6 +63,7 @@ SIGNATURES = {
     "dvae_conversion_latents": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_mul_div": (i32, [vp, vp, vp, vp, i64, vp]),
     "dvae_probe_launches": (i32, [i32, i32, i32, i32, vp, vp]),
+    "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
     "dvae_prof_enable": (i32, [i32]),
     "dvae_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
 }

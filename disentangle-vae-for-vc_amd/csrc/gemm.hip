@@ -47,7 +47,7 @@ struct GemmParams {
   int prio_mode;         // experiment knob DVAE_GEMM_PRIO
 };
 
-template <bool A_KC, bool B_KC, int NTW, int BK>
+template <bool A_KC, bool B_KC, int NTW, int BK, bool MF16>
 __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
   constexpr int BN = 64 * NTW;           // NTW = 32-wide n-tiles per wave
   constexpr int LD_KC = BK + 4;          // row stride of a k-contiguous image
@@ -198,13 +198,20 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
     }
   };
 
-  f32x16 acc[2][NTW];
+  // two MFMA shapes, same FLOP rate on paper: 32x32x2 (fewer, larger tiles) or 16x16x4 (MF16: finer issue
+  // granularity; the register-only probe scripts/mfma_peak.py reaches 155 TFLOP/s with it vs 143-152 with 32x32x2)
+  f32x16 acc[MF16 ? 1 : 2][MF16 ? 1 : NTW];
+  f32x4 acc16[MF16 ? 4 : 1][MF16 ? 2 * NTW : 1];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (MF16 ? 1 : 2); ++i)
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
+    for (int j = 0; j < (MF16 ? 1 : NTW); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MF16 ? 4 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (MF16 ? 2 * NTW : 1); ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int tap_n = 0, kit_n = 0;   // next tile to fetch
   auto advance = [&]() {
@@ -231,10 +238,55 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
   int cur = 0;
   for (int it = 0; it < n_iters; ++it) {
     const bool more = (it + 1 < n_iters);
-    if (more) {
+    if (more && !(p.prio_mode & 32)) {
       load_tiles(tap_n, kit_n);
       advance();
     }
+    if constexpr (MF16) {
+      // 16x16x4: lane (r = lane&15, q = lane>>4); 16-deep k groups, element e <-> k = 16g + 4q + e
+      constexpr int MI = 4, NJ = 2 * NTW, NG = BK / 16;
+      const int r16 = lane & 15, q16 = lane >> 4;
+      auto read16 = [&](int g, float (&av)[MI][4], float (&bv)[NJ][4]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (A_KC) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&As[cur][(wm * 64 + i * 16 + r16) * LDA + 16 * g + 4 * q16]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[i][e] = v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) av[i][e] = As[cur][(16 * g + 4 * q16 + e) * LDA + wm * 64 + i * 16 + r16];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (B_KC) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[cur][(wn * 32 * NTW + j * 16 + r16) * LDB + 16 * g + 4 * q16]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = Bs[cur][(16 * g + 4 * q16 + e) * LDB + wn * 32 * NTW + j * 16 + r16];
+          }
+        }
+      };
+      auto mfma16 = [&](float (&av)[MI][4], float (&bv)[NJ][4]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][e], bv[j][e], acc16[i][j], 0, 0, 0);
+      };
+      float a0[MI][4], b0[NJ][4], a1[MI][4], b1[NJ][4];
+      read16(0, a0, b0);
+      if (NG > 1) read16(1, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma16(a0, b0);
+      if (NG > 1) mfma16(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     // ---- fragments in 8-deep k groups: group c, element e <-> k = 8c + 4*kh + e.  The reads of group c+1 are
     // issued BEFORE the 4*2*NTW MFMAs of group c (two register sets, order pinned with sched_barrier), so the LDS
     // round trip runs under the matrix pipe instead of between MFMA bursts (measured: the burst structure hipcc
@@ -288,6 +340,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
       if (c + 1 < NC) mfma_group(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
     if (more && !(p.prio_mode & 16)) store_tiles(cur ^ 1);
     if (!(p.prio_mode & 8)) __syncthreads();
     cur ^= 1;
@@ -296,6 +349,31 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
   // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
   const int epi = p.epi, act = p.act;
+  if constexpr (MF16) {
+    // C/D map of the 16x16 tile: col = lane&15, row = (lane>>4)*4 + reg
+    const int r16 = lane & 15, q16 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2 * NTW; ++j) {
+        const int col = n0 + wn * 32 * NTW + j * 16 + r16;
+        if (col >= p.N) continue;
+        const float bias_v = add_bias ? p.bias[col] : 0.f;
+        const int row0 = m0 + wm * 64 + i * 16 + q16 * 4;
+        float* cbase = C + (int64_t)row0 * p.ldc + col;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          if (row0 + rg >= p.M) continue;
+          const float v = acc16[i][j][rg] + bias_v;
+          float* c = cbase + (int64_t)rg * p.ldc;
+          if (epi == DVAE_EPI_STORE) *c = (act == DVAE_ACT_NONE) ? v : act_apply(v, act);
+          else if (epi == DVAE_EPI_ACCUM) *c += v;
+          else atomicAdd(c, v);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -340,16 +418,27 @@ template <bool AK, bool BKC>
 void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk) {
   dim3 block(NTHR);
   static const int dyn = getenv("DVAE_GEMM_DYNLDS") ? atoi(getenv("DVAE_GEMM_DYNLDS")) : 0;   // experiment: cap occupancy
+  static const int mf16 = getenv("DVAE_GEMM_MF16") ? atoi(getenv("DVAE_GEMM_MF16")) : 0;
+  if (mf16) {
+    if (bk == 32) {
+      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, true>), grid, block, dyn, s, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, true>), grid, block, dyn, s, p);
+    } else {
+      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, true>), grid, block, dyn, s, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, true>), grid, block, dyn, s, p);
+    }
+    return;
+  }
   if (bk == 32) {
     if (narrow)
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32>), grid, block, dyn, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, false>), grid, block, dyn, s, p);
     else
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32>), grid, block, dyn, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false>), grid, block, dyn, s, p);
   } else {
     if (narrow)
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16>), grid, block, dyn, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, false>), grid, block, dyn, s, p);
     else
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16>), grid, block, dyn, s, p);
+      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, false>), grid, block, dyn, s, p);
   }
 }
 

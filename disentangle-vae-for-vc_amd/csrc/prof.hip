@@ -70,3 +70,38 @@ DVAE_API int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, 
     hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(threads), lds_bytes, (hipStream_t)stream, sink, lds_bytes / 4);
   return dvae_check_launch();
 }
+
+
+// ---- matrix-pipe ceiling probe: register-only chains of v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32
+namespace {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, int shape) {
+  const float a = (float)threadIdx.x * 1e-3f, b = 1.0f + (float)blockIdx.x * 1e-6f;
+  if (shape == 32) {
+    f32x16 c0, c1, c2, c3;
+    for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 1.f; c2[r] = 2.f; c3[r] = 3.f; }
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += c0[r] + c1[r] + c2[r] + c3[r];
+    if (s == 123.456f) out[0] = s;
+  } else {
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c2, 0, 0, 0);
+      c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
+    }
+    const float s = c0[0] + c1[1] + c2[2] + c3[3];
+    if (s == 123.456f) out[0] = s;
+  }
+}
+}  // namespace
+DVAE_API int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream) {
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, shape);
+  return dvae_check_launch();
+}

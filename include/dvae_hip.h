@@ -199,6 +199,8 @@ int dvae_prof_enable(int family);
 int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
 /* experiments: n back-to-back launches of an empty kernel (launch-floor probe, scripts/launch_floor.py) */
 int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
+/* experiments: register-only MFMA chains (shape 32 -> 32x32x2 f32, else 16x16x4 f32): the matrix-pipe ceiling of THIS chip */
+int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,18 @@
+"""GPU-box: register-only fp32 MFMA chains -> the matrix-pipe ceiling of this chip at the clock it holds."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import dvae_amd  # noqa
+from dvae_amd._lib import lib, check, stream
+L = lib()
+out = torch.zeros(4, device="cuda")
+for shape, flop in ((32, 32 * 32 * 2 * 2), (16, 16 * 16 * 4 * 2)):
+    for blocks in (256, 512, 1024):
+        iters = 20000 if shape == 32 else 40000
+        check(L.dvae_probe_mfma(blocks, 100, shape, out.data_ptr(), stream()), "probe"); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); check(L.dvae_probe_mfma(blocks, iters, shape, out.data_ptr(), stream()), "probe"); e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        tf = blocks * 4 * iters * 4 * flop / ms / 1e9
+        print(f"shape {shape}: {blocks} blocks x 4 waves, {iters} iters: {ms:.2f} ms -> {tf:.1f} TFLOP/s")
