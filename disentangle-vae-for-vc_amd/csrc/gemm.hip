@@ -25,7 +25,8 @@
 
 namespace {
 
-constexpr int BM = 128, NTHR = 256;   // BN = 64 * NTW (template): 128 or 64 ; BK (template): 16 or 32
+// Workgroup = WG x WG waves (WG = 2: 128 x 64*NTW tile, 256 threads; WG = 4: 256 x 128*NTW tile, 1024 threads).
+// The large tile halves the global-load instructions per MFMA (measured: loads cost ~15 % of the small tile's time).
 
 struct GemmParams {
   const float* A;
@@ -47,9 +48,10 @@ struct GemmParams {
   int prio_mode;         // experiment knob DVAE_GEMM_PRIO
 };
 
-template <bool A_KC, bool B_KC, int NTW, int BK, bool MF16>
-__global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
-  constexpr int BN = 64 * NTW;           // NTW = 32-wide n-tiles per wave
+template <bool A_KC, bool B_KC, int NTW, int BK, bool MF16, int WG>
+__global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
+  constexpr int BM = 64 * WG, NTHR = 64 * WG * WG;
+  constexpr int BN = 32 * NTW * WG;      // NTW = 32-wide n-tiles per wave
   constexpr int LD_KC = BK + 4;          // row stride of a k-contiguous image
   constexpr int LDA = A_KC ? LD_KC : BM + 4;
   constexpr int LDB = B_KC ? LD_KC : BN + 4;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WG, wn = wave % WG;
   const int l31 = lane & 31, kh = lane >> 5;
 
   const int tile_m = blockIdx.x % p.tiles_m;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
       }
       a_ok[j] = ok;
     } else {
-      const int kr = idx >> 5, m4 = idx & 31;
+      const int kr = idx / (BM / 4), m4 = idx % (BM / 4);
       a_k[j] = kr;
       a_src[j] = p.A + (int64_t)(k_begin + kr) * p.lda + m0 + 4 * m4;
       a_ok[j] = (m0 + 4 * m4 < p.M) ? 1u : 0u;
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
         const int row = idx / KQ, kq = idx % KQ;
         *reinterpret_cast<f32x4*>(&As[buf][row * LDA + 4 * kq]) = ra[j];
       } else {
-        const int kr = idx >> 5, m4 = idx & 31;
+        const int kr = idx / (BM / 4), m4 = idx % (BM / 4);
         *reinterpret_cast<f32x4*>(&As[buf][kr * LDA + 4 * m4]) = ra[j];
       }
     }
@@ -415,30 +417,30 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(const GemmParams p) {
 }
 
 template <bool AK, bool BKC>
-void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk) {
-  dim3 block(NTHR);
+void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, bool big) {
   static const int dyn = getenv("DVAE_GEMM_DYNLDS") ? atoi(getenv("DVAE_GEMM_DYNLDS")) : 0;   // experiment: cap occupancy
   static const int mf16 = getenv("DVAE_GEMM_MF16") ? atoi(getenv("DVAE_GEMM_MF16")) : 0;
+  if (big) {   // 256 x 256 x 32 tile, 16 waves
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 4>), grid, dim3(1024), dyn, s, p);
+    return;
+  }
+  dim3 block(256);
   if (mf16) {
     if (bk == 32) {
-      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, true>), grid, block, dyn, s, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, true>), grid, block, dyn, s, p);
+      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, true, 2>), grid, block, dyn, s, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, true, 2>), grid, block, dyn, s, p);
     } else {
-      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, true>), grid, block, dyn, s, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, true>), grid, block, dyn, s, p);
+      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, true, 2>), grid, block, dyn, s, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, true, 2>), grid, block, dyn, s, p);
     }
     return;
   }
   if (bk == 32) {
-    if (narrow)
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, false>), grid, block, dyn, s, p);
-    else
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false>), grid, block, dyn, s, p);
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, false, 2>), grid, block, dyn, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 2>), grid, block, dyn, s, p);
   } else {
-    if (narrow)
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, false>), grid, block, dyn, s, p);
-    else
-      hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, false>), grid, block, dyn, s, p);
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, false, 2>), grid, block, dyn, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, false, 2>), grid, block, dyn, s, p);
   }
 }
 
@@ -465,23 +467,29 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
   p.split_k = (p.K + kps - 1) / kps;
-  p.tiles_m = (p.M + BM - 1) / BM;
   const int zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
+  static const int big_env = getenv("DVAE_GEMM_BIG") ? atoi(getenv("DVAE_GEMM_BIG")) : -1;
+  // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
+  const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
+  bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256);
+  if (big_env >= 0) big = (big_env != 0) && (bk == 32);
+  const int bm = big ? 256 : 128;
+  p.tiles_m = (p.M + bm - 1) / bm;
   // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
   const int tiles128 = p.tiles_m * ((p.N + 127) / 128) * zdim;
-  const bool narrow = narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32);
-  const int bn = narrow ? 64 : 128;
+  const bool narrow = !big && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
+  const int bn = big ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * (p.tap_mode ? p.taps : 1));
   if (a_kc && b_kc)
-    launch_variant<true, true>(p, grid, s, narrow, bk);
+    launch_variant<true, true>(p, grid, s, narrow, bk, big);
   else if (a_kc && !b_kc)
-    launch_variant<true, false>(p, grid, s, narrow, bk);
+    launch_variant<true, false>(p, grid, s, narrow, bk, big);
   else if (!a_kc && b_kc)
-    launch_variant<false, true>(p, grid, s, narrow, bk);
+    launch_variant<false, true>(p, grid, s, narrow, bk, big);
   else
-    launch_variant<false, false>(p, grid, s, narrow, bk);
+    launch_variant<false, false>(p, grid, s, narrow, bk, big);
   return dvae_check_launch();
 }
 
