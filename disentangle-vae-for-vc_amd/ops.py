@@ -113,11 +113,17 @@ def _ready(*ps):
 
 
 def _split_k(m_tiles: int, k: int) -> int:
-    """Pick a split so that the launch has ~>=512 workgroups but each keeps >= 256 of K."""
-    s = 1
-    while m_tiles * s < 512 and k // (s * 2) >= 256:
-        s *= 2
-    return s
+    """Pick the split of the contraction that minimises (rounds over the chip) x (k per workgroup + fixed cost):
+    512 workgroup slots (2 per CU at the 128x128x32 tile), each split keeps >= 256 of K.  Not restricted to
+    powers of two: 80 tiles x 6 splits fill one round where x 8 needs two."""
+    slots, fixed = int(os.environ.get("DVAE_SPLIT_SLOTS", "512")), 192
+    best, best_cost = 1, None
+    for s in range(1, max(1, k // 256) + 1):
+        rounds = -(-(m_tiles * s) // slots)
+        cost = rounds * (-(-k // s) + fixed) * (1.0 if s == 1 else 1.03)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s, cost
+    return best
 
 
 def _tiles(m, n):
