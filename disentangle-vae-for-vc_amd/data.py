@@ -96,13 +96,23 @@ class GpuPairLoader:
     GB: trivial against 288 GB of HBM) and a batch is produced by one HIP gather kernel.  Pairing, per-epoch
     re-pairing (`dataset.shuffle_data()`), random crop / right zero-pad and the speaker label are those of
     SpeechDatasetGVAE — the pair list IS the dataset's; only where the bytes live and who crops changes.
-    Yields (x1 [B,80,T], x2 [B,80,T], speaker_ids [B]) on the device."""
+    Yields (x1 [B,80,T], x2 [B,80,T], speaker_ids [B]) on the device.
+
+    Data parallel: with `world_size` > 1 every rank holds the whole corpus (it is small) and takes pairs
+    rank, rank+world, ... of the SAME epoch permutation, so `seed` (and the dataset's seed) must be given and equal
+    on all ranks; every rank sees the same number of batches (the remainder is dropped)."""
 
     def __init__(self, dataset: SpeechDatasetGVAE, batch_size: int, device="cuda", seed: Optional[int] = None,
-                 drop_last: bool = True, shuffle: bool = True):
+                 drop_last: bool = True, shuffle: bool = True, rank: int = 0, world_size: int = 1):
+        if world_size > 1 and seed is None:
+            raise ValueError("GpuPairLoader: data-parallel sharding needs an explicit seed shared by all ranks")
+        if not 0 <= rank < world_size:
+            raise ValueError("GpuPairLoader: rank out of range")
         self.dataset = dataset
         self.batch_size, self.drop_last, self.shuffle = batch_size, drop_last, shuffle
+        self.rank, self.world_size = rank, world_size
         self.rng = np.random.RandomState(seed) if seed is not None else np.random
+        self.crop_rng = np.random.RandomState(seed + 7919 * (rank + 1)) if seed is not None else np.random
         self.T = dataset.samples_length
         files = sorted({f for utts in dataset.spk_utt for f in utts})
         self.index = {f: i for i, f in enumerate(files)}
@@ -118,13 +128,16 @@ class GpuPairLoader:
         self.lens_dev = torch.from_numpy(self.lengths).to(self.device)
         self.last_meta = None       # (utt1, utt2, off1, off2) of the last batch, for tests
 
+    def _n_local(self):
+        return len(self.dataset) // self.world_size
+
     def __len__(self):
-        n = len(self.dataset)
+        n = self._n_local()
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _offset(self, L):
         # same rule as SpeechDatasetGVAE._crop: random start if longer, 0 (and zero padding) otherwise
-        return int(self.rng.randint(0, L - self.T)) if L > self.T else 0
+        return int(self.crop_rng.randint(0, L - self.T)) if L > self.T else 0
 
     def gather(self, utt, off):
         """Crop batch on the device: utt, off int arrays [n] -> [n, 80, T]."""
@@ -139,7 +152,8 @@ class GpuPairLoader:
 
     def __iter__(self):
         n = len(self.dataset)
-        order = self.rng.permutation(n) if self.shuffle else np.arange(n)
+        order = self.rng.permutation(n) if self.shuffle else np.arange(n)     # identical on every rank
+        order = order[:self._n_local() * self.world_size][self.rank::self.world_size]
         for b in range(len(self)):
             sel = order[b * self.batch_size:(b + 1) * self.batch_size]
             pairs = self.dataset.utterance_fp[sel]

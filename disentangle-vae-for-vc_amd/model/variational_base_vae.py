@@ -9,7 +9,9 @@ Changed on purpose:
   * optional data parallelism: `attach_reducer()` installs ddp.GradReducer, after which `step`
     overlaps a bucketed RCCL all-reduce of the flat gradient buffer with backward;
   * TensorBoard is optional (tensorboardX is not a dependency): scalars go to `logs_path/scalars.jsonl`;
-  * out of scope here: estimate_trained_model / voice_conversion_mel / test.
+  * `estimate_trained_model` (:205-239) keeps its tensor part (eval-mode forward of one batch with train=False) and
+    writes the mels as .npy (+ PNG when matplotlib is importable; librosa.display is not a dependency);
+    `voice_conversion_mel` keeps its tensor part as `convert_mel`; vocoder / file I/O stay outside.
 """
 from __future__ import annotations
 
@@ -162,12 +164,55 @@ class VariationalBaseModelVAE:
         self.model.load_state_dict(torch.load(last, map_location=self.device))
         opt = last[:-4] + ".opt"
         if os.path.exists(opt):
-            self.optimizer.load_state_dict(torch.load(opt, map_location="cpu"))
+            sd = torch.load(opt, map_location="cpu")
+            self.optimizer.load_state_dict(sd)
+            if sd.get("cuda_rng_state") is not None and torch.device(self.device).type == "cuda":
+                torch.cuda.set_rng_state(sd["cuda_rng_state"], self.device)   # eps stream continues where it stopped
         logging_func(f"Loading {name} model from last checkpoint ({start_epoch})...")
         return start_epoch + 1
 
     def update_(self):
         pass
+
+    # ---- variational_base_vae.py:205-239
+    @torch.no_grad()
+    def estimate_trained_model(self, test_loader, checkpoints_path, estimation_dir, n_show=5):
+        """Load the last checkpoint, run ONE batch through the eval-mode forward (`train=False`: content z = mu,
+        BatchNorm on running statistics) and store the first `n_show` original / reconstructed mels of x1 as
+        `{epoch}_original_mel_{i}.npy` / `{epoch}_recons_mel_{i}.npy` (the reference stores specshow PNGs; PNGs are
+        also written here when matplotlib imports).  Returns (epoch, recons_x1, recons_x2)."""
+        logging_epoch = self.load_last_model(checkpoints_path, logging_func=lambda *_: None)
+        was_training = self.model.training
+        self.model.eval()
+        os.makedirs(estimation_dir, exist_ok=True)
+        try:
+            data1, data2, _ = next(iter(test_loader))
+            data1 = data1.to(self.device).float()
+            data2 = data2.to(self.device).float()
+            outs = self.model(data1, data2, train=False)
+            recons_x1, recons_x2 = outs[2], outs[3]
+            try:
+                import matplotlib
+                matplotlib.use("Agg")
+                import matplotlib.pyplot as plt
+            except Exception:                      # plotting is optional
+                plt = None
+            for i in range(min(n_show, data1.shape[0])):
+                for tag, mel in (("original", data1[i]), ("recons", recons_x1[i])):
+                    arr = mel.detach().cpu().numpy()
+                    base = os.path.join(estimation_dir, f"{logging_epoch}_{tag}_mel_{i}")
+                    import numpy as np
+                    np.save(base + ".npy", arr)
+                    if plt is not None:
+                        plt.figure()
+                        plt.title(("reconstructed" if tag == "recons" else "original") + " mel spectrogram")
+                        plt.imshow(arr, origin="lower", aspect="auto")
+                        plt.colorbar(format="%f")
+                        plt.savefig(base + ".png")
+                        plt.close()
+            return logging_epoch, recons_x1, recons_x2
+        finally:
+            self.model.train(was_training)
 
     # ---- tensor part of voice_conversion_mel (variational_base_vae.py:269-301); file I/O, plots and the WaveNet
     # vocoder of the reference stay outside (SURVEY.md §8f-3)
@@ -238,7 +283,9 @@ class VariationalBaseModelVAE:
                 with torch.no_grad():
                     base = f"{checkpoints_path}/{run_name}_{epoch}"
                     torch.save(self.model.state_dict(), base + ".pth")      # reference format: weights only
-                    torch.save(self.optimizer.state_dict(), base + ".opt")  # added: Adam moments + step count
+                    osd = self.optimizer.state_dict()                        # added: Adam moments + step count
+                    osd["cuda_rng_state"] = torch.cuda.get_rng_state(self.device)   # + the eps generator state
+                    torch.save(osd, base + ".opt")
         if log_f:
             log_f.close()
         return history

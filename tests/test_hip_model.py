@@ -320,3 +320,51 @@ def test_gpu_pair_loader_matches_dataset_semantics(tmp_path):
     w = make(3, 64)
     vals = w.train(loader, 1, logging_func=lambda *a: None)     # the trainer consumes it like a DataLoader
     assert all(np.isfinite(v) for v in vals)
+
+
+def test_gpu_pair_loader_rank_sharding(tmp_path):
+    """Data-parallel sharding of the device-resident loader: ranks take disjoint pairs of the same epoch permutation,
+    together they cover every pair once, and every rank sees the same number of batches."""
+    from dvae_amd.data import GpuPairLoader, SpeechDatasetGVAE, write_synthetic_corpus
+    root = write_synthetic_corpus(str(tmp_path / "corpus"), n_speakers=4, n_utt=8, length=80, seed=1)
+    seen = []
+    for rank in range(2):
+        ds = SpeechDatasetGVAE(root, samples_length=64, seed=4)
+        loader = GpuPairLoader(ds, batch_size=2, seed=5, rank=rank, world_size=2)
+        assert len(loader) == len(ds) // 2 // 2
+        mine = []
+        for x1, x2, spk in loader:
+            u1, u2, _, _ = loader.last_meta
+            mine += list(zip(u1.tolist(), u2.tolist()))
+        assert len(mine) == len(loader) * 2
+        seen.append(set(mine))
+    assert not (seen[0] & seen[1]) and len(seen[0] | seen[1]) == 16
+    with pytest.raises(ValueError):
+        GpuPairLoader(ds, batch_size=2, rank=0, world_size=2)          # no shared seed
+
+
+def test_estimate_trained_model(tmp_path):
+    """variational_base_vae.py:205-239: last checkpoint -> eval-mode forward(train=False) of one batch -> mels on disk.
+    The reconstruction must equal the oracle's eval-mode forward on the same weights."""
+    from oracle.dvae_ref import RefDVAE
+    w = make(3, 64)
+    sd = fill_state_dict(w.model.state_dict(), salt=5, random_running_stats=True)
+    ck = tmp_path / "ck"
+    ck.mkdir()
+    torch.save(sd, str(ck / "DisentangledVAE_VCTK_7.pth"))
+    x1, x2 = synthetic_pair(3, 64, 17)
+    loader = [(x1, x2, torch.zeros(3, dtype=torch.long))]
+    eps = synthetic_eps(3, seed=1)
+    w.model.eps_override = eps            # the style noise is drawn even with train=False (disentangled_vae.py:261)
+    epoch, r1, r2 = w.estimate_trained_model(loader, str(ck), str(tmp_path / "est"))
+    assert epoch == 8 and w.model.training
+    files = sorted(os.listdir(tmp_path / "est"))
+    assert "8_original_mel_0.npy" in files and "8_recons_mel_2.npy" in files
+    m = RefDVAE(4, 32, 64)
+    m.load_state_dict(sd)
+    m.eval()
+    with torch.no_grad():
+        ref = m(x1, x2, (None, None, eps[2]))
+    got = np.load(tmp_path / "est" / "8_recons_mel_1.npy")
+    np.testing.assert_allclose(got, ref[2][1].numpy(), atol=2e-3)
+    np.testing.assert_allclose(r2.cpu().numpy(), ref[3].numpy(), atol=2e-3)
