@@ -62,6 +62,9 @@ SIGNATURES = {
     "dvae_chunks_to_mel": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, vp]),
     "dvae_conversion_latents": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_mul_div": (i32, [vp, vp, vp, vp, i64, vp]),
+    "dvae_stft_frames": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp]),
+    "dvae_stft_magnitude": (i32, [vp, vp, i64, i32, vp]),
+    "dvae_mel_db_normalize": (i32, [vp, vp, i32, i32, i64, i64, f32, f32, f32, vp]),
     "dvae_probe_launches": (i32, [i32, i32, i32, i32, vp, vp]),
     "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
     "dvae_prof_enable": (i32, [i32]),

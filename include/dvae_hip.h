@@ -192,6 +192,18 @@ int dvae_conversion_latents(const float* src_style, const float* src_content, co
                             float* z_src, float* z_conv, int n, int m, int S, int Cn, void* stream);
 int dvae_mul_div(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 
+/* ---- mel front-end: preprocessing/utils.py:68-73 `melspectrogram` = lws STFT (1024/256, "speech" window)
+ * -> |.| -> 80-mel projection (librosa.filters.mel) -> dB (:127-129) - ref_level_db -> normalise to [0,1] (:136-137).
+ * The two contractions (frames x DFT basis, magnitudes x mel basis) are dvae_gemm_f32 launches; these are the passes around them.
+ * dvae_stft_frames: frames[M, fsize] = window * signal zero-padded by `left` samples in front (lws pads fsize-hop, :82-103).
+ * dvae_stft_magnitude: reim[rows, 2*nbp] (real block | imaginary block) -> mag[rows, nbp].
+ * dvae_mel_db_normalize: mel[M, n_mels] (frame-major) -> out[n_mels, ld_out] at column col0 (the [80, L] layout of the .npy corpus). */
+int dvae_stft_frames(const float* wav, int64_t n, const float* window, float* frames, int M, int fsize, int hop,
+                     int left, void* stream);
+int dvae_stft_magnitude(const float* reim, float* mag, int64_t rows, int nbins_padded, void* stream);
+int dvae_mel_db_normalize(const float* mel, float* out, int M, int n_mels, int64_t ld_out, int64_t col0,
+                          float min_level, float ref_level_db, float min_level_db, void* stream);
+
 /* ---- opt-in per-family kernel timing with HIP events on the launch stream (bench.py roofline) ----
  * family: 0 = off, 1 = GEMM/conv contraction kernel, 2 = LSTM step kernels.
  * dvae_prof_collect: synchronises the recorded events, returns total ms, launch count and algorithmic FLOPs. */

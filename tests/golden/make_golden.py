@@ -5,7 +5,7 @@ the reference never travels to the GPU box; the .npz files written next to this
 script do.
 
 What is patched to make the reference executable here:
-  * 14 absent leaf modules (torchvision, librosa, tensorboardX, ...) are stubbed
+  * 15 absent leaf modules (torchvision, librosa, tensorboardX, ...) are stubbed
     with MagicMock; none is touched by forward / loss / step;
   * torch.Tensor.cuda := identity (disentangled_vae.py:224 calls .cuda() on eps);
   * ConvolutionalMulVAE is constructed with device=cpu;
@@ -16,7 +16,7 @@ Weights come from oracle/fill.py (deterministic by state_dict key), inputs from
 seeded NumPy streams, the three eps tensors from torch.manual_seed(seed) drawn in
 the reference's own order — they are recorded in the fixture.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [steps|conversion|frontend]
 """
 import os
 import sys
@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, REF)
 
 for name in ["torchvision", "torchvision.utils", "torchvision.transforms", "mpl_toolkits.axes_grid1",
-             "librosa", "librosa.display", "soundfile", "tensorboardX", "wavenet_vocoder", "pyworld",
+             "librosa", "librosa.display", "librosa.filters", "soundfile", "tensorboardX", "wavenet_vocoder", "pyworld",
              "pysptk", "lws", "preprocessing.processing", "preprocessing.WORLD_processing"]:
     sys.modules[name] = MagicMock()
 
@@ -159,8 +159,54 @@ def run_conversion_case():
     print("conversion", src.shape, trg.shape, float(conv_voice.mean()), float(recons_voice.mean()))
 
 
+def run_frontend_case():
+    """Mel front-end.  The reference's preprocessing/utils.py is imported unmodified.  Its own
+    arithmetic (`_amp_to_db`, `_normalize`, `_denormalize`, `lws_num_frames`, `lws_pad_lr`) is recorded directly.
+    `melspectrogram` (:68-73) is recorded with its two THIRD-PARTY calls — `lws.lws(...).stft` and
+    `librosa.filters.mel`, both absent here — answered by the restatements in oracle/mel_ref.py: that pins the glue
+    (abs, mel projection, dB, reference level, normalisation, transposes), not lws / librosa themselves."""
+    import preprocessing.utils as pu
+    from oracle import mel_ref
+    rs = np.random.RandomState(5)
+    lengths = np.array([1, 255, 256, 257, 768, 1000, 1024, 4096, 16000, 16001, 48000 + 13])
+    frames = np.array([pu.lws_num_frames(int(n), 1024, 256) for n in lengths])
+    pads = np.array([pu.lws_pad_lr(np.zeros(int(n)), 1024, 256) for n in lengths])
+    amp = np.concatenate((rs.uniform(0, 3, 200), 10.0 ** rs.uniform(-8, 2, 200), [0.0, 1e-5, 1.0]))
+    db = pu._amp_to_db(amp)
+    sdb = rs.uniform(-140, 30, 300)
+    norm = pu._normalize(sdb)
+    denorm_in = rs.uniform(-0.2, 1.2, 300)
+    denorm = pu._denormalize(denorm_in)
+
+    class _Lws:                                           # stands in for the absent lws package
+        def __init__(self, fsize, fshift, mode=None):
+            assert (fsize, fshift, mode) == (1024, 256, "speech")
+            self.fsize, self.fshift = fsize, fshift
+
+        def stft(self, y):
+            return mel_ref.lws_stft(y, self.fsize, self.fshift)
+
+    sys.modules["lws"].lws = _Lws
+    pu.librosa.filters.mel = lambda sr, n_fft, fmin=0.0, fmax=None, n_mels=128: mel_ref.mel_basis(sr, n_fft, n_mels, fmin, fmax)
+    pu._mel_basis = None
+    t = np.arange(16000 + 77) / 16000.0
+    wav = (0.3 * np.sin(2 * np.pi * 440 * t) + 0.1 * np.sin(2 * np.pi * 3000 * t * (1 + 0.2 * t))
+           + 0.02 * rs.standard_normal(t.shape)) * np.hanning(len(t))
+    wav = wav.astype(np.float32).astype(np.float64)       # stored as fp32: compute the vector from the stored values
+    mel = pu.melspectrogram(wav)
+    out = os.path.join(HERE, "frontend.npz")
+    np.savez_compressed(out, lengths=lengths, frames=frames, pads=pads, amp=amp, db=db, sdb=sdb, norm=norm,
+                        denorm_in=denorm_in, denorm=denorm, wav=wav.astype(np.float32), mel=mel,
+                        hparams=np.array([pu.hparams.sample_rate, pu.hparams.fft_size, pu.get_hop_size(),
+                                          pu.hparams.num_mels, pu.hparams.fmin, pu.hparams.fmax,
+                                          pu.hparams.min_level_db, pu.hparams.ref_level_db], dtype=np.float64))
+    print("wrote", out, mel.shape, os.path.getsize(out))
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "frontend"):
+        run_frontend_case()
     if only in ("", "steps"):
         for c in CASES:
             run_case(*c)
