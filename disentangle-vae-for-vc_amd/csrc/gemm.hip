@@ -461,8 +461,9 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   p.prio_mode = prio_env;
   static const int narrow_env = getenv("DVAE_GEMM_NARROW") ? atoi(getenv("DVAE_GEMM_NARROW")) : -1;
   int kps = (p.K + p.split_k - 1) / p.split_k;
-  // k-tile 32 when the per-split K allows it without padding waste
-  int bk = (kps % 32 == 0 && kps >= 64) ? 32 : 16;
+  // k-tile 32 when the per-split K allows it without padding waste (a long split is simply rounded up to whole
+  // 32-deep tiles: the last split takes what is left)
+  int bk = ((kps % 32 == 0 && kps >= 64) || (p.split_k > 1 && kps >= 512)) ? 32 : 16;
   if (bk_env == 16 || bk_env == 32) bk = bk_env;
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;

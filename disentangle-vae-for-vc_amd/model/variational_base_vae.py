@@ -85,7 +85,7 @@ class VariationalBaseModelVAE:
         S, Cn = m.speaker_size, m.latent_dim - m.speaker_size
         self._graph_calls += 1
         if self._graph_calls == 1:
-            return tuple(self._eager_train_step(data1, data2).tolist())
+            return self._eager_train_step(data1, data2)
         if self._graph is None:
             self._g_x1, self._g_x2 = torch.empty_like(data1), torch.empty_like(data2)
             self._g_eps = (torch.empty((Bh, Cn), device=dev), torch.empty((Bh, Cn), device=dev),
@@ -108,44 +108,54 @@ class VariationalBaseModelVAE:
             self._graph.replay()
         finally:
             m.eps_override = user_eps
-        return tuple(self._g_losses.tolist())
+        return self._g_losses.clone()       # the static buffer is overwritten by the next replay
+
+    def step_async(self, data1, data2, speaker_ids=None):
+        """One TRAIN step without any host synchronisation: the 8 loss scalars come back as a device tensor, so the
+        host can enqueue the next step (noise draw, input copies, graph launch) while this one runs.  `step(...,
+        train=True)` is this plus one device->host copy."""
+        if self._use_graph and self.reducer is None:
+            return self._step_graph(data1, data2)
+        self.optimizer.zero_grad()
+        outs = self.model(data1, data2)
+        losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
+        if self.reducer is not None:
+            self.reducer.begin()
+        losses[0].backward()
+        scale = 1.0
+        if self.reducer is not None:
+            self.reducer.finish()
+            scale = 1.0 / self.reducer.world_size
+        self.optimizer.step(grad_scale=scale)
+        return torch.stack([l.detach() for l in losses])
 
     # ---- variational_base_vae.py:58-70
     def step(self, data1, data2, speaker_ids, train=False):
-        if train and self._use_graph and self.reducer is None:
-            return self._step_graph(data1, data2)
         if train:
-            self.optimizer.zero_grad()
+            return tuple(self.step_async(data1, data2, speaker_ids).tolist())   # one D2H copy, not 8 .item() syncs
         outs = self.model(data1, data2)
         losses = self.loss_functionGVAE2(data1, data2, *outs, train=train)
-        if train:
-            if self.reducer is not None:
-                self.reducer.begin()
-            losses[0].backward()
-            scale = 1.0
-            if self.reducer is not None:
-                self.reducer.finish()
-                scale = 1.0 / self.reducer.world_size
-            self.optimizer.step(grad_scale=scale)
-        vals = torch.stack([l.detach() for l in losses]).tolist()   # one D2H copy instead of 8 .item() syncs
-        return tuple(vals)
+        return tuple(torch.stack([l.detach() for l in losses]).tolist())
 
     # ---- variational_base_vae.py:74-101
     def train(self, train_loader, epoch, logging_func=print):
         self.model.train()
-        tot = [0.0] * 8
-        last_style = 0.0
+        # the running sums of :88-96 live on the device (fp64); the host reads them once per epoch instead of
+        # stalling the queue after every step
+        tot = torch.zeros(8, dtype=torch.float64, device=self.device)
+        last = None
         for data1, data2, speaker_ids in train_loader:
             data1 = data1.to(self.device, non_blocking=True).float()
             data2 = data2.to(self.device, non_blocking=True).float()
             speaker_ids = speaker_ids.view(-1)
-            vals = self.step(data1, data2, speaker_ids, train=True)
-            for i in range(8):
-                tot[i] += vals[i]
-            last_style = vals[7]
-        if hasattr(train_loader.dataset, "shuffle_data"):
+            last = self.step_async(data1, data2, speaker_ids)
+            tot.add_(last)
+        tot = tot.tolist()
+        last_style = float(last[7]) if last is not None else 0.0
+        if hasattr(train_loader, "dataset") and hasattr(train_loader.dataset, "shuffle_data"):
             train_loader.dataset.shuffle_data()
-        logging_func("====> Epoch: {} Average loss: {:.4f}".format(epoch, tot[0] / max(1, len(train_loader.dataset))))
+        n_items = len(train_loader.dataset) if hasattr(train_loader, "dataset") else len(train_loader)
+        logging_func("====> Epoch: {} Average loss: {:.4f}".format(epoch, tot[0] / max(1, n_items)))
         # NB the reference returns the style KL of the LAST batch, not the total (:101)
         return tot[1], tot[2], tot[3], tot[4], tot[5], tot[6], last_style
 

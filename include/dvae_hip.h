@@ -213,6 +213,9 @@ int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
 int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
 /* experiments: register-only MFMA chains (shape 32 -> 32x32x2 f32, else 16x16x4 f32): the matrix-pipe ceiling of THIS chip */
 int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream);
+/* timeline of the last LSTM forward frame launched with DVAE_LSTM_DBG bit 8 set: 8 stamps per workgroup (s_memtime at
+ * entry / first tile staged / first round computed / second tile staged / accumulators parked / reduced / done; slot 7 = wall clock). */
+int dvae_probe_lstm_timeline(unsigned long long* host_out, int n_words);
 
 #ifdef __cplusplus
 }
