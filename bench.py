@@ -169,11 +169,20 @@ def main():
             torch.cuda.synchronize()
         ms, launches, flops = ops.prof_collect()
         ops.prof_enable(0)
+        traffic, traffic_src = None, None
+        try:   # HBM-side bytes per launch of this kernel family from the committed PMC passes (not collectable live)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if B == 64 and T == 128:
+                traffic, traffic_src = pm["gemm_f32_kernel"]["traffic_bytes_per_launch"], pm["source"]
+        except Exception:
+            pass
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach,
                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                    "traffic": None, "launches_per_step": launches / prof_steps,
+                    "traffic": traffic, "traffic_unit": "bytes per launch (L2<->fabric, PMC)",
+                    "traffic_source": traffic_src, "launches_per_step": launches / prof_steps,
                     "kernel_ms_per_step": ms / prof_steps, "avg_launch_us": 1e3 * ms / max(1, launches),
                     "flops_per_step": flops / prof_steps,
                     "timed": "HIP events around every launch, " + ("inside the timed region" if prof_live else

@@ -62,6 +62,8 @@ SIGNATURES = {
     "dvae_chunks_to_mel": (i32, [vp, vp, i32, i32, i32, f32, f32, i32, vp]),
     "dvae_conversion_latents": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_mul_div": (i32, [vp, vp, vp, vp, i64, vp]),
+    "dvae_set_compute_mode": (i32, [i32]),
+    "dvae_get_compute_mode": (i32, []),
     "dvae_stft_frames": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_stft_magnitude": (i32, [vp, vp, i64, i32, vp]),
     "dvae_mel_db_normalize": (i32, [vp, vp, i32, i32, i64, i64, f32, f32, f32, vp]),
@@ -98,6 +100,9 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = h
+        mode = os.environ.get("DVAE_COMPUTE_DTYPE", "").lower()
+        if mode in ("bf16", "bfloat16"):     # same as ops.set_compute_dtype("bf16"), for scripts
+            h.dvae_set_compute_mode(1)
     return _lib
 
 

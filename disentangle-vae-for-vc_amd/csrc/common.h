@@ -8,6 +8,11 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+extern int g_dvae_compute_mode;   // gemm.hip: 0 fp32 MFMA, 1 bf16 operands with fp32 accumulation
 
 extern int g_dvae_last_hip_error;
 

@@ -21,7 +21,10 @@
 // product is unchanged).  All of a k-tile's fragments are fetched before its MFMAs are issued, so the
 // matrix pipe runs back to back instead of paying one LDS round trip per k-step.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
+
+int g_dvae_compute_mode = 0;   // 0: fp32 MFMA; 1: bf16 operands / fp32 accumulation (dvae_set_compute_mode)
 
 namespace {
 
@@ -48,21 +51,28 @@ struct GemmParams {
   int prio_mode;         // experiment knob DVAE_GEMM_PRIO
 };
 
-template <bool A_KC, bool B_KC, int NTW, int BK, bool MF16, int WG>
+// BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
+// to bf16 (RNE, v_cvt_pk_bf16_f32) while they are staged into LDS; the products run on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation.  Images: k-contiguous [rows][BK + 8] bf16 (80-B rows: conflict-free ds_read_b128 of 8 k values);
+// row-contiguous [BK][rows + 32] bf16 read with ds_read_b64_tr_b16 (the hardware transpose delivers 4 consecutive k
+// of one row per lane; 320-B / 192-B k-rows put the 4 k-rows of a read in 4 different 64-B bank quadrants).
+template <bool A_KC, bool B_KC, int NTW, int BK, bool MF16, int WG, bool BF = false>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
+  static_assert(!BF || (BK == 32 && !MF16 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
   constexpr int BM = 64 * WG, NTHR = 64 * WG * WG;
   constexpr int BN = 32 * NTW * WG;      // NTW = 32-wide n-tiles per wave
-  constexpr int LD_KC = BK + 4;          // row stride of a k-contiguous image
-  constexpr int LDA = A_KC ? LD_KC : BM + 4;
-  constexpr int LDB = B_KC ? LD_KC : BN + 4;
-  constexpr int A_SZ = A_KC ? BM * LD_KC : BK * (BM + 4);
-  constexpr int B_SZ = B_KC ? BN * LD_KC : BK * (BN + 4);
+  constexpr int LD_KC = BF ? BK + 8 : BK + 4;          // row stride of a k-contiguous image
+  constexpr int LDA = A_KC ? LD_KC : (BF ? BM + 32 : BM + 4);
+  constexpr int LDB = B_KC ? LD_KC : (BF ? BN + 32 : BN + 4);
+  constexpr int A_SZ = A_KC ? BM * LD_KC : BK * LDA;
+  constexpr int B_SZ = B_KC ? BN * LD_KC : BK * LDB;
+  using lds_t = typename std::conditional<BF, __bf16, float>::type;
   constexpr int NLA = BM * BK / 4 / NTHR;   // float4 per thread per k-tile (A)
   constexpr int NLB = BN * BK / 4 / NTHR;   // (B)
   constexpr int KQ = BK / 4;                // float4 per row of a k-contiguous tile
   constexpr int NC = BK / 8;                // 8-deep k groups per tile
-  __shared__ __attribute__((aligned(16))) float As[2][A_SZ];
-  __shared__ __attribute__((aligned(16))) float Bs[2][B_SZ];
+  __shared__ __attribute__((aligned(16))) lds_t As[2][A_SZ];
+  __shared__ __attribute__((aligned(16))) lds_t Bs[2][B_SZ];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -179,7 +189,10 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
       const int idx = t + NTHR * j;
-      if (A_KC) {
+      if constexpr (BF) {
+        const int off = A_KC ? (idx / KQ) * LDA + 4 * (idx % KQ) : (idx / (BM / 4)) * LDA + 4 * (idx % (BM / 4));
+        *reinterpret_cast<bf16x4*>(&As[buf][off]) = __builtin_convertvector(ra[j], bf16x4);
+      } else if (A_KC) {
         const int row = idx / KQ, kq = idx % KQ;
         *reinterpret_cast<f32x4*>(&As[buf][row * LDA + 4 * kq]) = ra[j];
       } else {
@@ -190,7 +203,10 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       const int idx = t + NTHR * j;
-      if (B_KC) {
+      if constexpr (BF) {
+        const int off = B_KC ? (idx / KQ) * LDB + 4 * (idx % KQ) : (idx / (BN / 4)) * LDB + 4 * (idx % (BN / 4));
+        *reinterpret_cast<bf16x4*>(&Bs[buf][off]) = __builtin_convertvector(rb[j], bf16x4);
+      } else if (B_KC) {
         const int row = idx / KQ, kq = idx % KQ;
         *reinterpret_cast<f32x4*>(&Bs[buf][row * LDB + 4 * kq]) = rb[j];
       } else {
@@ -244,7 +260,39 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       load_tiles(tap_n, kit_n);
       advance();
     }
-    if constexpr (MF16) {
+    if constexpr (BF) {
+      // v_mfma_f32_32x32x16_bf16: lane (r = lane&31, h = lane>>5) holds k = 16s + 8h + j, j = 0..7, of row r.
+      // k-contiguous image: one ds_read_b128.  Row-contiguous image [k][rows]: two ds_read_b64_tr_b16; lane 4q+pq of
+      // the 16-lane group g supplies &img[k0 + q][r0 + 4pq] (k0 = 16s + 8(g>>1) (+4), r0 = 16(g&1)) and receives
+      // 4 consecutive k of row r0 + (lane&15).
+      const int g16 = lane >> 4, li = lane & 15;
+      const int tr_k = 8 * (g16 >> 1) + (li >> 2), tr_r = 16 * (g16 & 1) + 4 * (li & 3);
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      auto frag = [&](const lds_t* img, bool kc, int ld, int row0, int s2) -> bf16x8 {
+        if (kc) return *reinterpret_cast<const bf16x8*>(&img[(row0 + l31) * ld + 16 * s2 + 8 * kh]);
+        const lds_t* q0 = &img[(16 * s2 + tr_k) * ld + row0 + tr_r];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * ld));
+        return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+      bf16x8 av[2][2], bv[2][NTW];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) av[s2][mt] = frag(&As[cur][0], A_KC, LDA, wm * 64 + mt * 32, s2);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bv[s2][nt] = frag(&Bs[cur][0], B_KC, LDB, wn * 32 * NTW + nt * 32, s2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][0], bv[s2][nt], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][1], bv[s2][nt], acc[1][nt], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (MF16) {
       // 16x16x4: lane (r = lane&15, q = lane>>4); 16-deep k groups, element e <-> k = 16g + 4q + e
       constexpr int MI = 4, NJ = 2 * NTW, NG = BK / 16;
       const int r16 = lane & 15, q16 = lane >> 4;
@@ -420,6 +468,11 @@ template <bool AK, bool BKC>
 void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, bool big) {
   static const int dyn = getenv("DVAE_GEMM_DYNLDS") ? atoi(getenv("DVAE_GEMM_DYNLDS")) : 0;   // experiment: cap occupancy
   static const int mf16 = getenv("DVAE_GEMM_MF16") ? atoi(getenv("DVAE_GEMM_MF16")) : 0;
+  if (g_dvae_compute_mode == 1) {   // bf16 operands, fp32 accumulation
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, false, 2, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 2, true>), grid, dim3(256), 0, s, p);
+    return;
+  }
   if (big) {   // 256 x 256 x 32 tile, 16 waves
     hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 4>), grid, dim3(1024), dyn, s, p);
     return;
@@ -465,6 +518,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   // 32-deep tiles: the last split takes what is left)
   int bk = ((kps % 32 == 0 && kps >= 64) || (p.split_k > 1 && kps >= 512)) ? 32 : 16;
   if (bk_env == 16 || bk_env == 32) bk = bk_env;
+  const bool bf = (g_dvae_compute_mode == 1);
+  if (bf) bk = 32;                       // the bf16 kernel has one k-tile; ragged tails are zero-filled
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
   p.split_k = (p.K + kps - 1) / kps;
@@ -474,6 +529,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
   bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256);
   if (big_env >= 0) big = (big_env != 0) && (bk == 32);
+  if (bf) big = false;
   const int bm = big ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
   // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
@@ -495,6 +551,13 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
 }
 
 }  // namespace
+
+DVAE_API int dvae_set_compute_mode(int mode) {
+  if (mode != 0 && mode != 1) return DVAE_EINVAL;
+  g_dvae_compute_mode = mode;
+  return DVAE_OK;
+}
+DVAE_API int dvae_get_compute_mode(void) { return g_dvae_compute_mode; }
 
 DVAE_API int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int act,

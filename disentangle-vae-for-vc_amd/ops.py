@@ -130,6 +130,35 @@ def _tiles(m, n):
     return ((m + 127) // 128) * ((n + 127) // 128)
 
 
+# ----------------------------------------------------------------------------- compute mode
+def set_compute_dtype(name: str):
+    """"fp32" (default; BASELINE configs[1]/[3]) or "bf16" (configs[2]/[4]): operands of every contraction — Linear,
+    Conv1d, LSTM input projection and recurrence, all weight gradients — are rounded to bf16 on their way into the
+    matrix cores and accumulated in fp32; tensors in HBM, BatchNorm, gates, losses, master weights and Adam stay fp32."""
+    modes = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+    if name not in modes:
+        raise ValueError(f"compute dtype {name!r}: expected 'fp32' or 'bf16'")
+    check(lib().dvae_set_compute_mode(modes[name]), "dvae_set_compute_mode")
+
+
+def get_compute_dtype() -> str:
+    return "bf16" if lib().dvae_get_compute_mode() == 1 else "fp32"
+
+
+class compute_dtype:
+    """Context manager: `with ops.compute_dtype("bf16"): ...`"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = get_compute_dtype()
+        set_compute_dtype(self.name)
+
+    def __exit__(self, *exc):
+        set_compute_dtype(self.prev)
+
+
 # ----------------------------------------------------------------------------- raw launches
 def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi=EPI_STORE, split_k=1):
     check(lib().dvae_gemm_f32(ptr(A), ptr(B), ptr(Cout), ptr(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),

@@ -43,6 +43,14 @@ extern "C" {
 #define DVAE_EPI_ATOMIC 2 /* C += result with global_atomic_add_f32 (split-K allowed) */
 
 int dvae_version(void);
+
+/* ---- compute mode of every contraction entry point below (process-wide, like torch's matmul precision):
+ * 0 (default) fp32 operands on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 — BASELINE configs[1], [3];
+ * 1 bf16 operands (fp32 tensors in HBM, rounded to nearest-even while staged into LDS / packed) with fp32
+ *   accumulation on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 — BASELINE configs[2], [4] ("bf16 compute").
+ * Everything that is not a contraction (BatchNorm, gates, losses, Adam, master weights) stays fp32 in both modes. */
+int dvae_set_compute_mode(int mode);
+int dvae_get_compute_mode(void);
 /* hipError_t of the last failed launch (0 if none) */
 int dvae_last_hip_error(void);
 
