@@ -27,6 +27,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def algorithmic_flops_per_pair(T):
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
     ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="compute mode of the contractions; f32 = BASELINE configs[1] (the headline), bf16 = "
+                         "configs[2]/[4] semantics (use with --batch 128 --frames 256 for configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph (N=1 only)")
@@ -119,6 +123,9 @@ def main():
     from dvae_amd.data import SyntheticPairs
 
     B, T = args.batch, args.frames
+    bf16 = args.dtype == "bf16"
+    if bf16:
+        ops.set_compute_dtype("bf16")
     torch.manual_seed(1234)
     w = dvae_amd.ConvolutionalMulVAE("VCTK", T, 80, 32, 1e-4, 0.01, 500, False, batch_size=B, speaker_size=4,
                                      device=dev, latent_dim=32, mse_cof=10, kl_cof=10)
@@ -173,14 +180,16 @@ def main():
         try:   # HBM-side bytes per launch of this kernel family from the committed PMC passes (not collectable live)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pm = json.load(f)
-            if B == 64 and T == 128:
+            if B == 64 and T == 128 and not bf16:
                 traffic, traffic_src = pm["gemm_f32_kernel"]["traffic_bytes_per_launch"], pm["source"]
         except Exception:
             pass
         if ms > 0:
             ach = flops / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+            peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel (" + ("v_mfma_f32_32x32x16_bf16, fp32 tensors in HBM"
+                                                                       if bf16 else "v_mfma_f32_32x32x2_f32") + ")",
+                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": traffic, "traffic_unit": "bytes per launch (L2<->fabric, PMC)",
                     "traffic_source": traffic_src, "launches_per_step": launches / prof_steps,
                     "kernel_ms_per_step": ms / prof_steps, "avg_launch_us": 1e3 * ms / max(1, launches),
@@ -196,12 +205,14 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         step_flops = algorithmic_flops_per_pair(T) * B
-        out = {"metric": "utterances/sec (B=64, 80-mel, T=128) train step", "value": value, "unit": "utterances/sec",
+        out = {"metric": f"utterances/sec (B={B}, 80-mel, T={T}) train step", "value": value, "unit": "utterances/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic U[0,1) mel pairs, random-init weights",
-               "config": {"workload": f"configs[1]: fp32 train step, B={B} pairs/GPU, 80-mel, T={T}, "
-                                      "10 synthetic speakers, speaker_size=4, latent=32, Adam lr=1e-4",
+               "config": {"workload": (f"configs[2]-style: bf16-compute train step (bf16 MFMA operands, fp32 accumulate, "
+                                       f"fp32 tensors / master weights / Adam), B={B} pairs/GPU, 80-mel, T={T}, "
+                                       if bf16 else f"configs[1]: fp32 train step, B={B} pairs/GPU, 80-mel, T={T}, ")
+                                      + "10 synthetic speakers, speaker_size=4, latent=32, Adam lr=1e-4",
                           "global_batch": world * B, "frames": T, "parallelism": f"dp{world}",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "params": sum(p.numel() for p in w.model.parameters())},

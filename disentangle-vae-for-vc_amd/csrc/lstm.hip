@@ -21,6 +21,7 @@
 // entry so their latency hides under the contraction.  W_hh is re-read every frame and stays
 // L2/MALL resident; the blockIdx -> tile map keeps all row-tiles of one weight slice on one XCD.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -40,6 +41,7 @@ struct StepArgs {
   StepDir d[2];
   int T, N, H;
   int64_t ldh;
+  int bf16;  // packed weights are bf16 fragments (dvae_lstm_pack_w_bf16): bf16 operands, fp32 accumulation
   int dbg;   // experiment bits (DVAE_LSTM_DBG): 1 skip in-loop global loads, 2 skip MFMAs, 4 naive block map
 };
 
@@ -611,10 +613,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int st
 // Eight waves = 4 gates (fwd) / k-quarters (bwd) x 2 k-halves give both: two waves per SIMD AND the
 // small traffic; the k-halves meet in the LDS reduction that the epilogue needs anyway.
 // =====================================================================================================
-template <int MT, int KR>
+// BF: bf16 compute mode -- W_hh packed as bf16 in the fragment order of v_mfma_f32_16x16x32_bf16 (lane (r, q) holds
+// k = 32c + 8q + j, j = 0..7, of gate column r: still one 1-KiB burst per wave per chunk, now 32 deep), the h tile
+// rounded to bf16 while it is staged into LDS (272-B rows: conflict-free ds_read_b128), fp32 accumulation and gates.
+template <int MT, int KR, bool BF = false>
 __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int step, int n_j, int n_m) {
   constexpr int NW = 8;
-  constexpr int NS = KR / 16, LDA = KR + 4;
+  constexpr int KC = BF ? 32 : 16;                 // k depth of one packed chunk
+  constexpr int NS = KR / KC, LDA = KR + (BF ? 8 : 4);
+  using lds_t = typename std::conditional<BF, __bf16, float>::type;
   constexpr int NST = MT * KR / 64;     // float4 per thread per round (activation stage, both k-halves together)
   const StepDir& d = a.d[blockIdx.z];
   const int H = a.H, N = a.N;
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
   const int gate = wave & 3, kh = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) float As[2][2][16 * MT * LDA];   // [buffer][k-half]
+  __shared__ __attribute__((aligned(16))) lds_t As[2][2][16 * MT * LDA];   // [buffer][k-half]
   __shared__ float sm[NW][MT * 16][17];
 
   // epilogue operands: one (segment, unit) element per thread
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
     const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
     const int nr = H / KR / 2, last = nr - 1;           // rounds per k-half
     // packed W: [(gate*n_j + jb)][k-chunk of 16][lane][4]; this wave's chunks start at kh*(H/32)
-    const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / 16) + (int64_t)kh * (H / 32)) * 256 + lane * 4;
+    const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / KC) + (int64_t)kh * (H / KC / 2)) * 256 + lane * 4;
     // staging: threads 0..255 stage k-half 0, 256..511 k-half 1; 16 lanes per 256-B row segment
     const int skh = tid >> 8, srow = (tid & 255) >> 4, sc4 = tid & 15;
     auto loadW = [&](f32x4 (&w)[NS], int rd) {
@@ -668,11 +675,25 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int q = 0; q < KR / 64; ++q)
-          *reinterpret_cast<f32x4*>(&As[buf][skh][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) = st[i * (KR / 64) + q];
+        for (int q = 0; q < KR / 64; ++q) {
+          if constexpr (BF)
+            *reinterpret_cast<bf16x4*>(&As[buf][skh][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) =
+                __builtin_convertvector(st[i * (KR / 64) + q], bf16x4);
+          else
+            *reinterpret_cast<f32x4*>(&As[buf][skh][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) = st[i * (KR / 64) + q];
+        }
     };
     auto compute = [&](int buf, f32x4 (&w)[NS]) {
-      const float* __restrict__ al = &As[buf][kh][r * LDA + 4 * kq];
+      if constexpr (BF) {
+        const lds_t* __restrict__ al = &As[buf][kh][r * LDA + 8 * kq];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                *reinterpret_cast<const bf16x8*>(al + mt * 16 * LDA + 32 * s), __builtin_bit_cast(bf16x8, w[s]), acc[mt], 0, 0, 0);
+      } else {
+      const lds_t* __restrict__ al = &As[buf][kh][r * LDA + 4 * kq];
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         f32x4 av[MT];
@@ -683,6 +704,7 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w[s][e], acc[mt], 0, 0, 0);
+      }
       }
     };
     f32x4 wA[NS], wB[NS], sA[NST], sB[NST];
@@ -744,10 +766,12 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
 // (An "all loads of the frame in flight up front" variant -- 217 VGPRs, no spills -- measured 17.1 us/frame against
 // 15.9 us for the just-in-time prefetch above: flooding the L2 queues delays the first tile of every workgroup.)
 
-template <int MT, int KR>
+template <int MT, int KR, bool BF = false>
 __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int step, int n_j, int n_m) {
   constexpr int NW = 8;
-  constexpr int NS = KR / 16, LDA = KR + 4;
+  constexpr int KC = BF ? 32 : 16;
+  constexpr int NS = KR / KC, LDA = KR + (BF ? 8 : 4);
+  using lds_t = typename std::conditional<BF, __bf16, float>::type;
   const StepDir& d = a.d[blockIdx.z];
   const int H = a.H, N = a.N;
   const int fstep = a.T - 1 - step;
@@ -761,7 +785,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
   const int quarter = wave >> 1, part = wave & 1;      // k range: [quarter*H + part*H/2, +H/2)
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) float Ast[NW][2 * 16 * MT * LDA];   // per wave, two buffers
+  __shared__ __attribute__((aligned(16))) lds_t Ast[NW][2 * 16 * MT * LDA];   // per wave, two buffers
   __shared__ float sm[NW][MT * 16][17];
 
   const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
@@ -783,8 +807,8 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
     const int H4 = 4 * H;
     const int koff = quarter * H + part * (H / 2);
     // packed W^T: [(jb*4 + quarter)][k-chunk of 16 inside the quarter][lane][4]
-    const float* __restrict__ bpk = d.wp + (((int64_t)jb * 4 + quarter) * (H / 16) + (int64_t)part * (H / 32)) * 256 + lane * 4;
-    float* __restrict__ stg = &Ast[wave][0];
+    const float* __restrict__ bpk = d.wp + (((int64_t)jb * 4 + quarter) * (H / KC) + (int64_t)part * (H / KC / 2)) * 256 + lane * 4;
+    lds_t* __restrict__ stg = &Ast[wave][0];
     const int lrow = lane >> 4, lc4 = lane & 15;
     const float* arow[4 * MT];
 #pragma unroll
@@ -803,15 +827,29 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
 #pragma unroll
       for (int i = 0; i < 4 * MT; ++i)
 #pragma unroll
-        for (int q = 0; q < KR / 64; ++q)
-          *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
+        for (int q = 0; q < KR / 64; ++q) {
+          if constexpr (BF)
+            *reinterpret_cast<bf16x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) =
+                __builtin_convertvector(st[i][q], bf16x4);
+          else
+            *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
+        }
     };
     auto loadB = [&](f32x4 (&b)[NS], int rd) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS + s) * 256);
     };
     auto compute = [&](int buf, f32x4 (&b)[NS]) {
-      const float* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 4 * kq;
+      if constexpr (BF) {
+        const lds_t* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 8 * kq;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                *reinterpret_cast<const bf16x8*>(al + mt * 16 * LDA + 32 * s), __builtin_bit_cast(bf16x8, b[s]), acc[mt], 0, 0, 0);
+      } else {
+      const lds_t* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 4 * kq;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         f32x4 av[MT];
@@ -822,6 +860,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int st
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], b[s][e], acc[mt], 0, 0, 0);
+      }
       }
     };
     f32x4 bA[NS], bB[NS], sA[4 * MT][KR / 64], sB[4 * MT][KR / 64];
@@ -1103,6 +1142,36 @@ __global__ __launch_bounds__(256) void lstm_pack_w_kernel(const float* __restric
   }
 }
 
+// bf16 fragment packing (v_mfma_f32_16x16x32_bf16): 32-deep chunks, lane (r, q) holds k = 32kc + 8q + j, j = 0..7.
+// fwd: [(g*n_j+jb)][kc][lane][8] <- W[g*H + jb*16 + r][32kc + 8q + j];  bwd: [(jb*4+w)][kc][lane][8] <- W[w*H + 32kc + 8q + j][jb*16 + r]
+__global__ __launch_bounds__(256) void lstm_pack_w_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ pf,
+                                                               __bf16* __restrict__ pb, int H) {
+  const int n_j = H / 16, nkc = H / 32;
+  const int64_t total = (int64_t)4 * n_j * nkc * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const int64_t c = i >> 6;
+    const int kc = (int)(c % nkc);
+    const int64_t gj = c / nkc;
+    const int r = lane & 15, q = lane >> 4;
+    if (pf) {
+      const int g = (int)(gj / n_j), jb = (int)(gj % n_j);
+      const float* src = W + ((int64_t)g * H + jb * 16 + r) * H + kc * 32 + 8 * q;
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[e];
+      reinterpret_cast<bf16x8*>(pf)[i] = v;
+    }
+    if (pb) {
+      const int jb = (int)(gj / 4), w = (int)(gj % 4);
+      bf16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)W[((int64_t)w * H + kc * 32 + 8 * q + e) * H + jb * 16 + r];
+      reinterpret_cast<bf16x8*>(pb)[i] = v;
+    }
+  }
+}
+
 int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, bool bwd) {
   if (!dirs || ndir < 1 || ndir > 2 || T < 1 || N < 1 || H < 64 || (H & 63) || (ldh & 3)) return DVAE_EINVAL;
   for (int i = 0; i < ndir; ++i) {
@@ -1114,6 +1183,10 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
     a.d[i].dh_out = s.dh_out; a.d[i].dgates = s.dgates; a.d[i].dc = s.dc_ws; a.d[i].reverse = s.reverse;
   }
   if (ndir == 1) a.d[1] = a.d[0];
+  a.bf16 = dirs[0].packed_bf16 ? 1 : 0;
+  for (int i = 0; i < ndir; ++i)
+    if ((dirs[i].packed_bf16 ? 1 : 0) != a.bf16 || (a.bf16 && !dirs[i].w_packed)) return DVAE_EINVAL;
+  if (a.bf16 && (H % 512)) return DVAE_EINVAL;        // bf16 frame kernels exist for H = 512, 1024, ...
   a.T = T; a.N = N; a.H = H; a.ldh = ldh;
   static const int dbg_env = getenv("DVAE_LSTM_DBG") ? atoi(getenv("DVAE_LSTM_DBG")) : 0;
   a.dbg = dbg_env;
@@ -1148,6 +1221,16 @@ DVAE_API int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packe
   return dvae_check_launch();
 }
 
+DVAE_API int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream) {
+  if (!w_hh || (!packed_fwd && !packed_bwd) || H < 512 || (H % 512)) return DVAE_EINVAL;
+  const int64_t total = (int64_t)4 * (H / 16) * (H / 32) * 64;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(lstm_pack_w_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hh,
+                     (__bf16*)packed_fwd, (__bf16*)packed_bwd, H);
+  return dvae_check_launch();
+}
+
 DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
                                void* stream) {
   StepArgs a{};
@@ -1172,7 +1255,10 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
     for (int step = 0; step < T; ++step) {
-      if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      if (a.bf16) {
+        if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
+        else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      } else if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
       else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
     }
     return dvae_check_launch();
@@ -1215,7 +1301,10 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
     for (int step = 0; step < T; ++step) {
-      if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      if (a.bf16) {
+        if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
+        else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      } else if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
       else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
     }
     return dvae_check_launch();

@@ -347,6 +347,9 @@ class LstmLayerFn(torch.autograd.Function):
         h_out = torch.empty((R, ldh), device=dev, dtype=torch.float32)
         params = [(w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r)][:ndir]
         dirs = (_lib.LstmDir * ndir)()
+        # bf16 compute mode: the recurrence runs on bf16 fragments where bf16 frame kernels exist (H = 512, 1024);
+        # the H = 64 encoder recurrence (3 % of the FLOPs, weights resident in registers) stays fp32
+        bf = 1 if (get_compute_dtype() == "bf16" and H % 512 == 0) else 0
         gates, cells, packs_b, keep = [], [], [], []
         for d, (wi, wh, bi, bh) in enumerate(params):
             g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
@@ -355,7 +358,10 @@ class LstmLayerFn(torch.autograd.Function):
             # W_hh re-packed in MFMA fragment order (forward copy used now, backward copy saved)
             wp_f = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
             wp_b = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
-            check(L.dvae_lstm_pack_w(ptr(wh), ptr(wp_f), ptr(wp_b), H, st), "dvae_lstm_pack_w")
+            if bf:
+                check(L.dvae_lstm_pack_w_bf16(ptr(wh), ptr(wp_f), ptr(wp_b), H, st), "dvae_lstm_pack_w_bf16")
+            else:
+                check(L.dvae_lstm_pack_w(ptr(wh), ptr(wp_f), ptr(wp_b), H, st), "dvae_lstm_pack_w")
             gates.append(g)
             cells.append(c)
             packs_b.append(wp_b)
@@ -363,18 +369,19 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].gates = ptr(g)
             dirs[d].w_hh = ptr(wh)
             dirs[d].w_packed = ptr(wp_f)
+            dirs[d].packed_bf16 = bf
             dirs[d].h_out = h_out.data_ptr() + 4 * d * H
             dirs[d].c_all = ptr(c)
             dirs[d].reverse = d
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
         ctx.save_for_backward(x, h_out, *gates, *cells, *packs_b, *[p for ps in params for p in ps])
-        ctx.cfg = (T, N, H, ndir)
+        ctx.cfg = (T, N, H, ndir, bf)
         del keep
         return h_out
 
     @staticmethod
     def backward(ctx, dh):
-        T, N, H, ndir = ctx.cfg
+        T, N, H, ndir, bf = ctx.cfg
         sv = ctx.saved_tensors
         x, h_out = sv[0], sv[1]
         gates = sv[2:2 + ndir]
@@ -400,6 +407,7 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].gates = ptr(gates[d])
             dirs[d].w_hh = ptr(wht)
             dirs[d].w_packed = ptr(packs_b[d])
+            dirs[d].packed_bf16 = bf
             dirs[d].c_all = ptr(cells[d])
             dirs[d].dh_out = dh.data_ptr() + 4 * d * H
             dirs[d].dgates = ptr(dg)

@@ -123,10 +123,13 @@ typedef struct {
   const float* w_packed; /* optional: weights re-packed in MFMA fragment order by dvae_lstm_pack_w (fwd: packed_fwd,
                             bwd: packed_bwd); when given, the faster 1-KiB-burst frame kernels are used */
   int reverse;        /* 0: t = 0..T-1, 1: t = T-1..0 */
-  int pad_;
+  int packed_bf16;    /* 0: w_packed from dvae_lstm_pack_w (fp32 recurrence); 1: from dvae_lstm_pack_w_bf16 (bf16
+                         operands / fp32 accumulation on v_mfma_f32_16x16x32_bf16; H must be a multiple of 512) */
 } dvae_lstm_dir_t;
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
+/* bf16 compute mode: the same copies rounded to bf16 (each 4H*H bf16 values = 2*4H*H bytes) */
+int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream);
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 

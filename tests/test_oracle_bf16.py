@@ -1,0 +1,45 @@
+"""CPU checks of the bf16-mode oracle (oracle/bf16_ref.py): with the rounding switched off it must coincide with the
+pinned fp32 oracle (so its hand-written LSTM / conv / linear restatement is the same network, forward and backward);
+with the rounding on it must sit a bf16-sized distance away."""
+import numpy as np
+import torch
+
+from oracle import bf16_ref
+from oracle.dvae_ref import RefDVAE, loss_gvae2
+from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+
+
+def _run(cls, B=2, T=64):
+    torch.manual_seed(0)
+    m = cls(4, 32, T)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    m.train()
+    x1, x2 = synthetic_pair(B, T, 11)
+    losses = loss_gvae2(x1, x2, m(x1, x2, synthetic_eps(B, seed=12)), B)
+    losses[0].backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    return [float(l) for l in losses], grads
+
+
+def test_without_rounding_it_is_the_fp32_oracle(monkeypatch):
+    monkeypatch.setattr(bf16_ref, "r16", lambda t: t)
+    l_ref, g_ref = _run(RefDVAE)
+    l_got, g_got = _run(bf16_ref.RefDVAEBf16)
+    for a, b in zip(l_got, l_ref):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (a, b)
+    for k in g_ref:
+        if ".0.conv.bias" in k or k.endswith(".0.bias"):       # pre-BatchNorm conv biases: pure round-off
+            continue
+        d = float((g_got[k] - g_ref[k]).norm()) / max(1e-12, float(g_ref[k].norm()))
+        assert d <= 2e-3, (k, d)
+
+
+def test_with_rounding_it_is_bf16_close():
+    l_ref, g_ref = _run(RefDVAE)
+    l_got, g_got = _run(bf16_ref.RefDVAEBf16)
+    d = [abs(a - b) / max(1.0, abs(b)) for a, b in zip(l_got, l_ref)]
+    assert 1e-6 < max(d) < 5e-2, d
+    k = "dec_lstm2.weight_hh_l1"
+    rel = float((g_got[k] - g_ref[k]).norm()) / float(g_ref[k].norm())
+    assert 1e-4 < rel < 0.2, rel
+    assert bf16_ref.r16(torch.tensor([1.00390625, 1.005859375])).tolist() == [1.0, 1.0078125]   # ties-to-even, RNE
