@@ -21,7 +21,8 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
-                ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_bf16", i32)]
+                ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_bf16", i32),
+                ("step_shift", i32), ("pad_", i32)]
 
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
@@ -42,6 +43,8 @@ SIGNATURES = {
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_seq_fwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_bwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
+    "dvae_lstm_seq_fwd_range": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, i32, i32, vp]),
+    "dvae_lstm_seq_bwd_range": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, i32, i32, vp]),
     "dvae_latent_fwd": (i32, [vp] * 9 + [i32, i32, i32, vp]),
     "dvae_latent_bwd": (i32, [vp] * 11 + [i32, i32, i32, vp]),
     "dvae_kl_fwd": (i32, [vp, vp, vp, i64, f32, vp]),

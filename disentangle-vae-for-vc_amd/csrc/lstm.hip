@@ -36,6 +36,8 @@ struct StepDir {
   float* dgates;        // [T,N,4H]
   float* dc;            // [N,H]
   int reverse;
+  int shift;            // this entry runs its (local) step s during the launch of global step s + shift (v5 kernels):
+                        // two STACKED layers ride in one launch, layer 2 a chunk of frames behind layer 1
 };
 struct StepArgs {
   StepDir d[2];
@@ -617,13 +619,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int st
 // k = 32c + 8q + j, j = 0..7, of gate column r: still one 1-KiB burst per wave per chunk, now 32 deep), the h tile
 // rounded to bf16 while it is staged into LDS (272-B rows: conflict-free ds_read_b128), fp32 accumulation and gates.
 template <int MT, int KR, bool BF = false>
-__global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int step, int n_j, int n_m) {
+__global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
   constexpr int NW = 8;
   constexpr int KC = BF ? 32 : 16;                 // k depth of one packed chunk
   constexpr int NS = KR / KC, LDA = KR + (BF ? 8 : 4);
   using lds_t = typename std::conditional<BF, __bf16, float>::type;
   constexpr int NST = MT * KR / 64;     // float4 per thread per round (activation stage, both k-halves together)
   const StepDir& d = a.d[blockIdx.z];
+  const int step = gstep - d.shift;
+  if (step < 0 || step >= a.T) return;        // this entry has no frame in this launch (uniform per workgroup)
   const int H = a.H, N = a.N;
   const int t = d.reverse ? (a.T - 1 - step) : step;
   const int tp = d.reverse ? t + 1 : t - 1;
@@ -635,8 +639,12 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
   const int gate = wave & 3, kh = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) lds_t As[2][2][16 * MT * LDA];   // [buffer][k-half]
-  __shared__ float sm[NW][MT * 16][17];
+  // h tiles [buffer][k-half][16*MT rows][LDA]; the gate tiles of the epilogue (sm) reuse the same bytes once the last
+  // round has been computed (every round ends with a workgroup barrier), so two workgroups fit in a CU's 160 KB
+  constexpr int AS_BYTES = 2 * 2 * 16 * MT * LDA * (int)sizeof(lds_t), SM_BYTES = NW * MT * 16 * 17 * 4;
+  __shared__ __attribute__((aligned(16))) char lds_raw[AS_BYTES > SM_BYTES ? AS_BYTES : SM_BYTES];
+  lds_t (*As)[2][16 * MT * LDA] = reinterpret_cast<lds_t (*)[2][16 * MT * LDA]>(lds_raw);
+  float (*sm)[MT * 16][17] = reinterpret_cast<float (*)[MT * 16][17]>(lds_raw);
 
   // epilogue operands: one (segment, unit) element per thread
   float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
@@ -767,12 +775,14 @@ __global__ __launch_bounds__(512) void lstm_step_fwd_v5(const StepArgs a, int st
 // 15.9 us for the just-in-time prefetch above: flooding the L2 queues delays the first tile of every workgroup.)
 
 template <int MT, int KR, bool BF = false>
-__global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int step, int n_j, int n_m) {
+__global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
   constexpr int NW = 8;
   constexpr int KC = BF ? 32 : 16;
   constexpr int NS = KR / KC, LDA = KR + (BF ? 8 : 4);
   using lds_t = typename std::conditional<BF, __bf16, float>::type;
   const StepDir& d = a.d[blockIdx.z];
+  const int step = gstep - d.shift;
+  if (step < 0 || step >= a.T) return;
   const int H = a.H, N = a.N;
   const int fstep = a.T - 1 - step;
   const int t = d.reverse ? (a.T - 1 - fstep) : fstep;
@@ -1181,6 +1191,8 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
     if ((((uintptr_t)s.w_hh) | ((uintptr_t)s.h_out) | ((uintptr_t)s.dgates)) & 15) return DVAE_EINVAL;
     a.d[i].gates = s.gates; a.d[i].w = s.w_hh; a.d[i].wp = s.w_packed; a.d[i].h_out = s.h_out; a.d[i].c_all = s.c_all;
     a.d[i].dh_out = s.dh_out; a.d[i].dgates = s.dgates; a.d[i].dc = s.dc_ws; a.d[i].reverse = s.reverse;
+    a.d[i].shift = s.step_shift;
+    if (s.step_shift < 0) return DVAE_EINVAL;
   }
   if (ndir == 1) a.d[1] = a.d[0];
   a.bf16 = dirs[0].packed_bf16 ? 1 : 0;
@@ -1231,19 +1243,28 @@ DVAE_API int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* pa
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
-                               void* stream) {
+namespace {
+// global launch steps [g0, g1): entry i runs its local step g - step_shift when that lies in [0, T)
+int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, int g0, int g1,
+                       void* stream) {
   StepArgs a{};
   int rc = fill_args(a, dirs, ndir, T, N, H, ldh, false);
   if (rc) return rc;
+  const bool shifted = a.d[0].shift != 0 || (ndir == 2 && a.d[1].shift != 0);
+  const bool whole = (g0 == 0 && g1 == T && !shifted);
+  if (g0 < 0 || g1 < g0) return DVAE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int mt = pick_mt(N, H, ndir);
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
-  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
+  int64_t frames = 0;   // (entry, step) pairs of this call that carry a recurrent product
+  for (int i = 0; i < ndir; ++i)
+    for (int g = g0; g < g1; ++g) frames += (g - a.d[i].shift > 0 && g - a.d[i].shift < T) ? 1 : 0;
+  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)frames);
   static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
   const bool big = (H % 256) == 0;
   if (H == 64 && ver >= 4) {   // whole sequence in one launch (row-split, no inter-workgroup dependency)
+    if (!whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_fwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
@@ -1254,15 +1275,21 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     const int mt5 = (n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1;
     const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
-    for (int step = 0; step < T; ++step) {
+    // stacked entries (a shift): the 64-deep variant keeps TWO workgroups resident per CU, so the two layers' frames
+    // really overlap (one's load latency under the other's MFMAs) instead of alternating
+    static const int kr_env = getenv("DVAE_LSTM_KR") ? atoi(getenv("DVAE_LSTM_KR")) : 0;
+    const bool kr64 = kr_env ? (kr_env == 64) : shifted;
+    for (int step = g0; step < g1; ++step) {
       if (a.bf16) {
         if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
         else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
-      } else if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      } else if (mt5 == 2 && kr64) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+      else if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
       else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
     }
     return dvae_check_launch();
   }
+  if (!whole) return DVAE_EINVAL;          // step ranges / stacked entries exist for the eight-wave kernels only
   for (int step = 0; step < T; ++step) {
     if (v4) {
       if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_fwd_v4<2, 256>), grid, block, 0, s, a, step, n_j, n_m);
@@ -1277,20 +1304,38 @@ DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
   }
   return dvae_check_launch();
 }
+}  // namespace
 
-DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
-                               void* stream) {
+DVAE_API int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream) {
+  return lstm_seq_fwd_range(dirs, ndir, T, N, H, ldh, 0, T, stream);
+}
+DVAE_API int dvae_lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
+                                     int step_begin, int step_end, void* stream) {
+  return lstm_seq_fwd_range(dirs, ndir, T, N, H, ldh, step_begin, step_end, stream);
+}
+
+namespace {
+// global launch steps [g0, g1): entry i runs its local step g - step_shift when that lies in [0, T)
+int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, int g0, int g1,
+                       void* stream) {
   StepArgs a{};
   int rc = fill_args(a, dirs, ndir, T, N, H, ldh, true);
   if (rc) return rc;
+  const bool shifted = a.d[0].shift != 0 || (ndir == 2 && a.d[1].shift != 0);
+  const bool whole = (g0 == 0 && g1 == T && !shifted);
+  if (g0 < 0 || g1 < g0) return DVAE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int mt = pick_mt(N, H, ndir);
   const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
   dim3 grid(n_j * n_m, 1, ndir), block(256);
-  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (T - 1) * ndir);
+  int64_t frames = 0;   // (entry, step) pairs of this call that carry a recurrent product
+  for (int i = 0; i < ndir; ++i)
+    for (int g = g0; g < g1; ++g) frames += (g - a.d[i].shift > 0 && g - a.d[i].shift < T) ? 1 : 0;
+  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)frames);
   static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
   const bool big = (H % 128) == 0;
   if (H == 64 && ver >= 4) {
+    if (!whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_bwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
@@ -1300,7 +1345,7 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     const int mt5 = (n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1;
     const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
-    for (int step = 0; step < T; ++step) {
+    for (int step = g0; step < g1; ++step) {
       if (a.bf16) {
         if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
         else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
@@ -1309,6 +1354,7 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     }
     return dvae_check_launch();
   }
+  if (!whole) return DVAE_EINVAL;          // step ranges / stacked entries exist for the eight-wave kernels only
   for (int step = 0; step < T; ++step) {
     if (v4) {
       if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_bwd_v4<2, 128>), grid, block, 0, s, a, step, n_j, n_m);
@@ -1322,4 +1368,13 @@ DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int
     }
   }
   return dvae_check_launch();
+}
+}  // namespace
+
+DVAE_API int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream) {
+  return lstm_seq_bwd_range(dirs, ndir, T, N, H, ldh, 0, T, stream);
+}
+DVAE_API int dvae_lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
+                                     int step_begin, int step_end, void* stream) {
+  return lstm_seq_bwd_range(dirs, ndir, T, N, H, ldh, step_begin, step_end, stream);
 }

@@ -26,7 +26,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..ops import (ACT_NONE, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, KlFn, L1SumFn, LatentFn, LinearFn,
-                   LstmLayerFn, Permute102Fn, mel_to_frames)
+                   LstmLayerFn, LstmStack2Fn, Permute102Fn, mel_to_frames)
 from ..optim import FlatAdam
 from .variational_base_vae import VariationalBaseModelVAE
 
@@ -222,6 +222,9 @@ class DisentangledVAE(nn.Module):
             raise ValueError(f"expected [B, {N_MEL}, {self.n_frames}] mel segments, got {tuple(x.shape)}")
 
     def _lstm(self, mod, x, T, n_seg):
+        if LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
+            # two stacked layers of equal width share their frame launches (ops.LstmStack2Fn)
+            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4])
         for l in range(mod.num_layers):
             x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l))
         return x

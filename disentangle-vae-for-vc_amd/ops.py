@@ -443,6 +443,110 @@ class LstmLayerFn(torch.autograd.Function):
         return (dx,) + (None,) * 10
 
 
+class LstmStack2Fn(torch.autograd.Function):
+    """Two STACKED unidirectional LSTM layers of equal hidden size sharing their frame launches (dec_lstm2,
+    disentangled_vae.py:193/:246; H = 1024): the sequence is cut into chunks of `CHUNK` frames; while layer 1 runs
+    chunk c+1, layer 2 runs chunk c in the SAME launches (dvae_lstm_seq_*_range with step_shift), after layer 1's
+    chunk-c outputs went through layer 2's input projection.  Same arithmetic per frame as two LstmLayerFn calls —
+    only the launch schedule changes: T + CHUNK launches of 2x the workgroups instead of 2T, two workgroups resident
+    per CU so one layer's load latency hides under the other's MFMAs.  Backward mirrors it (layer 2 ahead)."""
+
+    CHUNK = int(os.environ.get("DVAE_LSTM_CHUNK", "-1"))      # frames per chunk; -1: two chunks (T/2), 0: off
+    # measured at T = 128 (ms/step): unstacked 34.35, chunks of 16 / 32 / 64 frames 34.25 / 34.06 / 34.03
+    # (measured alternatives: the trailing layer on a second HIP stream inside the graph, 35.0 ms/step against 34.0
+    # fused and 34.2 unstacked; an idle skew of the trailing layer's workgroups: slower by exactly the skew)
+
+    @staticmethod
+    def chunk(T):
+        return T // 2 if LstmStack2Fn.CHUNK < 0 else LstmStack2Fn.CHUNK
+
+    @staticmethod
+    def usable(T, H, layers, bidirectional):
+        Tc = LstmStack2Fn.chunk(T)
+        return layers == 2 and not bidirectional and H % 512 == 0 and Tc > 0 and T % Tc == 0 and T // Tc >= 2
+
+    @staticmethod
+    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2):
+        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
+        L, st, dev = lib(), stream(), x.device
+        R, In = x.shape
+        H = w_hh1.shape[1]
+        Tc = LstmStack2Fn.chunk(T)
+        bf = 1 if get_compute_dtype() == "bf16" else 0
+        f32 = dict(device=dev, dtype=torch.float32)
+        g1, g2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
+        c1, c2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
+        h1, h2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
+        gemm(x, w_ih1, g1, b_ih1 + b_hh1, R, 4 * H, In, In, In, 4 * H, True, True)
+        bias2 = b_ih2 + b_hh2
+        packs = []
+        for wh in (w_hh1, w_hh2):
+            pf, pb = torch.empty((4 * H * H,), **f32), torch.empty((4 * H * H,), **f32)
+            check((L.dvae_lstm_pack_w_bf16 if bf else L.dvae_lstm_pack_w)(ptr(wh), ptr(pf), ptr(pb), H, st), "lstm_pack_w")
+            packs.append((pf, pb))
+        dirs = (_lib.LstmDir * 2)()
+        for d, (g, wh, h, c) in enumerate(((g1, w_hh1, h1, c1), (g2, w_hh2, h2, c2))):
+            dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed = ptr(g), ptr(wh), ptr(packs[d][0])
+            dirs[d].h_out, dirs[d].c_all = ptr(h), ptr(c)
+            dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
+        rows = Tc * N
+        for c0 in range(0, T + Tc, Tc):
+            if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
+                r0 = (c0 - Tc) * N
+                check(L.dvae_gemm_f32(h1.data_ptr() + 4 * r0 * H, ptr(w_ih2), g2.data_ptr() + 4 * r0 * 4 * H, ptr(bias2),
+                                      rows, 4 * H, H, H, H, 4 * H, 1, 1, ACT_NONE, EPI_STORE, 1, st), "dvae_gemm_f32")
+            check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
+        ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, packs[0][1], packs[1][1], w_ih1, w_hh1, b_ih1, b_hh1,
+                              w_ih2, w_hh2, b_ih2, b_hh2)
+        ctx.cfg = (T, N, H, bf)
+        return h2
+
+    @staticmethod
+    def backward(ctx, dh2):
+        T, N, H, bf = ctx.cfg
+        (x, h1, h2, g1, g2, c1, c2, pb1, pb2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2) = ctx.saved_tensors
+        L, st, dev = lib(), stream(), x.device
+        R, In = x.shape
+        Tc = LstmStack2Fn.chunk(T)
+        f32 = dict(device=dev, dtype=torch.float32)
+        dh2 = dh2.contiguous()
+        dg1, dg2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
+        dh1 = torch.empty((R, H), **f32)                   # gradient w.r.t. layer 1's outputs = layer 2's dgrad
+        dcs = [torch.empty((N, H), **f32) for _ in range(2)]
+        whts = [transpose2d(w_hh1), transpose2d(w_hh2)]
+        # backward step s handles frame T-1-s.  Entry 0 = layer 2 (ahead), entry 1 = layer 1 (a chunk behind).
+        dirs = (_lib.LstmDir * 2)()
+        for d, (g, wht, pb, c, dho, dg) in enumerate(((g2, whts[1], pb2, c2, dh2, dg2), (g1, whts[0], pb1, c1, dh1, dg1))):
+            dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed, dirs[d].c_all = ptr(g), ptr(wht), ptr(pb), ptr(c)
+            dirs[d].dh_out, dirs[d].dgates, dirs[d].dc_ws = ptr(dho), ptr(dg), ptr(dcs[d])
+            dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
+        rows = Tc * N
+        for c0 in range(0, T + Tc, Tc):
+            if c0 >= Tc:    # layer 2 finished backward steps [c0-Tc, c0) = frames [T-c0, T-c0+Tc): dgrad into dh1
+                r0 = (T - c0) * N
+                check(L.dvae_gemm_f32(dg2.data_ptr() + 4 * r0 * 4 * H, ptr(w_ih2), dh1.data_ptr() + 4 * r0 * H, None,
+                                      rows, H, 4 * H, 4 * H, H, H, 1, 0, ACT_NONE, EPI_STORE, 1, st), "dvae_gemm_f32")
+            check(L.dvae_lstm_seq_bwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_bwd_range")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((R, In), **f32)
+            gemm(dg1, w_ih1, dx, None, R, In, 4 * H, 4 * H, In, In, True, False)
+        with side_work(x, h1, h2, dg1, dg2):
+            st2 = stream()
+            for dg, inp, hh, wi, wh, bi, bh in ((dg2, h1, h2, w_ih2, w_hh2, b_ih2, b_hh2),
+                                                (dg1, x, h1, w_ih1, w_hh1, b_ih1, b_hh1)):
+                linear_wgrad_acc(dg, inp, _grad_buf(wi))
+                gw = _grad_buf(wh)
+                rws = R - N
+                sk = _split_k(_tiles(4 * H, H), rws)
+                check(L.dvae_gemm_f32(dg.data_ptr() + 4 * N * 4 * H, ptr(hh), ptr(gw), None, 4 * H, H, rws, 4 * H, H, H,
+                                      0, 0, ACT_NONE, EPI_ATOMIC, sk, st2), "dvae_gemm_f32(dW_hh)")
+                colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
+                _ready(wi, wh, bi, bh)
+        del whts, dcs
+        return (dx,) + (None,) * 10
+
+
 # ----------------------------------------------------------------------------- layout
 class FramesToMelFn(torch.autograd.Function):
     """[T*N, C] -> [N, C, T] (decode()'s final transpose, disentangled_vae.py:248)."""

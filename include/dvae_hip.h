@@ -125,6 +125,11 @@ typedef struct {
   int reverse;        /* 0: t = 0..T-1, 1: t = T-1..0 */
   int packed_bf16;    /* 0: w_packed from dvae_lstm_pack_w (fp32 recurrence); 1: from dvae_lstm_pack_w_bf16 (bf16
                          operands / fp32 accumulation on v_mfma_f32_16x16x32_bf16; H must be a multiple of 512) */
+  int step_shift;     /* *_range calls: this entry runs its step s in the launch of global step s + step_shift (0 for
+                         the plain calls).  Lets two STACKED layers share launches, the upper one a chunk of frames
+                         behind the lower one (whose chunk of outputs has meanwhile gone through the upper layer's input
+                         projection): twice the workgroups per launch, half the launches */
+  int pad_;
 } dvae_lstm_dir_t;
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
@@ -132,6 +137,12 @@ int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, in
 int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream);
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
+/* launches of global steps [step_begin, step_end) only (H a multiple of 512, packed weights); the `dirs` entries may be
+ * two directions of one layer or, with step_shift, two stacked layers of equal H, N, T and ldh */
+int dvae_lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
+                            int step_begin, int step_end, void* stream);
+int dvae_lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh,
+                            int step_begin, int step_end, void* stream);
 
 /* ---- reparameterise + latent assembly (disentangled_vae.py:222-228, 252-272) ----
  * style[N,2S], content[N,2Cn] with N = 2*Bh (x1 rows then x2 rows); eps_c[N,Cn] (null => z = mu), eps_s[Bh,S].
