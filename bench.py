@@ -201,6 +201,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    final_line = None
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
@@ -227,10 +228,19 @@ def main():
             out["cpu_baseline"] = cb
             if cb.get("value"):
                 out["speedup_vs_cpu_baseline"] = value / cb["value"]
-        print(json.dumps(out), flush=True)
+        final_line = json.dumps(out)
     if world > 1 or force_ddp:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a banner through C stdio, which sits in libc's buffer until exit: flush it first so that the
+        # JSON line is the LAST line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

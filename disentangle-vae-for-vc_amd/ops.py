@@ -542,7 +542,8 @@ class LstmStack2Fn(torch.autograd.Function):
                 check(L.dvae_gemm_f32(dg.data_ptr() + 4 * N * 4 * H, ptr(hh), ptr(gw), None, 4 * H, H, rws, 4 * H, H, H,
                                       0, 0, ACT_NONE, EPI_ATOMIC, sk, st2), "dvae_gemm_f32(dW_hh)")
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
-                _ready(wi, wh, bi, bh)
+        _ready(w_ih2, w_hh2, b_ih2, b_hh2)
+        _ready(w_ih1, w_hh1, b_ih1, b_hh1)
         del whts, dcs
         return (dx,) + (None,) * 10
 
