@@ -48,7 +48,6 @@ struct GemmParams {
   int k_per_split;       // multiple of the k-tile
   int act, epi;
   int tiles_m;
-  int prio_mode;         // experiment knob DVAE_GEMM_PRIO
 };
 
 // BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
@@ -56,9 +55,9 @@ struct GemmParams {
 // fp32 accumulation.  Images: k-contiguous [rows][BK + 8] bf16 (80-B rows: conflict-free ds_read_b128 of 8 k values);
 // row-contiguous [BK][rows + 32] bf16 read with ds_read_b64_tr_b16 (the hardware transpose delivers 4 consecutive k
 // of one row per lane; 320-B / 192-B k-rows put the 4 k-rows of a read in 4 different 64-B bank quadrants).
-template <bool A_KC, bool B_KC, int NTW, int BK, bool MF16, int WG, bool BF = false>
+template <bool A_KC, bool B_KC, int NTW, int BK, int WG, bool BF = false>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
-  static_assert(!BF || (BK == 32 && !MF16 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
+  static_assert(!BF || (BK == 32 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
   constexpr int BM = 64 * WG, NTHR = 64 * WG * WG;
   constexpr int BN = 32 * NTW * WG;      // NTW = 32-wide n-tiles per wave
   constexpr int LD_KC = BF ? BK + 8 : BK + 4;          // row stride of a k-contiguous image
@@ -216,20 +215,15 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     }
   };
 
-  // two MFMA shapes, same FLOP rate on paper: 32x32x2 (fewer, larger tiles) or 16x16x4 (MF16: finer issue
-  // granularity; the register-only probe scripts/mfma_peak.py reaches 155 TFLOP/s with it vs 143-152 with 32x32x2)
-  f32x16 acc[MF16 ? 1 : 2][MF16 ? 1 : NTW];
-  f32x4 acc16[MF16 ? 4 : 1][MF16 ? 2 * NTW : 1];
+  // (a 16x16x4 variant of this loop -- finer issue granularity, 155 vs 143-152 TFLOP/s in the register-only probe
+  // scripts/mfma_peak.py -- measured the same ~110 TFLOP/s in the full kernel and was dropped)
+  f32x16 acc[2][NTW];
 #pragma unroll
-  for (int i = 0; i < (MF16 ? 1 : 2); ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < (MF16 ? 1 : NTW); ++j)
+    for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-#pragma unroll
-  for (int i = 0; i < (MF16 ? 4 : 1); ++i)
-#pragma unroll
-    for (int j = 0; j < (MF16 ? 2 * NTW : 1); ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int tap_n = 0, kit_n = 0;   // next tile to fetch
   auto advance = [&]() {
@@ -249,14 +243,10 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   const int a_frag = A_KC ? (wm * 64 + l31) * LDA + 4 * kh : (4 * kh) * LDA + wm * 64 + l31;
   const int b_frag = B_KC ? (wn * 32 * NTW + l31) * LDB + 4 * kh : (4 * kh) * LDB + wn * 32 * NTW + l31;
 
-  if (p.prio_mode) {
-    const int sh = p.prio_mode == 1 ? 8 : (p.prio_mode == 2 ? 0 : (p.prio_mode == 3 ? 3 : 9));
-    if (__builtin_amdgcn_readfirstlane((blockIdx.x >> sh) & 1)) __builtin_amdgcn_s_setprio(2);
-  }
   int cur = 0;
   for (int it = 0; it < n_iters; ++it) {
     const bool more = (it + 1 < n_iters);
-    if (more && !(p.prio_mode & 32)) {
+    if (more) {
       load_tiles(tap_n, kit_n);
       advance();
     }
@@ -291,50 +281,6 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
           acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][0], bv[s2][nt], acc[0][nt], 0, 0, 0);
           acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][1], bv[s2][nt], acc[1][nt], 0, 0, 0);
         }
-      __builtin_amdgcn_sched_barrier(0);
-    } else if constexpr (MF16) {
-      // 16x16x4: lane (r = lane&15, q = lane>>4); 16-deep k groups, element e <-> k = 16g + 4q + e
-      constexpr int MI = 4, NJ = 2 * NTW, NG = BK / 16;
-      const int r16 = lane & 15, q16 = lane >> 4;
-      auto read16 = [&](int g, float (&av)[MI][4], float (&bv)[NJ][4]) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (A_KC) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&As[cur][(wm * 64 + i * 16 + r16) * LDA + 16 * g + 4 * q16]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) av[i][e] = v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) av[i][e] = As[cur][(16 * g + 4 * q16 + e) * LDA + wm * 64 + i * 16 + r16];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (B_KC) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&Bs[cur][(wn * 32 * NTW + j * 16 + r16) * LDB + 16 * g + 4 * q16]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][e] = v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][e] = Bs[cur][(16 * g + 4 * q16 + e) * LDB + wn * 32 * NTW + j * 16 + r16];
-          }
-        }
-      };
-      auto mfma16 = [&](float (&av)[MI][4], float (&bv)[NJ][4]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][e], bv[j][e], acc16[i][j], 0, 0, 0);
-      };
-      float a0[MI][4], b0[NJ][4], a1[MI][4], b1[NJ][4];
-      read16(0, a0, b0);
-      if (NG > 1) read16(1, a1, b1);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma16(a0, b0);
-      if (NG > 1) mfma16(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
     } else {
     // ---- fragments in 8-deep k groups: group c, element e <-> k = 8c + 4*kh + e.  The reads of group c+1 are
@@ -391,39 +337,14 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-    if (more && !(p.prio_mode & 16)) store_tiles(cur ^ 1);
-    if (!(p.prio_mode & 8)) __syncthreads();
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
     cur ^= 1;
   }
 
   // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
   const int epi = p.epi, act = p.act;
-  if constexpr (MF16) {
-    // C/D map of the 16x16 tile: col = lane&15, row = (lane>>4)*4 + reg
-    const int r16 = lane & 15, q16 = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2 * NTW; ++j) {
-        const int col = n0 + wn * 32 * NTW + j * 16 + r16;
-        if (col >= p.N) continue;
-        const float bias_v = add_bias ? p.bias[col] : 0.f;
-        const int row0 = m0 + wm * 64 + i * 16 + q16 * 4;
-        float* cbase = C + (int64_t)row0 * p.ldc + col;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          if (row0 + rg >= p.M) continue;
-          const float v = acc16[i][j][rg] + bias_v;
-          float* c = cbase + (int64_t)rg * p.ldc;
-          if (epi == DVAE_EPI_STORE) *c = (act == DVAE_ACT_NONE) ? v : act_apply(v, act);
-          else if (epi == DVAE_EPI_ACCUM) *c += v;
-          else atomicAdd(c, v);
-        }
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -466,34 +387,22 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 
 template <bool AK, bool BKC>
 void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, bool big) {
-  static const int dyn = getenv("DVAE_GEMM_DYNLDS") ? atoi(getenv("DVAE_GEMM_DYNLDS")) : 0;   // experiment: cap occupancy
-  static const int mf16 = getenv("DVAE_GEMM_MF16") ? atoi(getenv("DVAE_GEMM_MF16")) : 0;
   if (g_dvae_compute_mode == 1) {   // bf16 operands, fp32 accumulation
-    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, false, 2, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 2, true>), grid, dim3(256), 0, s, p);
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2, true>), grid, dim3(256), 0, s, p);
     return;
   }
   if (big) {   // 256 x 256 x 32 tile, 16 waves
-    hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 4>), grid, dim3(1024), dyn, s, p);
+    hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 4>), grid, dim3(1024), 0, s, p);
     return;
   }
   dim3 block(256);
-  if (mf16) {
-    if (bk == 32) {
-      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, true, 2>), grid, block, dyn, s, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, true, 2>), grid, block, dyn, s, p);
-    } else {
-      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, true, 2>), grid, block, dyn, s, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, true, 2>), grid, block, dyn, s, p);
-    }
-    return;
-  }
   if (bk == 32) {
-    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, false, 2>), grid, block, dyn, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, false, 2>), grid, block, dyn, s, p);
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2>), grid, block, 0, s, p);
   } else {
-    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, false, 2>), grid, block, dyn, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, false, 2>), grid, block, dyn, s, p);
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, 2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, 2>), grid, block, 0, s, p);
   }
 }
 
@@ -510,8 +419,6 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
   // tuning knobs for experiments (scripts/one_shape.py); unset in production
   static const int bk_env = getenv("DVAE_GEMM_BK") ? atoi(getenv("DVAE_GEMM_BK")) : 0;
-  static const int prio_env = getenv("DVAE_GEMM_PRIO") ? atoi(getenv("DVAE_GEMM_PRIO")) : 0;
-  p.prio_mode = prio_env;
   static const int narrow_env = getenv("DVAE_GEMM_NARROW") ? atoi(getenv("DVAE_GEMM_NARROW")) : -1;
   int kps = (p.K + p.split_k - 1) / p.split_k;
   // k-tile 32 when the per-split K allows it without padding waste (a long split is simply rounded up to whole
