@@ -125,3 +125,54 @@ def test_shard_range():
     assert [shard_range(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
     with pytest.raises(ValueError):
         shard_range(10, 0, 4)
+
+
+def test_compute_mode_switch_is_host_side_state():
+    """dvae_set_compute_mode / ops.set_compute_dtype: pure host state of the library, checkable without a GPU."""
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ops
+    from dvae_amd._lib import lib
+    assert ops.get_compute_dtype() == "fp32"
+    try:
+        ops.set_compute_dtype("bf16")
+        assert lib().dvae_get_compute_mode() == 1 and ops.get_compute_dtype() == "bf16"
+        with ops.compute_dtype("fp32"):
+            assert ops.get_compute_dtype() == "fp32"
+        assert ops.get_compute_dtype() == "bf16"
+        assert lib().dvae_set_compute_mode(7) == -1          # DVAE_EINVAL, mode unchanged
+        assert ops.get_compute_dtype() == "bf16"
+        with pytest.raises(ValueError):
+            ops.set_compute_dtype("fp8")
+    finally:
+        ops.set_compute_dtype("fp32")
+
+
+def test_split_k_chooser():
+    """ops._split_k: whole rounds of the 512 resident workgroups, >= 256 of K per split, not only powers of two."""
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ops
+    assert ops._split_k(80, 16384) == 6            # 5 taps x 16 tiles of the 512->512 conv weight gradient
+    assert ops._split_k(256, 16256) == 2           # W_hh gradient at H = 1024
+    assert ops._split_k(4096, 1024) == 1           # already many rounds: no split
+    for tiles in (1, 3, 16, 20, 80, 128, 500, 513, 5000):
+        for k in (32, 255, 256, 1000, 16384, 100000):
+            s = ops._split_k(tiles, k)
+            assert s >= 1 and (s == 1 or k // s >= 256), (tiles, k, s)
+    assert ops._split_k(513, 16384) > 1            # 513 tiles: a second, nearly empty round unless the work is split
+
+
+def test_stacked_lstm_schedule_rules():
+    import dvae_amd  # noqa: F401
+    from dvae_amd.ops import LstmStack2Fn as S
+    assert S.chunk(128) == 64 and S.chunk(64) == 32
+    assert S.usable(128, 1024, 2, False) and S.usable(64, 512, 2, False)
+    assert not S.usable(128, 1024, 1, False)       # one layer: nothing to stack
+    assert not S.usable(128, 64, 2, True)          # the bidirectional H=64 encoder LSTM runs whole sequences per launch
+    assert not S.usable(1, 1024, 2, False) and not S.usable(127, 1024, 2, False)
+
+
+def test_frontend_refuses_cpu():
+    import dvae_amd  # noqa: F401
+    from dvae_amd.frontend import MelFrontend
+    with pytest.raises(RuntimeError):
+        MelFrontend(device="cpu")
