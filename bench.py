@@ -176,12 +176,13 @@ def main():
             torch.cuda.synchronize()
         ms, launches, flops = ops.prof_collect()
         ops.prof_enable(0)
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_alg = None, None, None
         try:   # HBM-side bytes per launch of this kernel family from the committed PMC passes (not collectable live)
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 pm = json.load(f)
             if B == 64 and T == 128 and not bf16:
                 traffic, traffic_src = pm["gemm_f32_kernel"]["traffic_bytes_per_launch"], pm["source"]
+                traffic_alg = pm["gemm_f32_kernel"].get("algorithmic_bytes_per_launch")
         except Exception:
             pass
         if ms > 0:
@@ -191,7 +192,7 @@ def main():
                                                                        if bf16 else "v_mfma_f32_32x32x2_f32") + ")",
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": traffic, "traffic_unit": "bytes per launch (L2<->fabric, PMC)",
-                    "traffic_source": traffic_src, "launches_per_step": launches / prof_steps,
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": traffic_alg, "launches_per_step": launches / prof_steps,
                     "kernel_ms_per_step": ms / prof_steps, "avg_launch_us": 1e3 * ms / max(1, launches),
                     "flops_per_step": flops / prof_steps,
                     "timed": "HIP events around every launch, " + ("inside the timed region" if prof_live else

@@ -48,6 +48,7 @@ struct GemmParams {
   int k_per_split;       // multiple of the k-tile
   int act, epi;
   int tiles_m;
+  int xcd_map;           // contiguous m-tile ranges per XCD (see the kernel)
 };
 
 // BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
@@ -78,14 +79,27 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   const int wm = wave / WG, wn = wave % WG;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  const int tile_m = blockIdx.x % p.tiles_m;
-  const int tile_n = blockIdx.x / p.tiles_m;
+  // Workgroup -> tile.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): with xcd_map the
+  // m-tiles an XCD works on are CONTIGUOUS (XCD x owns m-tiles [x*tiles_m/8, (x+1)*tiles_m/8) of every n-tile), so the
+  // +-2-tile row shifts of the conv taps stay in the same L2 instead of being fetched by five different XCDs.
+  int tile_m, tile_n;
+  if (WG == 2 && p.xcd_map) {   // (the 16-wave variant never runs tap modes and has no registers to spare)
+    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    tile_m = x * per + q % per;
+    tile_n = q / per;
+  } else {
+    tile_m = blockIdx.x % p.tiles_m;
+    tile_n = blockIdx.x / p.tiles_m;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int tap_fixed = 0, ks = blockIdx.z;
   if (p.tap_mode == 2) {
-    tap_fixed = blockIdx.z / p.split_k;
-    ks = blockIdx.z % p.split_k;
+    // taps fastest: the five taps of one (tile, k-split) are dispatched back to back AND land on the same XCD (their
+    // linear workgroup ids differ by multiples of the tile count, a multiple of 8 for every conv of this model), so
+    // they share dY (identical) and X (shifted by four k-tiles) in L2: 408 -> ~200 MB of fabric reads per launch
+    tap_fixed = blockIdx.z % p.taps;
+    ks = blockIdx.z / p.taps;
   }
   const int k_begin = ks * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
@@ -225,11 +239,21 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Tile order of tap mode 1: taps INNER (k-tile outer).  The five taps of one k-tile read the same 32 columns of five
+  // neighbouring row tiles, which the neighbouring workgroups of this XCD read in the same k-tile: ~0.3 MB of
+  // activations live per XCD, so each row tile comes over the fabric once.  (Taps outer streams 5 MB per XCD per tap
+  // through a 4 MB L2 and every tap misses: measured 199 MB of fabric reads per 512->512 conv launch for 39 MB of
+  // operands.)
+  const int ntaps_loop = (p.tap_mode == 1) ? p.taps : 1;
   int tap_n = 0, kit_n = 0;   // next tile to fetch
   auto advance = [&]() {
-    if (++kit_n == kiters) {
-      kit_n = 0;
-      ++tap_n;
+    if constexpr (WG == 4) {   // never a tap mode
+      ++kit_n;
+      return;
+    }
+    if (++tap_n == ntaps_loop) {
+      tap_n = 0;
+      ++kit_n;
     }
   };
   if (n_iters > 0) {
@@ -434,8 +458,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   static const int big_env = getenv("DVAE_GEMM_BIG") ? atoi(getenv("DVAE_GEMM_BIG")) : -1;
   // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
-  bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256);
-  if (big_env >= 0) big = (big_env != 0) && (bk == 32);
+  bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0);
+  if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0);
   if (bf) big = false;
   const int bm = big ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
@@ -444,6 +468,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   const bool narrow = !big && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
   const int bn = big ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
+  static const int xcd_env = getenv("DVAE_GEMM_XCDMAP") ? atoi(getenv("DVAE_GEMM_XCDMAP")) : 1;
+  p.xcd_map = (xcd_env && (p.tiles_m % 8 == 0) && (xcd_env == 2 || p.tap_mode == 1)) ? 1 : 0;
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * (p.tap_mode ? p.taps : 1));
   if (a_kc && b_kc)
