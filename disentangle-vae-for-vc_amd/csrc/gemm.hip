@@ -27,8 +27,8 @@
 int g_dvae_compute_mode = 0;   // 0: fp32 MFMA; 1: bf16 operands / fp32 accumulation (dvae_set_compute_mode)
 
 #ifdef DVAE_GEMM_TS
-// Development probe (build with -DDVAE_GEMM_TS): wave 0 of every workgroup sums the s_memtime cycles it spends in the
-// four phases of a k-tile (issue global loads | LDS reads + MFMAs | wait for the loads + LDS stores | barrier).
+// Development probe (build with -DDVAE_GEMM_TS): wave 0 of every workgroup measures the s_memtime cycles of its whole
+// k-loop (two stamps only: stamps inside the loop serialise it and change what they measure).
 __device__ unsigned long long g_gemm_ts[1024 * 8];
 #define TS_NOW() __builtin_amdgcn_s_memtime()
 #endif
@@ -276,20 +276,14 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 
   int cur = 0;
 #ifdef DVAE_GEMM_TS
-  unsigned long long ts_acc[4] = {0, 0, 0, 0}, ts_t0 = TS_NOW(), ts_a, ts_b;
+  const unsigned long long ts_t0 = TS_NOW();
 #endif
   for (int it = 0; it < n_iters; ++it) {
     const bool more = (it + 1 < n_iters);
-#ifdef DVAE_GEMM_TS
-    ts_a = TS_NOW();
-#endif
     if (more) {
       load_tiles(tap_n, kit_n);
       advance();
     }
-#ifdef DVAE_GEMM_TS
-    ts_b = TS_NOW(); ts_acc[0] += ts_b - ts_a; ts_a = ts_b;
-#endif
     if constexpr (BF) {
       // v_mfma_f32_32x32x16_bf16: lane (r = lane&31, h = lane>>5) holds k = 16s + 8h + j, j = 0..7, of row r.
       // k-contiguous image: one ds_read_b128.  Row-contiguous image [k][rows]: two ds_read_b64_tr_b16; lane 4q+pq of
@@ -377,24 +371,15 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-#ifdef DVAE_GEMM_TS
-    ts_b = TS_NOW(); ts_acc[1] += ts_b - ts_a; ts_a = ts_b;
-#endif
     if (more) store_tiles(cur ^ 1);
-#ifdef DVAE_GEMM_TS
-    ts_b = TS_NOW(); ts_acc[2] += ts_b - ts_a; ts_a = ts_b;
-#endif
     __syncthreads();
-#ifdef DVAE_GEMM_TS
-    ts_b = TS_NOW(); ts_acc[3] += ts_b - ts_a;
-#endif
     cur ^= 1;
   }
 #ifdef DVAE_GEMM_TS
   if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0) {
     unsigned long long* o = g_gemm_ts + blockIdx.x * 8;
-    o[0] = ts_acc[0]; o[1] = ts_acc[1]; o[2] = ts_acc[2]; o[3] = ts_acc[3];
-    o[4] = TS_NOW() - ts_t0; o[5] = (unsigned long long)n_iters;
+    o[0] = TS_NOW() - ts_t0;
+    o[1] = (unsigned long long)n_iters;
   }
 #endif
 
