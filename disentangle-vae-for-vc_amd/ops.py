@@ -202,7 +202,9 @@ def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None):
     lda = Nout if lda is None else lda
     ldb = K if ldb is None else ldb
     sk = _split_k(_tiles(Nout, K), rows)
-    gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, EPI_ATOMIC, sk)
+    # one split: every element has one writer, a plain read-modify-write (coalesced 128-B rows) replaces the atomics
+    epi = EPI_ATOMIC if (sk > 1 or os.environ.get("DVAE_WGRAD_ATOMIC") == "1") else EPI_ACCUM
+    gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, epi, sk)
 
 
 def colsum_add(x, out1, out2=None, rows=None, cols=None, ld=None):

@@ -16,8 +16,10 @@ def t(*s):
     return torch.randn(*s, device=dev)
 
 
-def timeit(fn, flops, name, reps=5):
-    fn()
+def timeit(fn, flops, name, reps=100):
+    # sustained: a burst of a few launches runs ~13 % slower (clocks still ramping) and says nothing about the step
+    for _ in range(30):
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

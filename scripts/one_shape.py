@@ -6,7 +6,7 @@ import dvae_amd  # noqa
 from dvae_amd import ops
 from dvae_amd._lib import check, lib, ptr, stream
 kind = sys.argv[1] if len(sys.argv) > 1 else "conv"
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000   # sustained; 20-launch bursts read ~13 % low
 R, N = 16384, 128
 L = lib()
 t = lambda *s: torch.randn(*s, device="cuda")
@@ -22,7 +22,8 @@ else:
     x, w, y = t(R, 1024), t(4096, 1024), torch.empty(R, 4096, device="cuda")
     fn = lambda: ops.gemm(x, w, y, None, R, 4096, 1024, 1024, 1024, 4096, True, True)
     fl = 2.0 * R * 4096 * 1024
-fn(); torch.cuda.synchronize()
+for _ in range(50): fn()
+torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps): fn()

@@ -15,13 +15,14 @@ dwp = torch.zeros(5, cout, cin, device="cuda")
 fl = 2.0 * R * cin * cout * 5
 for sk in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 19, 25, 32):
     f = lambda: check(L.dvae_conv5_wgrad(ptr(y), ptr(x), ptr(dwp), R, N, cin, cout, sk, stream()), "")
-    f()
+    for _ in range(100):
+        f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    for _ in range(300):
         f()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
+    ms = e0.elapsed_time(e1) / 300
     print(f"sk={sk:3d} {ms * 1e3:8.1f} us {fl / ms / 1e9:7.1f} TF/s", flush=True)
