@@ -298,3 +298,25 @@ def test_model_bf16_trains(ops):
     w.enable_graph(True)
     hist = [w.step(x1, x2, None, train=True)[0] for _ in range(6)]
     assert all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+
+
+def test_model_bf16_full_size_steps(ops):
+    """BASELINE configs[1]'s shape (B=64, T=128) in bf16 mode through the replayed graph: finite, decreasing, and within
+    bf16 distance of the fp32 path on the same batch and noise."""
+    from oracle.fill import synthetic_eps, synthetic_pair
+    B, T = 64, 128
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 5))
+    eps = synthetic_eps(B, seed=6)
+    first = {}
+    for mode in ("bf16", "fp32"):
+        ops.set_compute_dtype(mode)
+        w = _make(B, T)
+        w.model.eps_override = eps
+        w.enable_graph(True)
+        hist = [w.step(x1, x2, None, train=True) for _ in range(4)]
+        assert all(np.isfinite(h).all() for h in hist)
+        assert hist[-1][0] < hist[0][0], (mode, [h[0] for h in hist])
+        first[mode] = hist[0]
+    ops.set_compute_dtype("bf16")
+    d = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(first["bf16"], first["fp32"]))
+    assert 1e-7 < d < 2e-2, d
