@@ -143,7 +143,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = bool(args.graph) and world == 1 and not force_ddp
+    use_graph = bool(args.graph) and ((world == 1 and not force_ddp) or os.environ.get("DVAE_DDP_GRAPH") == "1")
     if use_graph:
         w.enable_graph(True)
     log(f"rank {rank}/{world}: model built ({sum(p.numel() for p in w.model.parameters())} params), warm-up x{args.warmup}")

@@ -74,8 +74,14 @@ class VariationalBaseModelVAE:
         self.optimizer.zero_grad()
         outs = self.model(data1, data2)
         losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
+        if self.reducer is not None:
+            self.reducer.begin()
         losses[0].backward()
-        self.optimizer.step()
+        scale = 1.0
+        if self.reducer is not None:
+            self.reducer.finish()
+            scale = 1.0 / self.reducer.world_size
+        self.optimizer.step(grad_scale=scale)
         return torch.stack([l.detach() for l in losses])
 
     def _step_graph(self, data1, data2):
@@ -102,7 +108,10 @@ class VariationalBaseModelVAE:
             if self._graph is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # with a reducer the RCCL collectives are captured too (opt-in, see step_async); its watchdog thread
+                # makes HIP calls of its own, hence thread-local capture checking
+                mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
+                with torch.cuda.graph(g, **mode):
                     self._g_losses = self._eager_train_step(self._g_x1, self._g_x2)
                 self._graph = g
             self._graph.replay()
@@ -114,7 +123,9 @@ class VariationalBaseModelVAE:
         """One TRAIN step without any host synchronisation: the 8 loss scalars come back as a device tensor, so the
         host can enqueue the next step (noise draw, input copies, graph launch) while this one runs.  `step(...,
         train=True)` is this plus one device->host copy."""
-        if self._use_graph and self.reducer is None:
+        # data parallel + graph: opt-in (DVAE_DDP_GRAPH=1) — capturing RCCL collectives could only be exercised with a
+        # single rank here; verify on the target node before relying on it
+        if self._use_graph and (self.reducer is None or os.environ.get("DVAE_DDP_GRAPH") == "1"):
             return self._step_graph(data1, data2)
         self.optimizer.zero_grad()
         outs = self.model(data1, data2)
