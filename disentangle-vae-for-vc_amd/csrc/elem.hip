@@ -265,16 +265,25 @@ __global__ __launch_bounds__(256) void permute_102_kernel(const float* __restric
 constexpr int CS_ROWS = 128;
 // out[c] += sum_r X[r][c]: 64 column-quads x 4 row lanes per workgroup, 16-byte loads (1 KiB per wave per row)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ o1,
-                                                     float* __restrict__ o2, int R, int C, int64_t ld) {
+                                                     float* __restrict__ o2, int R, int C, int64_t ld, int rows_pb) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cl) * 4;
-  const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+  const int r0 = blockIdx.y * rows_pb, r1 = min(R, r0 + rows_pb);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (c + 3 < C) {
-    for (int r = r0 + rl; r < r1; r += 4) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(X + (int64_t)r * ld + c);
-      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    // eight independent 16-byte loads in flight per thread (one dependent load per iteration left the kernel at
+    // ~2 TB/s: too little memory-level parallelism for HBM latency)
+    const float* __restrict__ px = X + (int64_t)(r0 + rl) * ld + c;
+    const int n = (r1 - r0 - rl + 3) >> 2;          // rows of this thread
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(px + (int64_t)(i + u) * 4 * ld);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
+    for (; i < n; ++i) s += *reinterpret_cast<const f32x4*>(px + (int64_t)i * 4 * ld);
   } else if (c < C) {
     for (int r = r0 + rl; r < r1; r += 4)
       for (int k = 0; k < 4 && c + k < C; ++k) s[k] += X[(int64_t)r * ld + c + k];
@@ -552,8 +561,12 @@ DVAE_API int dvae_permute_102(const float* in, float* out, int A, int B, int C, 
 DVAE_API int dvae_colsum_add(const float* X, float* out1, float* out2, int R, int C, int64_t ld, void* stream) {
   if (!X || !out1 || R < 1 || C < 1) return DVAE_EINVAL;
   if ((ld & 3) || (((uintptr_t)X) & 15)) return DVAE_EINVAL;
-  dim3 grid((C + 255) / 256, (R + CS_ROWS - 1) / CS_ROWS);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld);
+  // (fewer rows per workgroup for narrow matrices -- more workgroups -- was tried: the extra same-address atomics
+  // cost more than the parallelism gains, 0.43 -> 1.0 ms per step)
+  const int cb = (C + 255) / 256;
+  const int rows_pb = CS_ROWS;
+  dim3 grid(cb, (R + rows_pb - 1) / rows_pb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
   return dvae_check_launch();
 }
 
