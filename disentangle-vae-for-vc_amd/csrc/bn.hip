@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int ROWS_PER_CHUNK = 128;
+constexpr int ROWS_PER_CHUNK = 64;   // 512 workgroups at R = 16384, C = 512: two per CU (128 rows: one per CU at 2-3 TB/s; 32 rows: no faster, finalize slower)
 
 __host__ __device__ inline int n_chunks(int R) { return (R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK; }
 
@@ -95,13 +95,13 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Finalize kernels: 16 channels x 16 chunk-lanes per 256-thread workgroup; the chunk partials are summed by the
-// 16 chunk-lanes in parallel and combined through LDS (a serial per-channel loop over 64 chunks was latency-bound).
+// Finalize kernels: 4 channels per 256-thread workgroup, one WAVE per channel: its 64 lanes sum the chunk partials in
+// parallel (chunks/64 loads each) and meet in a shuffle reduction; C/4 workgroups.
 __device__ __forceinline__ void sum_partials(const double* __restrict__ part, int chunks, int C, int G, int c, int kl,
-                                             double (&o)[4], double (*red)[16][4]) {
+                                             double (&o)[4]) {
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (c < C) {
-    for (int k = kl; k < chunks; k += 16) {
+    for (int k = kl; k < chunks; k += 64) {
       for (int g = 0; g < G; ++g) {
         const double* p = part + (((int64_t)k * G + g) * C + c) * 2;
         s[2 * g] += p[0];
@@ -109,17 +109,8 @@ __device__ __forceinline__ void sum_partials(const double* __restrict__ part, in
       }
     }
   }
-  const int cl = threadIdx.x & 15;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) red[kl][cl][q] = s[q];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    double t = 0.0;
-    if (kl == 0)
-      for (int k = 0; k < 16; ++k) t += red[k][cl][q];
-    o[q] = t;
-  }
+  for (int q = 0; q < 4; ++q) o[q] = wave_sum_d(s[q]);
 }
 
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ part,
@@ -127,11 +118,10 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
                                                                 float* __restrict__ rmean, float* __restrict__ rvar,
                                                                 int64_t* __restrict__ nbt, int chunks, int R, int N,
                                                                 int C, int G, float eps, float momentum) {
-  __shared__ double red[16][16][4];
-  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int kl = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + cl;
   double o[4];
-  sum_partials(part, chunks, C, G, c, kl, o, red);
+  sum_partials(part, chunks, C, G, c, kl, o);
   if (kl != 0) return;
   if (c == 0 && nbt) *nbt += G;
   if (c >= C) return;
@@ -183,11 +173,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ s12,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               int chunks, int C, int G) {
-  __shared__ double red[16][16][4];
-  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int kl = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 4 + cl;
   double o[4];
-  sum_partials(part, chunks, C, G, c, kl, o, red);
+  sum_partials(part, chunks, C, G, c, kl, o);
   if (kl != 0 || c >= C) return;
   double tg = 0.0, tb = 0.0;
   for (int g = 0; g < G; ++g) {
@@ -254,7 +243,7 @@ DVAE_API int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* 
   dim3 grid((C + 255) / 256, ch);
   hipLaunchKernelGGL((bn_partial_kernel<0>), grid, dim3(256), 0, s, Y, nullptr, nullptr, nullptr, nullptr, part, R, N,
                      C, G, 0);
-  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, mean, rstd,
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, mean, rstd,
                      running_mean, running_var, num_batches_tracked, ch, R, N, C, G, eps, momentum);
   return dvae_check_launch();
 }
@@ -280,7 +269,7 @@ DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const 
   float* s12 = (float*)((char*)ws + (int64_t)ch * G * C * 2 * sizeof(double));
   dim3 grid((C + 255) / 256, ch);
   hipLaunchKernelGGL((bn_partial_kernel<1>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, s12, dgamma, dbeta, ch, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, s12, dgamma, dbeta, ch, C,
                      G);
   const int64_t total4 = (int64_t)R * C / 4;
   const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
