@@ -1272,7 +1272,8 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   const bool v5 = v4 && (ver == 5) && (H % 512) == 0;   // eight-wave kernels
   if (v5) {
     // 32-row tiles when that still gives every CU a workgroup, else 16-row tiles: either way two waves per SIMD
-    const int mt5 = (n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1;
+    static const int mt5_env = getenv("DVAE_LSTM_MT5") ? atoi(getenv("DVAE_LSTM_MT5")) : 0;
+    const int mt5 = mt5_env ? mt5_env : ((n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1);
     const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
     // stacked entries (a shift): the 64-deep variant keeps TWO workgroups resident per CU, so the two layers' frames
@@ -1342,7 +1343,8 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
   const bool v5 = v4 && (ver == 5) && (H % 256) == 0;
   if (v5) {
-    const int mt5 = (n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1;
+    static const int mt5_env = getenv("DVAE_LSTM_MT5") ? atoi(getenv("DVAE_LSTM_MT5")) : 0;
+    const int mt5 = mt5_env ? mt5_env : ((n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1);
     const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
     dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
     for (int step = g0; step < g1; ++step) {
