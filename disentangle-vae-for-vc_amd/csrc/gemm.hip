@@ -33,6 +33,8 @@ __device__ unsigned long long g_gemm_ts[1024 * 8];
 #define TS_NOW() __builtin_amdgcn_s_memtime()
 #endif
 
+__device__ __attribute__((aligned(16))) float g_gemm_zero[4] = {0.f, 0.f, 0.f, 0.f};   // what masked lanes load
+
 namespace {
 
 // Workgroup = WG x WG waves (WG = 2: 128 x 64*NTW tile, 256 threads; WG = 4: 256 x 128*NTW tile, 1024 threads).
@@ -172,36 +174,43 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   f32x4 ra[NLA], rb[NLB];
 
   // (tap, kit) of the tile being fetched; uniform
+  // Branch-free loads: a lane whose element does not exist (ragged edge, conv padding, k tail) reads 16 bytes of zeros
+  // (g_gemm_zero) instead.  With `if (ok) load` hipcc gives every load its own basic block (s_and_saveexec + branch)
+  // and a vmcnt(0) at the loop head, and nothing in the load phase can be scheduled next to an MFMA.
+  const float* __restrict__ zsrc = g_gemm_zero;
   auto load_tiles = [&](int tap, int kit) {
     const int kofs = kit * BK;
     const int64_t a_tap = (p.tap_mode == 1) ? (int64_t)(tap - 2) * p.a_row_shift * p.lda : 0;
     const int64_t b_tap = (p.tap_mode == 1) ? (int64_t)tap * p.b_tap_stride : 0;
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool ok;
+      const float* src;
       if (A_KC) {
-        if (((a_ok[j] >> tap) & 1u) && (kofs + a_k[j] < klen))
-          v = *reinterpret_cast<const f32x4*>(a_src[j] + a_tap + kofs);
+        ok = ((a_ok[j] >> tap) & 1u) && (kofs + a_k[j] < klen);
+        src = a_src[j] + a_tap + kofs;
       } else {
-        if (a_ok[j] && (kofs + a_k[j] < klen))
-          v = *reinterpret_cast<const f32x4*>(a_src[j] + (int64_t)kofs * p.lda);
+        ok = a_ok[j] && (kofs + a_k[j] < klen);
+        src = a_src[j] + (int64_t)kofs * p.lda;
       }
-      ra[j] = v;
+      ra[j] = *reinterpret_cast<const f32x4*>(ok ? src : zsrc);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      bool ok;
+      const float* src;
       if (B_KC) {
-        if (b_ok[j] && (kofs + b_k[j] < klen)) v = *reinterpret_cast<const f32x4*>(b_src[j] + b_tap + kofs);
+        ok = b_ok[j] && (kofs + b_k[j] < klen);
+        src = b_src[j] + b_tap + kofs;
       } else {
-        bool ok = b_ok[j] && (kofs + b_k[j] < klen);
+        ok = b_ok[j] && (kofs + b_k[j] < klen);
         if (p.tap_mode == 2) {
           const int64_t kk = (int64_t)k_begin + kofs + b_k[j] + b_shift;
           ok = ok && (kk >= 0) && (kk < p.K);
         }
-        if (ok) v = *reinterpret_cast<const f32x4*>(b_src[j] + b_tap + (int64_t)kofs * p.ldb);
+        src = b_src[j] + b_tap + (int64_t)kofs * p.ldb;
       }
-      rb[j] = v;
+      rb[j] = *reinterpret_cast<const f32x4*>(ok ? src : zsrc);
     }
   };
 
