@@ -963,26 +963,24 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   }
   __syncthreads();
 
-  // the pre-activations of frame step+1 are fetched while frame step computes (their latency, ~1 us from L2,
-  // is several times one frame's work here)
-  float xn[2][4];
+  // The pre-activations of frame step+1 are fetched while frame step computes (their latency, ~1 us from L2, is
+  // several times one frame's work here).  Two register sets that swap roles every frame (loop unrolled by two) and
+  // branch-free loads (rows past N read row N-1 and are never stored): with `x = ok ? load : 0` + a copy per frame,
+  // hipcc put every load in its own basic block and drained vmcnt(0) in the middle of the SAME frame's MFMAs.
+  int nrow[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) nrow[e] = min(m0 + erow[e], N - 1);
   auto fetch = [&](int step_, float (&x)[2][4]) {
     const int t_ = d.reverse ? (T - 1 - step_) : step_;
     const float* __restrict__ G_ = d.gates + (int64_t)t_ * N * 4 * H;
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) x[e][g] = eok[e] ? G_[(int64_t)(m0 + erow[e]) * 4 * H + g * H + ej[e]] : 0.f;
+      for (int g = 0; g < 4; ++g) x[e][g] = G_[(int64_t)nrow[e] * 4 * H + g * H + ej[e]];
   };
-  fetch(0, xn);
-  for (int step = 0; step < T; ++step) {
+  auto frame = [&](int step, float (&xp)[2][4], float (&xn)[2][4]) {
     const int t = d.reverse ? (T - 1 - step) : step;
     float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
-    float xp[2][4];
-#pragma unroll
-    for (int e = 0; e < 2; ++e)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) xp[e][g] = xn[e][g];
     fetch(min(step + 1, T - 1), xn);
 
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -1023,6 +1021,12 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
       }
     }
     __syncthreads();
+  };
+  float xa[2][4], xb[2][4];
+  fetch(0, xa);
+  for (int step = 0; step < T; step += 2) {
+    frame(step, xa, xb);
+    if (step + 1 < T) frame(step + 1, xb, xa);
   }
 }
 
@@ -1057,36 +1061,38 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   }
   __syncthreads();
 
-  float gtn[2][4], ccn[2], cpn[2], dhon[2];
-  auto fetch = [&](int step_, float (&g_)[2][4], float (&cc_)[2], float (&cp_)[2], float (&dh_)[2]) {
+  // frame operands of step+1 in flight under frame step: two register sets swapping roles, branch-free clamped loads
+  // (see lstm_seq_fwd_h64)
+  struct Ops {
+    float gt[2][4], cc[2], cp[2], dho[2];
+  };
+  int nrow[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) nrow[e] = min(m0 + erow[e], N - 1);
+  auto fetch = [&](int step_, Ops& o) {
     const int fs = T - 1 - step_;
     const int t_ = d.reverse ? (T - 1 - fs) : fs;
-    const int tp_ = d.reverse ? t_ + 1 : t_ - 1;
+    const int tp_ = min(max(d.reverse ? t_ + 1 : t_ - 1, 0), T - 1);
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const int64_t n = m0 + erow[e];
+      const int64_t n = nrow[e];
       const int j = ej[e];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) g_[e][g] = eok[e] ? d.gates[((int64_t)t_ * N + n) * 4 * H + g * H + j] : 0.f;
-      cc_[e] = eok[e] ? d.c_all[((int64_t)t_ * N + n) * H + j] : 0.f;
-      cp_[e] = (eok[e] && fs > 0) ? d.c_all[((int64_t)tp_ * N + n) * H + j] : 0.f;
-      dh_[e] = eok[e] ? d.dh_out[((int64_t)t_ * N + n) * a.ldh + j] : 0.f;
+      for (int g = 0; g < 4; ++g) o.gt[e][g] = d.gates[((int64_t)t_ * N + n) * 4 * H + g * H + j];
+      o.cc[e] = d.c_all[((int64_t)t_ * N + n) * H + j];
+      const float cpv = d.c_all[((int64_t)tp_ * N + n) * H + j];
+      o.cp[e] = fs > 0 ? cpv : 0.f;
+      o.dho[e] = d.dh_out[((int64_t)t_ * N + n) * a.ldh + j];
     }
   };
-  fetch(0, gtn, ccn, cpn, dhon);
-  for (int step = 0; step < T; ++step) {
+  auto frame = [&](int step, Ops& cur, Ops& nxt) {
     const int fstep = T - 1 - step;
     const int t = d.reverse ? (T - 1 - fstep) : fstep;
-    float gt[2][4], cc[2], cp[2], dho[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) gt[e][g] = gtn[e][g];
-      cc[e] = ccn[e];
-      cp[e] = cpn[e];
-      dho[e] = dhon[e];
-    }
-    fetch(min(step + 1, T - 1), gtn, ccn, cpn, dhon);
+    auto& gt = cur.gt;
+    auto& cc = cur.cc;
+    auto& cp = cur.cp;
+    auto& dho = cur.dho;
+    fetch(min(step + 1, T - 1), nxt);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < 8; ++kc) {
@@ -1122,6 +1128,12 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
       }
     }
     __syncthreads();
+  };
+  Ops oa, ob;
+  fetch(0, oa);
+  for (int step = 0; step < T; step += 2) {
+    frame(step, oa, ob);
+    if (step + 1 < T) frame(step + 1, ob, oa);
   }
 }
 
