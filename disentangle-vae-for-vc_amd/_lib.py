@@ -34,6 +34,8 @@ SIGNATURES = {
     "dvae_conv5_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_conv5_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dvae_conv_pack_w": (i32, [vp, vp, i32, i32, vp]),
+    "dvae_conv_pack_wt": (i32, [vp, vp, i32, i32, vp]),
+    "dvae_conv5_dgrad_t": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_conv_unpack_add_w": (i32, [vp, vp, i32, i32, vp]),
     "dvae_bn_ws_bytes": (i64, [i32, i32, i32]),
     "dvae_bn_stats_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),

@@ -338,6 +338,30 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
     for (int tap = 0; tap < 5; ++tap) Wp[tap * cc + i] = W[i * 5 + tap];
   }
 }
+// W[co][ci][5] -> Wpt[tap][ci][co]: the transposed pack the data-gradient contraction reads k-contiguously
+// (32x32 tiles of the (co, ci) plane through LDS: coalesced on both sides up to the stride-5 gather)
+__global__ __launch_bounds__(256) void conv_pack_t_kernel(const float* __restrict__ W, float* __restrict__ Wpt, int Cout,
+                                                          int Cin) {
+  __shared__ float tile[5][32][33];
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    if (co < Cout && ci < Cin) {
+      const float* src = W + ((int64_t)co * Cin + ci) * 5;
+#pragma unroll
+      for (int tap = 0; tap < 5; ++tap) tile[tap][r][tx] = src[tap];
+    }
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) {
+#pragma unroll
+      for (int tap = 0; tap < 5; ++tap) Wpt[((int64_t)tap * Cin + ci) * Cout + co] = tile[tap][tx][r];
+    }
+  }
+}
 __global__ __launch_bounds__(256) void conv_unpack_add_kernel(const float* __restrict__ dWp, float* __restrict__ dW,
                                                               int64_t cc) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cc; i += (int64_t)gridDim.x * 256) {
@@ -593,6 +617,13 @@ DVAE_API int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void
   if (!W || !Wp || Cout < 1 || Cin < 1) return DVAE_EINVAL;
   const int64_t cc = (int64_t)Cout * Cin;
   hipLaunchKernelGGL(conv_pack_kernel, dim3(nblk(cc)), dim3(256), 0, (hipStream_t)stream, W, Wp, cc);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_conv_pack_wt(const float* W, float* Wpt, int Cout, int Cin, void* stream) {
+  if (!W || !Wpt || Cout < 1 || Cin < 1) return DVAE_EINVAL;
+  dim3 grid((Cin + 31) / 32, (Cout + 31) / 32);
+  hipLaunchKernelGGL(conv_pack_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, W, Wpt, Cout, Cin);
   return dvae_check_launch();
 }
 

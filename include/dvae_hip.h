@@ -82,6 +82,10 @@ int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp,
                      int R, int N, int Cin, int Cout, int split_k, void* stream);
 /* W[Cout][Cin][5] (torch layout, state_dict contract) -> Wp[5][Cout][Cin] */
 int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void* stream);
+/* Wpt[5][Cin][Cout]: the transposed pack; with it the data gradient reads BOTH operands k-contiguously (the faster
+ * ds_read_b128 fragment path of the contraction kernel): dvae_conv5_dgrad_t == dvae_conv5_dgrad on the other layout. */
+int dvae_conv_pack_wt(const float* W, float* Wpt, int Cout, int Cin, void* stream);
+int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout, void* stream);
 /* dW[Cout][Cin][5] += dWp[5][Cout][Cin] */
 int dvae_conv_unpack_add_w(const float* dWp, float* dW, int Cout, int Cin, void* stream);
 

@@ -125,6 +125,10 @@ def test_conv5(ops, N, T, Cin, Cout):
     dx = torch.empty(R, Cin, device="cuda")
     check(L.dvae_conv5_dgrad(ptr(gyf), ptr(wp), ptr(dx), R, N, Cin, Cout, stream()), "dgrad")
     close(from_frames(dx.cpu(), N, T), x.grad, name="bf16 conv_dgrad")
+    wpt, dx2 = torch.empty(5, Cin, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
+    check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
+    check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, stream()), "dgrad_t")
+    close(from_frames(dx2.cpu(), N, T), x.grad, name="bf16 conv_dgrad_t")
     dwp = torch.zeros(5, Cout, Cin, device="cuda")
     check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 3, stream()), "wgrad")
     dw = torch.zeros(Cout, Cin, 5, device="cuda")

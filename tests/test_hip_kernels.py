@@ -116,6 +116,11 @@ def test_conv5_fwd_dgrad_wgrad(ops, N, T, Cin, Cout):
     dx = torch.empty(R, Cin, device="cuda")
     check(L.dvae_conv5_dgrad(ptr(gyf), ptr(wp), ptr(dx), R, N, Cin, Cout, stream()), "dgrad")
     close(from_frames(dx.cpu(), N, T), x.grad, name="conv_dgrad")
+    wpt, dx2 = torch.empty(5, Cin, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
+    check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
+    close(wpt, w.detach().permute(2, 1, 0), rel=0, name="pack_t")
+    check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, stream()), "dgrad_t")
+    close(from_frames(dx2.cpu(), N, T), x.grad, name="conv_dgrad_t")
 
     dwp = torch.zeros(5, Cout, Cin, device="cuda")
     check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 4, stream()), "wgrad")
