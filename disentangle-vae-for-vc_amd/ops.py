@@ -424,7 +424,10 @@ class LstmLayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), device=dev, dtype=torch.float32)
             for d, (wi, wh, bi, bh) in enumerate(params):
-                gemm(dgs[d], wi, dx, None, R, In, 4 * H, 4 * H, In, In, True, False, ACT_NONE,
+                # dx = dgates @ W_ih contracts over 4H: against W_ih^T both operands are k-contiguous (the faster
+                # fragment path; the transpose of a few MB is ~10 us, the big projections gain 30-70 us each)
+                wit = transpose2d(wi)                      # [In, 4H]
+                gemm(dgs[d], wit, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
                      EPI_STORE if d == 0 else EPI_ACCUM)
         with side_work(x, h_out, *dgs):
             st2 = stream()
@@ -527,16 +530,17 @@ class LstmStack2Fn(torch.autograd.Function):
             dirs[d].dh_out, dirs[d].dgates, dirs[d].dc_ws = ptr(dho), ptr(dg), ptr(dcs[d])
             dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
         rows = Tc * N
+        w_ih2t = transpose2d(w_ih2)      # [H, 4H]: both operands of the data gradients k-contiguous (see LstmLayerFn)
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 2 finished backward steps [c0-Tc, c0) = frames [T-c0, T-c0+Tc): dgrad into dh1
                 r0 = (T - c0) * N
-                check(L.dvae_gemm_f32(dg2.data_ptr() + 4 * r0 * 4 * H, ptr(w_ih2), dh1.data_ptr() + 4 * r0 * H, None,
-                                      rows, H, 4 * H, 4 * H, H, H, 1, 0, ACT_NONE, EPI_STORE, 1, st), "dvae_gemm_f32")
+                check(L.dvae_gemm_f32(dg2.data_ptr() + 4 * r0 * 4 * H, ptr(w_ih2t), dh1.data_ptr() + 4 * r0 * H, None,
+                                      rows, H, 4 * H, 4 * H, 4 * H, H, 1, 1, ACT_NONE, EPI_STORE, 1, st), "dvae_gemm_f32")
             check(L.dvae_lstm_seq_bwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_bwd_range")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), **f32)
-            gemm(dg1, w_ih1, dx, None, R, In, 4 * H, 4 * H, In, In, True, False)
+            gemm(dg1, transpose2d(w_ih1), dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True)
         with side_work(x, h1, h2, dg1, dg2):
             st2 = stream()
             for dg, inp, hh, wi, wh, bi, bh in ((dg2, h1, h2, w_ih2, w_hh2, b_ih2, b_hh2),
