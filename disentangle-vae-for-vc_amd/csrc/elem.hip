@@ -193,10 +193,11 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   const int64_t n4 = n >> 2;
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 pp = *reinterpret_cast<f32x4*>(p + 4 * i);
-    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 4 * i);
-    f32x4 mm = *reinterpret_cast<f32x4*>(m + 4 * i);
-    f32x4 vv = *reinterpret_cast<f32x4*>(v + 4 * i);
+    // streamed once per step: non-temporal accesses keep 2.7 GB of optimiser traffic from evicting the caches
+    f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + 4 * i));
+    const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + 4 * i));
+    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + 4 * i));
+    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + 4 * i));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float gr = gg[k] * gs;
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
       vv[k] = vv[k] * b2 + (1.f - b2) * gr * gr;
       pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) / bc2s + eps));
     }
-    *reinterpret_cast<f32x4*>(p + 4 * i) = pp;
-    *reinterpret_cast<f32x4*>(m + 4 * i) = mm;
-    *reinterpret_cast<f32x4*>(v + 4 * i) = vv;
+    __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + 4 * i));
+    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + 4 * i));
+    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + 4 * i));
   }
 }
 
