@@ -130,6 +130,9 @@ def main():
     w = dvae_amd.ConvolutionalMulVAE("VCTK", T, 80, 32, 1e-4, 0.01, 500, False, batch_size=B, speaker_size=4,
                                      device=dev, latent_dim=32, mse_cof=10, kl_cof=10)
     w.model.train()
+    # identical weights on every rank (same seed, then broadcast), but an INDEPENDENT reparameterisation-noise stream
+    # per rank: the global batch of a data-parallel step must not carry one rank's eps eight times
+    torch.cuda.manual_seed(1234 + 7919 * rank)
     if world > 1 or force_ddp:
         ddp.broadcast_parameters(w.optimizer.flat_p, [b for b in w.model.buffers()])
         red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets)
@@ -143,7 +146,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = bool(args.graph) and ((world == 1 and not force_ddp) or os.environ.get("DVAE_DDP_GRAPH") == "1")
+    # data parallel: the RCCL collectives are captured inside the graph unless DVAE_DDP_GRAPH=0
+    use_graph = bool(args.graph) and ((world == 1 and not force_ddp) or os.environ.get("DVAE_DDP_GRAPH", "1") != "0")
     if use_graph:
         w.enable_graph(True)
     log(f"rank {rank}/{world}: model built ({sum(p.numel() for p in w.model.parameters())} params), warm-up x{args.warmup}")

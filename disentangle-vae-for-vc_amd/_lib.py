@@ -31,7 +31,6 @@ SIGNATURES = {
     "dvae_last_hip_error": (i32, []),
     "dvae_gemm_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
     "dvae_conv5_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "dvae_conv5_dgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_conv5_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dvae_conv_pack_w": (i32, [vp, vp, i32, i32, vp]),
     "dvae_conv_pack_wt": (i32, [vp, vp, i32, i32, vp]),
@@ -75,7 +74,6 @@ SIGNATURES = {
     "dvae_mel_db_normalize": (i32, [vp, vp, i32, i32, i64, i64, f32, f32, f32, vp]),
     "dvae_probe_launches": (i32, [i32, i32, i32, i32, vp, vp]),
     "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
-    "dvae_probe_lstm_timeline": (i32, [vp, i32]),
     "dvae_prof_enable": (i32, [i32]),
     "dvae_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
 }

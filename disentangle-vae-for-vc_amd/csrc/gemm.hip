@@ -549,19 +549,7 @@ DVAE_API int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, 
   return launch_gemm(p, true, true, (hipStream_t)stream);
 }
 
-DVAE_API int dvae_conv5_dgrad(const float* dY, const float* Wp, float* dX, int R, int N, int Cin, int Cout,
-                              void* stream) {
-  GemmParams p{};
-  p.A = dY; p.B = Wp; p.C = dX; p.bias = nullptr;
-  p.M = R; p.N = Cin; p.K = Cout;
-  p.lda = Cout; p.ldb = Cin; p.ldc = Cin;
-  p.taps = 5; p.tap_mode = 1;
-  p.a_row_shift = -(int64_t)N; p.b_tap_stride = (int64_t)Cout * Cin;
-  p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
-  return launch_gemm(p, true, false, (hipStream_t)stream);
-}
-
-// same product with the weights packed as Wpt[5][Cin][Cout] (dvae_conv_pack_wt): both operands k-contiguous
+// data gradient: the weights packed as Wpt[5][Cin][Cout] (dvae_conv_pack_wt): both operands k-contiguous
 DVAE_API int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout,
                                 void* stream) {
   GemmParams p{};

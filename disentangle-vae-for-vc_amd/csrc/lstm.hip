@@ -29,7 +29,7 @@ namespace {
 struct StepDir {
   float* gates;         // [T,N,4H]
   const float* w;       // fwd [4H,H] ; bwd W_hh^T [H,4H]
-  const float* wp;      // fragment-packed weights for the v4 kernels (dvae_lstm_pack_w), or null
+  const float* wp;      // fragment-packed weights for the v5 kernels (dvae_lstm_pack_w), or null
   float* h_out;         // [T,N,ldh] (column offset already applied)
   float* c_all;         // [T,N,H]
   const float* dh_out;  // [T,N,ldh]
@@ -44,7 +44,6 @@ struct StepArgs {
   int T, N, H;
   int64_t ldh;
   int bf16;  // packed weights are bf16 fragments (dvae_lstm_pack_w_bf16): bf16 operands, fp32 accumulation
-  int dbg;   // experiment bits (DVAE_LSTM_DBG): 1 skip in-loop global loads, 2 skip MFMAs, 4 naive block map
 };
 
 constexpr int KC = 64;   // k-chunk
@@ -53,16 +52,8 @@ constexpr int LDS_LD = 68;  // floats per staged row (64 + 4 pad; 272 B keeps 16
 // XCD-aware decode of the linear block id into (j-block, m-block): consecutive ids go to
 // different XCDs (round-robin dispatch), ids equal mod 8 share one.  Put all m-blocks of a
 // j-block on one XCD so a W_hh slice lives in exactly one L2.
-// timeline probe (DVAE_LSTM_DBG bit 8): thread 0 of every workgroup of the v5 forward kernel stamps s_memtime at
-// fixed points of the frame; the last frame's stamps are read back with dvae_probe_lstm_timeline.
-__device__ unsigned long long g_lstm_ts[512 * 8];
-__device__ __forceinline__ void ts_stamp(int dbg, int slot) {
-  if ((dbg & 8) && threadIdx.x == 0 && blockIdx.x < 512)
-    g_lstm_ts[blockIdx.x * 8 + slot] = slot == 7 ? wall_clock64() : __builtin_amdgcn_s_memtime();
-}
-
-__device__ __forceinline__ void decode_block(int bid, int n_j, int n_m, int& jb, int& mb, int dbg = 0) {
-  if ((n_j & 7) == 0 && !(dbg & 4)) {
+__device__ __forceinline__ void decode_block(int bid, int n_j, int n_m, int& jb, int& mb) {
+  if ((n_j & 7) == 0) {
     const int x = bid & 7;        // XCD label
     const int q = bid >> 3;       // index inside that XCD
     mb = q % n_m;
@@ -110,7 +101,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
   const int t = d.reverse ? (a.T - 1 - step) : step;
   const int tp = d.reverse ? t + 1 : t - 1;
   int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  decode_block(blockIdx.x, n_j, n_m, jb, mb);
   const int j0 = jb * 16, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
@@ -141,7 +132,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
     // staging map: 16 lanes cover one 256-B row segment
     const int srow = tid >> 4, sc4 = tid & 15;
     auto gload = [&](f32x4 (&rw)[4], f32x4 (&ra)[MT], int c) {
-      if ((a.dbg & 1) && c > 1) return;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int row = srow + 16 * i;  // 0..63 : gate = row>>4, j = row&15
@@ -162,7 +152,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const StepArgs a, in
     auto compute = [&](int buf) {
       const float* __restrict__ wl = &Ws[buf][(wave * 16 + r) * LDS_LD + 4 * kq];
       const float* __restrict__ al = &As[buf][r * LDS_LD + 4 * kq];
-      if (a.dbg & 2) return;
       f32x4 bq[KC / 16], aq[MT][KC / 16];
 #pragma unroll
       for (int kk = 0; kk < KC / 16; ++kk) {
@@ -221,7 +210,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
   const int tn = d.reverse ? t - 1 : t + 1;                // frame processed AFTER t in the forward recurrence
   const int tp = d.reverse ? t + 1 : t - 1;                // frame processed BEFORE t
   int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  decode_block(blockIdx.x, n_j, n_m, jb, mb);
   const int j0 = jb * 16, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, kq = lane >> 4;
@@ -256,7 +245,6 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
     const int H4 = 4 * H;
     const int srow = tid >> 4, sc4 = tid & 15;   // 16 rows x 16 float4 per pass
     auto gload = [&](f32x4 (&rb)[4], f32x4 (&ra)[4 * MT], int c) {
-      if ((a.dbg & 1) && c > 1) return;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         rb[q] = *reinterpret_cast<const f32x4*>(d.w + (int64_t)(j0 + srow) * H4 + q * H + c * KC + 4 * sc4);
@@ -281,7 +269,6 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
     auto compute = [&](int buf) {
       const float* __restrict__ bl = &Bs[buf][(wave * 16 + r) * LDS_LD + 4 * kq];
       const float* __restrict__ al = &As[buf][(wave * 16 * MT + r) * LDS_LD + 4 * kq];
-      if (a.dbg & 2) return;
       f32x4 bq[KC / 16], aq[MT][KC / 16];
 #pragma unroll
       for (int kk = 0; kk < KC / 16; ++kk) {
@@ -328,288 +315,14 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
 
 
 // =====================================================================================================
-// v4 frame kernels.  A W_hh row is consumed by exactly one wave, so staging it through LDS only costs
-// ds_write bandwidth and barriers; but fragment-shaped global loads (16 rows x 64 B per instruction) are
-// slow on the texture path.  So the weights are RE-PACKED once per training step into fragment order
-// (dvae_lstm_pack_w): the 64 lanes of a wave then read one contiguous 1-KiB burst per 16-deep k-chunk,
-// straight into registers, a whole round ahead.  Only activation rows go through LDS: forward H[t-1]
-// (shared by the four gate waves) in a few large block-level rounds; backward dG[t+1] in WAVE-PRIVATE
-// staging (each wave owns a k-quarter), so the backward main loop has no workgroup barrier at all.
-// Loads are unconditional (row / round indices clamped) so hipcc keeps counted vmcnt waits.
-// =====================================================================================================
-template <int MT, int KR>
-__global__ __launch_bounds__(256) void lstm_step_fwd_v4(const StepArgs a, int step, int n_j, int n_m) {
-  constexpr int NS = KR / 16;          // 16-deep MFMA groups per round
-  constexpr int LDA = KR + 4;          // staged row stride (floats)
-  constexpr int NST = MT * KR / 64;    // float4 per thread per round for the activation stage
-  const StepDir& d = a.d[blockIdx.z];
-  const int H = a.H, N = a.N;
-  const int t = d.reverse ? (a.T - 1 - step) : step;
-  const int tp = d.reverse ? t + 1 : t - 1;
-  int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
-  const int j0 = jb * 16, m0 = mb * 16 * MT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, kq = lane >> 4;
-
-  __shared__ __attribute__((aligned(16))) float As[2][16 * MT * LDA];
-  __shared__ float sm[4][MT * 16][17];
-
-  float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
-  float pre[MT][4], cp[MT];
-#pragma unroll
-  for (int e = 0; e < MT; ++e) {
-    const int idx = tid + 256 * e;
-    const int n = m0 + (idx >> 4), j = j0 + (idx & 15);
-    const bool ok = n < N;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) pre[e][g] = ok ? G[(int64_t)n * 4 * H + g * H + j] : 0.f;
-    cp[e] = (ok && step > 0) ? d.c_all[((int64_t)tp * N + n) * H + j] : 0.f;
-  }
-
-  f32x4 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (step > 0) {
-    const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
-    // packed layout: [(gate*n_j + jb)][k-chunk of 16][lane][4]
-    const float* __restrict__ wpk = d.wp + ((int64_t)wave * n_j + jb) * (H / 16) * 256 + lane * 4;
-    const int srow = tid >> 4, sc4 = tid & 15;
-    const int nr = H / KR, last = nr - 1;
-    auto loadW = [&](f32x4 (&w)[NS], int rd) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS + s) * 256);
-    };
-    auto loadA = [&](f32x4 (&st)[NST], int rd) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int n = min(m0 + srow + 16 * i, N - 1);
-#pragma unroll
-        for (int q = 0; q < KR / 64; ++q)
-          st[i * (KR / 64) + q] = *reinterpret_cast<const f32x4*>(hp + (int64_t)n * a.ldh + rd * KR + 64 * q + 4 * sc4);
-      }
-    };
-    auto storeA = [&](int buf, f32x4 (&st)[NST]) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int q = 0; q < KR / 64; ++q)
-          *reinterpret_cast<f32x4*>(&As[buf][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) = st[i * (KR / 64) + q];
-    };
-    auto compute = [&](int buf, f32x4 (&w)[NS]) {
-      const float* __restrict__ al = &As[buf][r * LDA + 4 * kq];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        f32x4 av[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDA + 16 * s);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], w[s][e], acc[mt], 0, 0, 0);
-      }
-    };
-    f32x4 wA[NS], wB[NS], sA[NST], sB[NST];
-    loadA(sA, 0);
-    loadW(wA, 0);
-    storeA(0, sA);
-    __syncthreads();
-    if (nr == 1) {
-      compute(0, wA);
-    } else {
-      // nr is even (H is a multiple of 2*KR): both halves unconditional, so every load and its use sit in ONE
-      // basic block and hipcc cannot sink the prefetch loads down to their consumers
-      for (int rd = 0; rd < nr; rd += 2) {
-        loadA(sB, rd + 1);
-        loadW(wB, rd + 1);
-        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the MFMAs (hipcc otherwise sinks it below)
-        compute(0, wA);
-        __builtin_amdgcn_sched_barrier(0);
-        storeA(1, sB);
-        __syncthreads();
-        loadA(sA, min(rd + 2, last));
-        loadW(wA, min(rd + 2, last));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1, wB);
-        __builtin_amdgcn_sched_barrier(0);
-        storeA(0, sA);
-        __syncthreads();
-      }
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
-  __syncthreads();
-
-  float* __restrict__ cout = d.c_all + (int64_t)t * N * H;
-  float* __restrict__ hout = d.h_out + (int64_t)t * N * a.ldh;
-#pragma unroll
-  for (int e = 0; e < MT; ++e) {
-    const int idx = tid + 256 * e;
-    const int row = idx >> 4, col = idx & 15;
-    const int n = m0 + row;
-    if (n >= N) continue;
-    const int j = j0 + col;
-    float* g = G + (int64_t)n * 4 * H + j;
-    const float gi = gate_sigmoid(sm[0][row][col] + pre[e][0]);
-    const float gf = gate_sigmoid(sm[1][row][col] + pre[e][1]);
-    const float gg = gate_tanh(sm[2][row][col] + pre[e][2]);
-    const float go = gate_sigmoid(sm[3][row][col] + pre[e][3]);
-    const float c = gf * cp[e] + gi * gg;
-    g[0] = gi;
-    g[H] = gf;
-    g[2 * H] = gg;
-    g[3 * H] = go;
-    cout[(int64_t)n * H + j] = c;
-    hout[(int64_t)n * a.ldh + j] = go * gate_tanh(c);
-  }
-}
-
-template <int MT, int KR>
-__global__ __launch_bounds__(256) void lstm_step_bwd_v4(const StepArgs a, int step, int n_j, int n_m) {
-  constexpr int NS = KR / 16;
-  constexpr int LDA = KR + 4;
-  const StepDir& d = a.d[blockIdx.z];
-  const int H = a.H, N = a.N;
-  const int fstep = a.T - 1 - step;
-  const int t = d.reverse ? (a.T - 1 - fstep) : fstep;
-  const int tn = d.reverse ? t - 1 : t + 1;
-  const int tp = d.reverse ? t + 1 : t - 1;
-  int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
-  const int j0 = jb * 16, m0 = mb * 16 * MT;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, kq = lane >> 4;
-
-  __shared__ __attribute__((aligned(16))) float Ast[4][2 * 16 * MT * LDA];   // per wave, two buffers
-  __shared__ float sm[4][MT * 16][17];
-
-  const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
-  float gt[MT][4], cc[MT], cp[MT], dho[MT], dcar[MT];
-#pragma unroll
-  for (int e = 0; e < MT; ++e) {
-    const int idx = tid + 256 * e;
-    const int n = m0 + (idx >> 4), j = j0 + (idx & 15);
-    const bool ok = n < N;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) gt[e][g] = ok ? G[(int64_t)n * 4 * H + g * H + j] : 0.f;
-    cc[e] = ok ? d.c_all[((int64_t)t * N + n) * H + j] : 0.f;
-    cp[e] = (ok && fstep > 0) ? d.c_all[((int64_t)tp * N + n) * H + j] : 0.f;
-    dho[e] = ok ? d.dh_out[((int64_t)t * N + n) * a.ldh + j] : 0.f;
-    dcar[e] = (ok && step > 0) ? d.dc[(int64_t)n * H + j] : 0.f;
-  }
-
-  f32x4 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (step > 0) {
-    const int H4 = 4 * H;
-    // packed layout: [(jb*4 + quarter)][k-chunk of 16][lane][4]
-    const float* __restrict__ bpk = d.wp + ((int64_t)jb * 4 + wave) * (H / 16) * 256 + lane * 4;
-    // wave-private staging of this wave's dG[t+1] quarter: 4 rows x 256 B per load instruction
-    float* __restrict__ stg = &Ast[wave][0];
-    const int lrow = lane >> 4, lc4 = lane & 15;
-    const float* arow[4 * MT];
-#pragma unroll
-    for (int i = 0; i < 4 * MT; ++i) {
-      const int n = min(m0 + lrow + 4 * i, N - 1);
-      arow[i] = d.dgates + ((int64_t)tn * N + n) * H4 + (int64_t)wave * H + 4 * lc4;
-    }
-    const int nr = H / KR, last = nr - 1;
-    auto loadA = [&](f32x4 (&st)[4 * MT][KR / 64], int rd) {
-#pragma unroll
-      for (int i = 0; i < 4 * MT; ++i)
-#pragma unroll
-        for (int q = 0; q < KR / 64; ++q) st[i][q] = *reinterpret_cast<const f32x4*>(arow[i] + rd * KR + 64 * q);
-    };
-    auto storeA = [&](int buf, f32x4 (&st)[4 * MT][KR / 64]) {
-#pragma unroll
-      for (int i = 0; i < 4 * MT; ++i)
-#pragma unroll
-        for (int q = 0; q < KR / 64; ++q)
-          *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
-    };
-    auto loadB = [&](f32x4 (&b)[NS], int rd) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS + s) * 256);
-    };
-    auto compute = [&](int buf, f32x4 (&b)[NS]) {
-      const float* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 4 * kq;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        f32x4 av[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(al + mt * 16 * LDA + 16 * s);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], b[s][e], acc[mt], 0, 0, 0);
-      }
-    };
-    f32x4 bA[NS], bB[NS], sA[4 * MT][KR / 64], sB[4 * MT][KR / 64];
-    loadA(sA, 0);
-    loadB(bA, 0);
-    storeA(0, sA);
-    __builtin_amdgcn_wave_barrier();
-    if (nr == 1) {
-      compute(0, bA);
-    } else {
-      for (int rd = 0; rd < nr; rd += 2) {      // nr even, see the forward kernel
-        loadA(sB, rd + 1);
-        loadB(bB, rd + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(0, bA);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_wave_barrier();
-        storeA(1, sB);
-        __builtin_amdgcn_wave_barrier();
-        loadA(sA, min(rd + 2, last));
-        loadB(bA, min(rd + 2, last));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1, bB);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_wave_barrier();
-        storeA(0, sA);
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
-  __syncthreads();
-
-  float* __restrict__ dG = d.dgates + (int64_t)t * N * 4 * H;
-#pragma unroll
-  for (int e = 0; e < MT; ++e) {
-    const int idx = tid + 256 * e;
-    const int row = idx >> 4, col = idx & 15;
-    const int n = m0 + row;
-    if (n >= N) continue;
-    const int j = j0 + col;
-    const float dh = dho[e] + sm[0][row][col] + sm[1][row][col] + sm[2][row][col] + sm[3][row][col];
-    const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
-    const float tc = gate_tanh(cc[e]);
-    const float dc = dcar[e] + dh * go * (1.f - tc * tc);
-    float* o = dG + (int64_t)n * 4 * H + j;
-    o[0] = dc * gg * gi * (1.f - gi);
-    o[H] = dc * cp[e] * gf * (1.f - gf);
-    o[2 * H] = dc * gi * (1.f - gg * gg);
-    o[3 * H] = dh * tc * go * (1.f - go);
-    d.dc[(int64_t)n * H + j] = dc * gf;
-  }
-}
-
-
-// =====================================================================================================
-// v5 frame kernels: v4's data movement with EIGHT waves per workgroup over a 16-unit x 32-segment tile.
+// v5 frame kernels (H a multiple of 512): EIGHT waves per workgroup over a 16-unit x 16/32-segment tile.
+// A W_hh row is consumed by exactly one wave, so staging it through LDS only costs ds_write bandwidth and barriers;
+// but fragment-shaped global loads (16 rows x 64 B per instruction) are slow on the texture path.  So the weights are
+// RE-PACKED into fragment order (dvae_lstm_pack_w): the 64 lanes of a wave read one contiguous 1-KiB burst per
+// 16-deep k-chunk, straight into registers, a whole round ahead.  Only activation rows go through LDS: forward H[t-1]
+// (shared by the four gate waves) in a few large block-level rounds; backward dG[t+1] in WAVE-PRIVATE staging (each
+// wave owns a k-range), so the backward main loop has no workgroup barrier at all.  Loads are unconditional (row /
+// round indices clamped) so hipcc keeps counted vmcnt waits.
 // Measured on MI355X: a 32-row tile halves the W_hh re-read traffic but leaves one wave per SIMD
 // (latency-bound, 21 us/frame); a 16-row tile gives two waves per SIMD but doubles the traffic (18 us).
 // Eight waves = 4 gates (fwd) / k-quarters (bwd) x 2 k-halves give both: two waves per SIMD AND the
@@ -632,8 +345,7 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
   const int t = d.reverse ? (a.T - 1 - step) : step;
   const int tp = d.reverse ? t + 1 : t - 1;
   int jb, mb;
-  ts_stamp(a.dbg, 0);
-  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  decode_block(blockIdx.x, n_j, n_m, jb, mb);
   const int j0 = jb * 16, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gate = wave & 3, kh = wave >> 2;
@@ -720,7 +432,6 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
     loadW(wA, 0);
     storeA(0, sA);
     __syncthreads();
-    ts_stamp(a.dbg, 1);
     if (nr == 1) {
       compute(0, wA);
     } else {
@@ -730,10 +441,8 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
         __builtin_amdgcn_sched_barrier(0);
         compute(0, wA);
         __builtin_amdgcn_sched_barrier(0);
-        if (rd == 0) ts_stamp(a.dbg, 2);
         storeA(1, sB);
         __syncthreads();
-        if (rd == 0) ts_stamp(a.dbg, 3);
         loadA(sA, min(rd + 2, last));
         loadW(wA, min(rd + 2, last));
         __builtin_amdgcn_sched_barrier(0);
@@ -748,9 +457,7 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
-  ts_stamp(a.dbg, 4);
   __syncthreads();
-  ts_stamp(a.dbg, 5);
 
   if (eok) {
     const int row = tid >> 4, col = tid & 15;
@@ -767,8 +474,6 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
     d.c_all[((int64_t)t * N + en) * H + ej] = c;
     d.h_out[((int64_t)t * N + en) * a.ldh + ej] = go * gate_tanh(c);
   }
-  ts_stamp(a.dbg, 6);
-  ts_stamp(a.dbg, 7);
 }
 
 // (An "all loads of the frame in flight up front" variant -- 217 VGPRs, no spills -- measured 17.1 us/frame against
@@ -789,7 +494,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
   const int tn = d.reverse ? t - 1 : t + 1;
   const int tp = d.reverse ? t + 1 : t - 1;
   int jb, mb;
-  decode_block(blockIdx.x, n_j, n_m, jb, mb, a.dbg);
+  decode_block(blockIdx.x, n_j, n_m, jb, mb);
   const int j0 = jb * 16, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quarter = wave >> 1, part = wave & 1;      // k range: [quarter*H + part*H/2, +H/2)
@@ -1212,29 +917,10 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
     if ((dirs[i].packed_bf16 ? 1 : 0) != a.bf16 || (a.bf16 && !dirs[i].w_packed)) return DVAE_EINVAL;
   if (a.bf16 && (H % 512)) return DVAE_EINVAL;        // bf16 frame kernels exist for H = 512, 1024, ...
   a.T = T; a.N = N; a.H = H; a.ldh = ldh;
-  static const int dbg_env = getenv("DVAE_LSTM_DBG") ? atoi(getenv("DVAE_LSTM_DBG")) : 0;
-  a.dbg = dbg_env;
   return DVAE_OK;
-}
-
-// rows per workgroup: prefer the largest MT that still yields >= 256 workgroups
-int pick_mt(int N, int H, int ndir) {
-  static const int mt_env = getenv("DVAE_LSTM_MT") ? atoi(getenv("DVAE_LSTM_MT")) : 0;
-  if (mt_env == 1 || mt_env == 2) return mt_env;
-  // measured on MI355X (scripts/lstm_shape.py): 16-row workgroups (two per CU at H=1024) beat 32-row ones
-  // at every H of this model -- the extra W_hh traffic costs less than the latency the second workgroup hides
-  (void)N; (void)H; (void)ndir;
-  return 1;
 }
 
 }  // namespace
-
-DVAE_API int dvae_probe_lstm_timeline(unsigned long long* host_out, int n_words) {
-  if (!host_out || n_words < 1 || n_words > 512 * 8) return DVAE_EINVAL;
-  if (hipDeviceSynchronize() != hipSuccess) return DVAE_ELAUNCH;
-  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lstm_ts), sizeof(unsigned long long) * n_words) != hipSuccess) return DVAE_ELAUNCH;
-  return DVAE_OK;
-}
 
 DVAE_API int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream) {
   if (!w_hh || (!packed_fwd && !packed_bwd) || H < 64 || (H & 63)) return DVAE_EINVAL;
@@ -1256,65 +942,63 @@ DVAE_API int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* pa
 }
 
 namespace {
+// Three kernel families, chosen by H alone (every one of them is reached by tests/test_hip_kernels.py::test_lstm_layer):
+//   H == 64            lstm_seq_*_h64      whole sequence in one launch, W_hh in registers
+//   H % 512 == 0       lstm_step_*_v5      one launch per frame, fragment-packed W_hh (needs dirs[i].w_packed)
+//   other H % 64 == 0  lstm_step_*_kernel  one launch per frame, W_hh staged through LDS (generic fallback)
+struct SeqPlan {
+  bool shifted, whole;
+  int n_j, mt5, n_m5;
+  int64_t frames;   // (entry, step) pairs of this call that carry a recurrent product
+};
+int plan_seq(const StepArgs& a, int ndir, int g0, int g1, SeqPlan& p) {
+  if (g0 < 0 || g1 < g0) return DVAE_EINVAL;
+  p.shifted = a.d[0].shift != 0 || (ndir == 2 && a.d[1].shift != 0);
+  p.whole = (g0 == 0 && g1 == a.T && !p.shifted);
+  p.n_j = a.H / 16;
+  // 32-row tiles when that still gives every CU a workgroup, else 16-row tiles: either way two waves per SIMD
+  p.mt5 = (p.n_j * ((a.N + 31) / 32) * ndir >= 256) ? 2 : 1;
+  p.n_m5 = (a.N + 16 * p.mt5 - 1) / (16 * p.mt5);
+  p.frames = 0;
+  for (int i = 0; i < ndir; ++i)
+    for (int g = g0; g < g1; ++g) p.frames += (g - a.d[i].shift > 0 && g - a.d[i].shift < a.T) ? 1 : 0;
+  return DVAE_OK;
+}
+
 // global launch steps [g0, g1): entry i runs its local step g - step_shift when that lies in [0, T)
 int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, int g0, int g1,
                        void* stream) {
   StepArgs a{};
   int rc = fill_args(a, dirs, ndir, T, N, H, ldh, false);
   if (rc) return rc;
-  const bool shifted = a.d[0].shift != 0 || (ndir == 2 && a.d[1].shift != 0);
-  const bool whole = (g0 == 0 && g1 == T && !shifted);
-  if (g0 < 0 || g1 < g0) return DVAE_EINVAL;
+  SeqPlan p;
+  if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int mt = pick_mt(N, H, ndir);
-  const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
-  dim3 grid(n_j * n_m, 1, ndir), block(256);
-  int64_t frames = 0;   // (entry, step) pairs of this call that carry a recurrent product
-  for (int i = 0; i < ndir; ++i)
-    for (int g = g0; g < g1; ++g) frames += (g - a.d[i].shift > 0 && g - a.d[i].shift < T) ? 1 : 0;
-  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)frames);
-  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
-  const bool big = (H % 256) == 0;
-  if (H == 64 && ver >= 4) {   // whole sequence in one launch (row-split, no inter-workgroup dependency)
-    if (!whole) return DVAE_EINVAL;
+  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
+  if (H == 64) {
+    if (!p.whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_fwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
-  const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
-  const bool v5 = v4 && (ver == 5) && (H % 512) == 0;   // eight-wave kernels
-  if (v5) {
-    // 32-row tiles when that still gives every CU a workgroup, else 16-row tiles: either way two waves per SIMD
-    static const int mt5_env = getenv("DVAE_LSTM_MT5") ? atoi(getenv("DVAE_LSTM_MT5")) : 0;
-    const int mt5 = mt5_env ? mt5_env : ((n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1);
-    const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
-    dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
+  if (H % 512 == 0) {
+    if (!a.d[0].wp || !a.d[ndir - 1].wp) return DVAE_EINVAL;
+    dim3 grid5(p.n_j * p.n_m5, 1, ndir), block5(512);
     // stacked entries (a shift): the 64-deep variant keeps TWO workgroups resident per CU, so the two layers' frames
     // really overlap (one's load latency under the other's MFMAs) instead of alternating
-    static const int kr_env = getenv("DVAE_LSTM_KR") ? atoi(getenv("DVAE_LSTM_KR")) : 0;
-    const bool kr64 = kr_env ? (kr_env == 64) : shifted;
     for (int step = g0; step < g1; ++step) {
       if (a.bf16) {
-        if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
-        else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
-      } else if (mt5 == 2 && kr64) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
-      else if (mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
-      else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128>), grid5, block5, 0, s, a, step, n_j, n_m5);
+        if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+        else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      } else if (p.mt5 == 2 && p.shifted) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 64>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      else if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
     }
     return dvae_check_launch();
   }
-  if (!whole) return DVAE_EINVAL;          // step ranges / stacked entries exist for the eight-wave kernels only
-  for (int step = 0; step < T; ++step) {
-    if (v4) {
-      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_fwd_v4<2, 256>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (mt == 2) hipLaunchKernelGGL((lstm_step_fwd_v4<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (big) hipLaunchKernelGGL((lstm_step_fwd_v4<1, 256>), grid, block, 0, s, a, step, n_j, n_m);
-      else hipLaunchKernelGGL((lstm_step_fwd_v4<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
-    } else if (mt == 2) {
-      hipLaunchKernelGGL((lstm_step_fwd_kernel<2>), grid, block, 0, s, a, step, n_j, n_m);
-    } else {
-      hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), grid, block, 0, s, a, step, n_j, n_m);
-    }
-  }
+  if (!p.whole || a.bf16) return DVAE_EINVAL;   // step ranges / stacked entries / bf16 exist for the eight-wave kernels only
+  const int n_m = (N + 15) / 16;
+  for (int step = 0; step < T; ++step)
+    hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), dim3(p.n_j * n_m, 1, ndir), dim3(256), 0, s, a, step, p.n_j, n_m);
   return dvae_check_launch();
 }
 }  // namespace
@@ -1328,59 +1012,36 @@ DVAE_API int dvae_lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int 
 }
 
 namespace {
-// global launch steps [g0, g1): entry i runs its local step g - step_shift when that lies in [0, T)
 int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, int g0, int g1,
                        void* stream) {
   StepArgs a{};
   int rc = fill_args(a, dirs, ndir, T, N, H, ldh, true);
   if (rc) return rc;
-  const bool shifted = a.d[0].shift != 0 || (ndir == 2 && a.d[1].shift != 0);
-  const bool whole = (g0 == 0 && g1 == T && !shifted);
-  if (g0 < 0 || g1 < g0) return DVAE_EINVAL;
+  SeqPlan p;
+  if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int mt = pick_mt(N, H, ndir);
-  const int n_j = H / 16, n_m = (N + 16 * mt - 1) / (16 * mt);
-  dim3 grid(n_j * n_m, 1, ndir), block(256);
-  int64_t frames = 0;   // (entry, step) pairs of this call that carry a recurrent product
-  for (int i = 0; i < ndir; ++i)
-    for (int g = g0; g < g1; ++g) frames += (g - a.d[i].shift > 0 && g - a.d[i].shift < T) ? 1 : 0;
-  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)frames);
-  static const int ver = getenv("DVAE_LSTM_V") ? atoi(getenv("DVAE_LSTM_V")) : 5;
-  const bool big = (H % 128) == 0;
-  if (H == 64 && ver >= 4) {
-    if (!whole) return DVAE_EINVAL;
+  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
+  if (H == 64) {
+    if (!p.whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_bwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
-  const bool v4 = (ver >= 4) && a.d[0].wp && a.d[ndir - 1].wp;
-  const bool v5 = v4 && (ver == 5) && (H % 256) == 0;
-  if (v5) {
-    static const int mt5_env = getenv("DVAE_LSTM_MT5") ? atoi(getenv("DVAE_LSTM_MT5")) : 0;
-    const int mt5 = mt5_env ? mt5_env : ((n_j * ((N + 31) / 32) * ndir >= 256) ? 2 : 1);
-    const int n_m5 = (N + 16 * mt5 - 1) / (16 * mt5);
-    dim3 grid5(n_j * n_m5, 1, ndir), block5(512);
+  if (H % 512 == 0) {
+    if (!a.d[0].wp || !a.d[ndir - 1].wp) return DVAE_EINVAL;
+    dim3 grid5(p.n_j * p.n_m5, 1, ndir), block5(512);
     for (int step = g0; step < g1; ++step) {
       if (a.bf16) {
-        if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
-        else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, true>), grid5, block5, 0, s, a, step, n_j, n_m5);
-      } else if (mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
-      else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64>), grid5, block5, 0, s, a, step, n_j, n_m5);
+        if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+        else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      } else if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
     }
     return dvae_check_launch();
   }
-  if (!whole) return DVAE_EINVAL;          // step ranges / stacked entries exist for the eight-wave kernels only
-  for (int step = 0; step < T; ++step) {
-    if (v4) {
-      if (mt == 2 && big) hipLaunchKernelGGL((lstm_step_bwd_v4<2, 128>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (mt == 2) hipLaunchKernelGGL((lstm_step_bwd_v4<2, 64>), grid, block, 0, s, a, step, n_j, n_m);
-      else if (big) hipLaunchKernelGGL((lstm_step_bwd_v4<1, 128>), grid, block, 0, s, a, step, n_j, n_m);
-      else hipLaunchKernelGGL((lstm_step_bwd_v4<1, 64>), grid, block, 0, s, a, step, n_j, n_m);
-    } else if (mt == 2) {
-      hipLaunchKernelGGL((lstm_step_bwd_kernel<2>), grid, block, 0, s, a, step, n_j, n_m);
-    } else {
-      hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), grid, block, 0, s, a, step, n_j, n_m);
-    }
-  }
+  if (!p.whole || a.bf16) return DVAE_EINVAL;
+  const int n_m = (N + 15) / 16;
+  for (int step = 0; step < T; ++step)
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), dim3(p.n_j * n_m, 1, ndir), dim3(256), 0, s, a, step, p.n_j, n_m);
   return dvae_check_launch();
 }
 }  // namespace

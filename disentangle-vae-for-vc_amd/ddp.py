@@ -52,6 +52,8 @@ class GradReducer:
         self.works = []
         self.active = False
         self.force = False      # issue the collective even with one rank (tests of the RCCL path)
+        # buckets launched from the autograd hook (overlapped with backward) / left over for finish(), cumulative
+        self.stats = {"hook": 0, "finish": 0, "steps": 0}
 
     def begin(self):
         self.pending = list(self.pending_init)
@@ -73,6 +75,7 @@ class GradReducer:
             return
         self.pending[b] -= 1
         if self.pending[b] == 0:
+            self.stats["hook"] += 1
             self._launch(b)
 
     def finish(self):
@@ -80,8 +83,10 @@ class GradReducer:
         ops.grad_ready_hook = None
         ops.join_side()
         self.active = False
+        self.stats["steps"] += 1
         for b, left in enumerate(self.pending):
             if left > 0:
+                self.stats["finish"] += 1
                 self._launch(b)
         for w in self.works:
             w.wait()

@@ -160,6 +160,16 @@ class DisentangledVAE(nn.Module):
                  latent_sz: int = 32, c: float = 512, c_delta: float = 0.001, beta: float = 0.1,
                  beta_delta: float = 0, dim_neck=64, latent_dim=64, dim_pre=512, batch_size=10, n_frames: int = 64):
         super().__init__()
+        # the contraction kernels move operands in 16-byte pieces: the two Gaussian heads (mu | logvar) need an even
+        # width each and the latent (decoder input) a multiple of 4 — the reference accepts any size, this path says so
+        # here instead of failing inside the first backward
+        c_sz = latent_dim - speaker_size
+        if speaker_size < 1 or c_sz < 1 or speaker_size % 2 or c_sz % 2 or latent_dim % 4:
+            raise ValueError(f"DisentangledVAE(HIP): speaker_size={speaker_size} and latent_dim-speaker_size={c_sz} must "
+                             f"be even and latent_dim={latent_dim} a multiple of 4 (16-byte operand rows)")
+        if dim_neck != 64 or dim_pre != 512:
+            raise ValueError("DisentangledVAE(HIP): dim_neck=64 and dim_pre=512 are the sizes the reference hard-codes "
+                             "(disentangled_vae.py:165,171: 8192 = 64 frames x 2*dim_neck) and the ones built here")
         self.batch_size = batch_size
         self._input_sz = input_sz
         self._channel_szs = [input_sz[0]] + list(kernel_szs)

@@ -51,9 +51,11 @@ class VariationalBaseModelVAE:
         self.optimizer = None
         self.batch_size = batch_size
         self.reducer = None     # ddp.GradReducer when data parallel
-        # hipGraph replay of the whole train step (single-GPU): ~1 400 launches become one graph launch
+        # hipGraph replay of the whole train step: ~1 000 launches become one graph launch
         self._use_graph = False
+        self._graph_ddp = True
         self._graph = None
+        self._graph_sig = None
         self._graph_calls = 0
 
     def loss_function(self):
@@ -63,12 +65,27 @@ class VariationalBaseModelVAE:
     def attach_reducer(self, reducer):
         self.reducer = reducer
 
-    def enable_graph(self, flag: bool = True):
-        """Capture the train step into a hipGraph on its second call and replay it afterwards (fixed batch shape;
-        ignored under data parallelism).  The first call runs eagerly (it is a real step and warms everything up)."""
+    def enable_graph(self, flag: bool = True, ddp=None):
+        """Capture the train step into a hipGraph on its second call and replay it afterwards.  The first call runs
+        eagerly (it is a real step, warms everything up and, under data parallelism, lets RCCL set up its communicator
+        outside the capture).  The graph bakes host scalars into kernel arguments (learning rate, loss coefficients,
+        1/batch_size, BatchNorm train/eval, shapes): `_graph_signature` is compared on every step and the graph is
+        re-captured when any of them changed, so `optimizer.param_groups[0]['lr'] = ...`, `update_kl()` or
+        `model.eval()` take effect exactly as in the eager path.
+        `ddp`: with a reducer attached the bucketed RCCL all-reduces are captured INSIDE the graph (ranks replay the
+        same step a single GPU does).  Default: on, unless DVAE_DDP_GRAPH=0; with it off a data-parallel step runs
+        eagerly whatever `flag` says."""
         self._use_graph = flag
+        self._graph_ddp = (os.environ.get("DVAE_DDP_GRAPH", "1") != "0") if ddp is None else bool(ddp)
         self._graph = None
+        self._graph_sig = None
         self._graph_calls = 0
+
+    def _graph_signature(self, data1):
+        opt = self.optimizer
+        return (tuple(data1.shape), float(opt.param_groups[0]["lr"]), tuple(opt.betas), float(opt.eps),
+                float(self.mse_cof), float(self.kl_cof), int(self.batch_size), bool(self.model.training),
+                self.reducer is not None, getattr(self.reducer, "world_size", 1))
 
     def _eager_train_step(self, data1, data2):
         self.optimizer.zero_grad()
@@ -92,12 +109,14 @@ class VariationalBaseModelVAE:
         self._graph_calls += 1
         if self._graph_calls == 1:
             return self._eager_train_step(data1, data2)
+        sig = self._graph_signature(data1)
+        if self._graph is not None and sig != self._graph_sig:
+            self._graph = None          # a baked-in scalar or the batch shape changed: capture again
         if self._graph is None:
+            self._graph_sig = sig
             self._g_x1, self._g_x2 = torch.empty_like(data1), torch.empty_like(data2)
             self._g_eps = (torch.empty((Bh, Cn), device=dev), torch.empty((Bh, Cn), device=dev),
                            torch.empty((Bh, S), device=dev))
-        if tuple(data1.shape) != tuple(self._g_x1.shape):
-            raise ValueError("graph mode needs a fixed batch shape; call enable_graph() again to re-capture")
         self._g_x1.copy_(data1)
         self._g_x2.copy_(data2)
         user_eps = m.eps_override
@@ -123,22 +142,9 @@ class VariationalBaseModelVAE:
         """One TRAIN step without any host synchronisation: the 8 loss scalars come back as a device tensor, so the
         host can enqueue the next step (noise draw, input copies, graph launch) while this one runs.  `step(...,
         train=True)` is this plus one device->host copy."""
-        # data parallel + graph: opt-in (DVAE_DDP_GRAPH=1) — capturing RCCL collectives could only be exercised with a
-        # single rank here; verify on the target node before relying on it
-        if self._use_graph and (self.reducer is None or os.environ.get("DVAE_DDP_GRAPH") == "1"):
+        if self._use_graph and (self.reducer is None or self._graph_ddp):
             return self._step_graph(data1, data2)
-        self.optimizer.zero_grad()
-        outs = self.model(data1, data2)
-        losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
-        if self.reducer is not None:
-            self.reducer.begin()
-        losses[0].backward()
-        scale = 1.0
-        if self.reducer is not None:
-            self.reducer.finish()
-            scale = 1.0 / self.reducer.world_size
-        self.optimizer.step(grad_scale=scale)
-        return torch.stack([l.detach() for l in losses])
+        return self._eager_train_step(data1, data2)
 
     # ---- variational_base_vae.py:58-70
     def step(self, data1, data2, speaker_ids, train=False):
@@ -189,6 +195,10 @@ class VariationalBaseModelVAE:
             self.optimizer.load_state_dict(sd)
             if sd.get("cuda_rng_state") is not None and torch.device(self.device).type == "cuda":
                 torch.cuda.set_rng_state(sd["cuda_rng_state"], self.device)   # eps stream continues where it stopped
+                if self.reducer is not None and self.reducer.rank > 0:
+                    # the checkpoint holds rank 0's generator; the other ranks must not replay ITS noise on their shards
+                    g = torch.cuda.default_generators[torch.device(self.device).index or 0]
+                    g.manual_seed(g.initial_seed() + 7919 * self.reducer.rank)
         logging_func(f"Loading {name} model from last checkpoint ({start_epoch})...")
         return start_epoch + 1
 

@@ -100,7 +100,10 @@ def _ok(*ts):
 
 def _grad_buf(p: torch.Tensor) -> torch.Tensor:
     if p.grad is None:
-        p.grad = torch.zeros_like(p)
+        if getattr(p, "_dvae_flat_owned", False):
+            raise RuntimeError("gradient of a FlatAdam-owned parameter was set to None (model.zero_grad()?): its "
+                               "gradient must stay a view of the optimiser's flat buffer; use optimizer.zero_grad()")
+        p.grad = torch.zeros_like(p)      # stand-alone use of an op (kernel tests): a private gradient buffer
     return p.grad
 
 

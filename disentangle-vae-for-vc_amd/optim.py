@@ -45,6 +45,7 @@ class FlatAdam:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
+            p._dvae_flat_owned = True      # ops._grad_buf refuses to re-allocate a gradient for such a parameter
         self.lr, self.betas, self.eps = lr, betas, eps
         self.dev_state = torch.zeros(4, device=dev, dtype=torch.float32)   # [t, 1-b1^t, sqrt(1-b2^t), -]
         # torch.optim-compatible surface used by callers of the reference wrapper
@@ -67,6 +68,11 @@ class FlatAdam:
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdam.step runs only on the HIP device (no CPU fallback)")
         from . import ops
+        if not self.views_intact():
+            # model.zero_grad() (set_to_none), .to()/.float() or `p.grad = None` would detach parameters from the flat
+            # buffers: the kernels would then accumulate elsewhere while Adam and the all-reduce read stale zeros
+            raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
+                               "(use optimizer.zero_grad(), never model.zero_grad()/p.grad = None/model.to())")
         ops.join_side()     # weight-gradient work may still be running on the side stream
         lr = self.param_groups[0]["lr"]
         check(lib().dvae_adam_flat_dev(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),

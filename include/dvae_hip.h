@@ -70,20 +70,18 @@ int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
 /* ---- Conv1d(k=5, stride 1, pad 2) on frame-major data (disentangled_vae.py:111-114, 178-181) ----
  * Weights are used in PACKED form Wp[5][Cout][Cin] (see dvae_conv_pack_w).
  * fwd : Y[R,Cout]   = sum_tap X[r+(tap-2)*N, :] * Wp[tap]^T + bias      (rows outside [0,R) are zero)
- * dgrad: dX[R,Cin]  = sum_tap dY[r-(tap-2)*N, :] * Wp[tap]
+ * dgrad: dX[R,Cin]  = sum_tap dY[r-(tap-2)*N, :] * Wp[tap]                  (dvae_conv5_dgrad_t, on the transposed pack)
  * wgrad: dWp[tap][Cout][Cin] += sum_r dY[r, co] * X[r+(tap-2)*N, ci]     (atomic accumulation)
  * R = T*N rows, N = segments per frame.
  */
 int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y,
                    int R, int N, int Cin, int Cout, void* stream);
-int dvae_conv5_dgrad(const float* dY, const float* Wp, float* dX,
-                     int R, int N, int Cin, int Cout, void* stream);
 int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp,
                      int R, int N, int Cin, int Cout, int split_k, void* stream);
 /* W[Cout][Cin][5] (torch layout, state_dict contract) -> Wp[5][Cout][Cin] */
 int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void* stream);
 /* Wpt[5][Cin][Cout]: the transposed pack; with it the data gradient reads BOTH operands k-contiguously (the faster
- * ds_read_b128 fragment path of the contraction kernel): dvae_conv5_dgrad_t == dvae_conv5_dgrad on the other layout. */
+ * ds_read_b128 fragment path of the contraction kernel). */
 int dvae_conv_pack_wt(const float* W, float* Wpt, int Cout, int Cin, void* stream);
 int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout, void* stream);
 /* dW[Cout][Cin][5] += dWp[5][Cout][Cin] */
@@ -239,10 +237,6 @@ int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
 int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
 /* experiments: register-only MFMA chains (shape 32 -> 32x32x2 f32, else 16x16x4 f32): the matrix-pipe ceiling of THIS chip */
 int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream);
-/* timeline of the last LSTM forward frame launched with DVAE_LSTM_DBG bit 8 set: 8 stamps per workgroup (s_memtime at
- * entry / first tile staged / first round computed / second tile staged / accumulators parked / reduced / done; slot 7 = wall clock). */
-int dvae_probe_lstm_timeline(unsigned long long* host_out, int n_words);
-
 #ifdef __cplusplus
 }
 #endif

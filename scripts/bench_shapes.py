@@ -40,7 +40,8 @@ for cin, cout, cnt in ((80, 512, 2), (512, 512, 8), (512, 80, 1)):
     tot += cnt * timeit(lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, cin, cout, stream()), ""),
                         fl, f"conv_fwd {cin}->{cout} x{cnt}")
     dx = torch.empty(R, cin, device=dev)
-    tot += cnt * timeit(lambda: check(L.dvae_conv5_dgrad(ptr(y), ptr(wp), ptr(dx), R, N, cin, cout, stream()), ""),
+    wpt = t(5, cin, cout)
+    tot += cnt * timeit(lambda: check(L.dvae_conv5_dgrad_t(ptr(y), ptr(wpt), ptr(dx), R, N, cin, cout, stream()), ""),
                         fl, f"conv_dgrad {cin}->{cout} x{cnt}")
     dwp = torch.zeros(5, cout, cin, device=dev)
     sk = ops._split_k(5 * ops._tiles(cout, cin), R)

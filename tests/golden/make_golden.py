@@ -16,7 +16,7 @@ Weights come from oracle/fill.py (deterministic by state_dict key), inputs from
 seeded NumPy streams, the three eps tensors from torch.manual_seed(seed) drawn in
 the reference's own order — they are recorded in the fixture.
 
-Usage:  python tests/golden/make_golden.py [steps|conversion|frontend]
+Usage:  python tests/golden/make_golden.py [steps[:case_name]|conversion|frontend|dataset]
 """
 import os
 import sys
@@ -48,6 +48,8 @@ CASES = [
     ("c0_b4_t64", 4, 64, 1234, 7),
     ("b3_t64", 3, 64, 4321, 11),
     ("b2_t128", 2, 128, 1234, 13),
+    # the benchmarked workload itself (BASELINE.json configs[1]): one reference step is ~9 s on 8 threads here
+    ("c1_b64_t128", 64, 128, 1234, 17),
 ]
 
 
@@ -203,12 +205,81 @@ def run_frontend_case():
     print("wrote", out, mel.shape, os.path.getsize(out))
 
 
+def run_dataset_case():
+    """Pairing / re-pairing / crop rule of the REAL SpeechDatasetGVAE (preprocessing/dataset.py:53-114), driven by the
+    global NumPy generator under np.random.seed on the BASELINE configs[0] corpus (2 speakers x 8 utterances [80, 96],
+    data.write_synthetic_corpus(seed=0)) plus one speaker whose utterances are SHORTER than the crop (right zero-pad
+    branch, :100-101).  os.listdir / glob.glob return sorted lists while the reference class is constructed (their
+    native order is the file system's, which no fixture can carry).  Recorded: the pair list after __init__ and after
+    shuffle_data() as (speaker index, utterance index) and, for every item, the crop offsets recovered from the
+    returned arrays plus their checksums."""
+    import glob as _glob
+    import tempfile
+    import preprocessing.dataset as pd_ref
+    from importlib import import_module
+    data = import_module("disentangle-vae-for-vc_amd.data")
+    T = 64
+    with tempfile.TemporaryDirectory() as root:
+        data.write_synthetic_corpus(root, n_speakers=2, n_utt=8, length=96, seed=0)
+        rs = np.random.RandomState(9)
+        d = os.path.join(root, "spk_short")
+        os.makedirs(d)
+        for u in range(5):                                    # odd count: the last utterance stays unpaired (:66-67)
+            np.save(os.path.join(d, f"utt{u:03d}_mel.npy"), rs.uniform(0, 1, size=(80, 40 + u)))
+        real_listdir, real_glob = os.listdir, _glob.glob
+        pd_ref.os.listdir = lambda p: sorted(real_listdir(p))
+        pd_ref.glob.glob = lambda p: sorted(real_glob(p))
+        try:
+            np.random.seed(2024)
+            ds = pd_ref.SpeechDatasetGVAE(root, samples_length=T)
+        finally:
+            pd_ref.os.listdir, pd_ref.glob.glob = real_listdir, real_glob
+
+        def ident(path):
+            spk = ds.speaker_ids.index(path.split("/")[-2])
+            return spk, int(os.path.basename(path)[3:6])
+
+        def snapshot():
+            pairs = np.array([[*ident(a), *ident(b)] for a, b in ds.utterance_fp])
+            offs, sums, labels = [], [], []
+            for i in range(len(ds)):
+                m1, m2, spk = ds[i]
+                labels.append(int(spk))
+                row = []
+                for m, path in ((m1, ds.utterance_fp[i, 0]), (m2, ds.utterance_fp[i, 1])):
+                    full = np.load(path)
+                    m = m.numpy()
+                    assert m.shape == (80, T)
+                    if full.shape[1] < T:
+                        assert np.array_equal(m[:, :full.shape[1]], full) and not m[:, full.shape[1]:].any()
+                        row.append(-1)
+                    else:
+                        hit = [o for o in range(full.shape[1] - T + 1) if np.array_equal(full[:, o:o + T], m)]
+                        assert len(hit) == 1
+                        row.append(hit[0])
+                    sums.append(float(m.sum()))
+                offs.append(row)
+            return pairs, np.array(offs), np.array(sums), np.array(labels)
+
+        p0, o0, s0, l0 = snapshot()
+        ds.shuffle_data()
+        p1, o1, s1, l1 = snapshot()
+        out = os.path.join(HERE, "dataset_pairs.npz")
+        np.savez_compressed(out, seed=2024, samples_length=T, speaker_ids=np.array(ds.speaker_ids),
+                            pairs_epoch0=p0, offsets_epoch0=o0, sums_epoch0=s0, labels_epoch0=l0,
+                            pairs_epoch1=p1, offsets_epoch1=o1, sums_epoch1=s1, labels_epoch1=l1)
+        print("wrote", out, p0.shape, o0.tolist())
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     if only in ("", "frontend"):
         run_frontend_case()
-    if only in ("", "steps"):
+    if only in ("", "steps") or only.startswith("steps:"):
         for c in CASES:
-            run_case(*c)
+            if ":" not in only or only.split(":", 1)[1] == c[0]:
+                run_case(*c)
     if only in ("", "conversion"):
         run_conversion_case()
+    if only in ("", "dataset"):
+        run_dataset_case()

@@ -122,9 +122,6 @@ def test_conv5(ops, N, T, Cin, Cout):
     check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(dev(b)), ptr(y), R, N, Cin, Cout, stream()), "fwd")
     close(from_frames(y.cpu(), N, T), y_ref, name="bf16 conv_fwd")
     gyf = dev(to_frames(gy))
-    dx = torch.empty(R, Cin, device="cuda")
-    check(L.dvae_conv5_dgrad(ptr(gyf), ptr(wp), ptr(dx), R, N, Cin, Cout, stream()), "dgrad")
-    close(from_frames(dx.cpu(), N, T), x.grad, name="bf16 conv_dgrad")
     wpt, dx2 = torch.empty(5, Cin, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
     check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
     check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, stream()), "dgrad_t")

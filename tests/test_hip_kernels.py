@@ -36,13 +36,16 @@ def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 72, 80), (16384, 512, 128), (8, 2048, 32), (130, 260, 516)])
+# (8192, 4096, 1024): 512 tiles of 256x256 -> the 16-wave 256x256x32 instantiation the benchmark's LSTM input
+# projections run (gemm.hip launch_gemm `big`)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 72, 80), (16384, 512, 128), (8, 2048, 32), (130, 260, 516),
+                                   (8192, 4096, 1024)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_nt_bias_act(ops, M, N, K, act):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
     y = torch.empty(M, N, device="cuda")
     ops.gemm(dev(x), dev(w), y, dev(b), M, N, K, K, K, N, True, True, act, ops.EPI_STORE, 1)
-    ref = x @ w.t() + b
+    ref = x.double() @ w.double().t() + b.double()
     ref = [ref, torch.relu(ref), torch.tanh(ref)][act]
     close(y, ref, name="gemm_nt")
 
@@ -66,7 +69,10 @@ def test_gemm_nn_dgrad(ops, M, N, K):
     close(dx, 2 * (dy.double() @ w.double()), name="gemm_nn_accum")
 
 
-@pytest.mark.parametrize("M,N,K,sk", [(256, 128, 512, 1), (80, 512, 1000, 4), (2048, 128, 16384, 8), (8, 2048, 6, 1)])
+# (4096, 1024, 16256, 8): dW_hh of an H=1024 layer at B=64/T=128 -> 16*4*8 = 512 tiles of 256x256 (the 16-wave
+# instantiation with atomic split-K); (2048, 16384, 128, 1): the enc_linear / dec_pre_linear2 outer products
+@pytest.mark.parametrize("M,N,K,sk", [(256, 128, 512, 1), (80, 512, 1000, 4), (2048, 128, 16384, 8), (8, 2048, 6, 1),
+                                      (4096, 1024, 16256, 8), (2048, 16384, 128, 1)])
 def test_gemm_tn_wgrad(ops, M, N, K, sk):
     dy, x = rnd(K, M, seed=6), rnd(K, N, seed=7)
     base = rnd(M, N, seed=8)
@@ -113,9 +119,6 @@ def test_conv5_fwd_dgrad_wgrad(ops, N, T, Cin, Cout):
     close(from_frames(y.cpu(), N, T), y_ref, name="conv_fwd")
 
     gyf = dev(to_frames(gy))
-    dx = torch.empty(R, Cin, device="cuda")
-    check(L.dvae_conv5_dgrad(ptr(gyf), ptr(wp), ptr(dx), R, N, Cin, Cout, stream()), "dgrad")
-    close(from_frames(dx.cpu(), N, T), x.grad, name="conv_dgrad")
     wpt, dx2 = torch.empty(5, Cin, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
     check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
     close(wpt, w.detach().permute(2, 1, 0), rel=0, name="pack_t")
@@ -191,8 +194,11 @@ def test_bn_residual(ops):
 
 
 # ------------------------------------------------------------------ LSTM
+# (128, 4, ., 1024) / (128, 4, ., 512): N >= 97 selects the 32-row eight-wave tiles the benchmark runs (lstm.hip
+# plan_seq: n_j * ceil(N/32) >= 256); H = 128 / 256 reach the generic LDS-staged frame kernels
 @pytest.mark.parametrize("N,T,In,H,bidir", [(8, 12, 512, 64, True), (128, 6, 128, 512, False), (6, 5, 512, 1024, False),
-                                            (20, 9, 128, 64, True)])
+                                            (20, 9, 128, 64, True), (128, 4, 512, 1024, False), (128, 4, 128, 512, True),
+                                            (20, 5, 64, 128, False), (20, 5, 96, 256, True), (33, 3, 512, 1024, False)])
 def test_lstm_layer(ops, N, T, In, H, bidir):
     ref = torch.nn.LSTM(In, H, 1, batch_first=True, bidirectional=bidir)
     x = rnd(N, T, In, seed=1)
@@ -214,6 +220,29 @@ def test_lstm_layer(ops, N, T, In, H, bidir):
         close(ps[i].grad, getattr(ref, n).grad, rel=5e-4, name=n)
         if bidir:
             close(ps[4 + i].grad, getattr(ref, n + "_reverse").grad, rel=5e-4, name=n + "_reverse")
+
+
+@pytest.mark.parametrize("N,T,In,H", [(128, 8, 512, 1024), (6, 4, 512, 1024), (128, 4, 128, 512), (40, 6, 64, 512)])
+def test_lstm_stack2(ops, N, T, In, H):
+    """ops.LstmStack2Fn (two stacked layers sharing frame launches, the dec_lstm2 schedule of the benchmark) against a
+    2-layer nn.LSTM.  N = 128 at H = 1024 is the benchmarked instantiation (32-row tiles, 64-deep stacked forward)."""
+    assert ops.LstmStack2Fn.usable(T, H, 2, False)
+    ref = torch.nn.LSTM(In, H, 2, batch_first=True)
+    x = rnd(N, T, In, seed=1)
+    xr = x.clone().requires_grad_()
+    out_ref, _ = ref(xr)
+    gy = rnd(N, T, H, seed=2)
+    out_ref.backward(gy)
+    P = lambda t: torch.nn.Parameter(dev(t.detach().clone()))
+    names = [f"{n}_l{l}" for l in (0, 1) for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+    ps = [P(getattr(ref, n)) for n in names]
+    xf = dev(x.permute(1, 0, 2).reshape(T * N, In)).requires_grad_()
+    h = ops.LstmStack2Fn.apply(xf, T, N, *ps)
+    close(h.detach().cpu().reshape(T, N, -1).permute(1, 0, 2), out_ref, name="stack2_fwd")
+    h.backward(dev(gy.permute(1, 0, 2).reshape(T * N, -1)))
+    close(xf.grad.cpu().reshape(T, N, In).permute(1, 0, 2), xr.grad, rel=5e-4, name="stack2_dx")
+    for i, n in enumerate(names):
+        close(ps[i].grad, getattr(ref, n).grad, rel=5e-4, name=n)
 
 
 # ------------------------------------------------------------------ Linear

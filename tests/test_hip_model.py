@@ -37,7 +37,7 @@ def is_prebn_conv_bias(name):
     return name.endswith(".0.conv.bias") or (name.startswith("dec_modules.") and name.endswith(".0.bias"))
 
 
-@pytest.mark.parametrize("name", ["c0_b4_t64", "b3_t64", "b2_t128"])
+@pytest.mark.parametrize("name", ["c0_b4_t64", "b3_t64", "b2_t128", "c1_b64_t128"])
 def test_against_reference_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     B, T = int(g["batch"]), int(g["n_frames"])
@@ -76,7 +76,7 @@ def test_against_reference_golden(golden_dir, name):
             np.testing.assert_allclose(v, g[k], rtol=2e-4, atol=1e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["c0_b4_t64", "b2_t128"])
+@pytest.mark.parametrize("name", ["c0_b4_t64", "b2_t128", "c1_b64_t128"])
 def test_two_steps_against_reference_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     B, T = int(g["batch"]), int(g["n_frames"])

@@ -101,6 +101,91 @@ def test_dataset_pairs_same_speaker_and_crops(tmp_path):
     assert ds_eq[0][0].shape == (80, 96)
 
 
+def test_dataset_against_reference_fixture(tmp_path, golden_dir):
+    """data.SpeechDatasetGVAE vs the REAL preprocessing/dataset.py:53-114 class (tests/golden/make_golden.py dataset):
+    same corpus, same np.random seed on the global generator -> same pair list after construction and after
+    shuffle_data(), same crop offsets in item order (incl. the right zero-pad branch and an odd utterance count)."""
+    from dvae_amd.data import SpeechDatasetGVAE, write_synthetic_corpus
+    g = np.load(os.path.join(golden_dir, "dataset_pairs.npz"))
+    T = int(g["samples_length"])
+    root = write_synthetic_corpus(str(tmp_path / "corpus"), n_speakers=2, n_utt=8, length=96, seed=0)
+    rs = np.random.RandomState(9)
+    os.makedirs(os.path.join(root, "spk_short"))
+    for u in range(5):
+        np.save(os.path.join(root, "spk_short", f"utt{u:03d}_mel.npy"), rs.uniform(0, 1, size=(80, 40 + u)))
+    np.random.seed(int(g["seed"]))
+    ds = SpeechDatasetGVAE(root, samples_length=T)          # seed=None: draws from the global generator, as the reference
+    assert ds.speaker_ids == list(g["speaker_ids"])
+
+    def check(tag):
+        pairs = g["pairs_" + tag]
+        assert len(ds) == len(pairs)
+        got = [[ds.speaker_ids.index(p.split("/")[-2]), int(os.path.basename(p)[3:6])] for row in ds.utterance_fp
+               for p in row]
+        assert np.array_equal(np.array(got).reshape(-1, 4), pairs)
+        sums = []
+        for i in range(len(ds)):
+            m1, m2, spk = ds[i]
+            assert int(spk) == int(g["labels_" + tag][i])
+            for m, path, off in ((m1, ds.utterance_fp[i][0], g["offsets_" + tag][i][0]),
+                                 (m2, ds.utterance_fp[i][1], g["offsets_" + tag][i][1])):
+                full = np.load(path)
+                want = np.pad(full, ((0, 0), (0, T - full.shape[1]))) if off < 0 else full[:, off:off + T]
+                assert np.array_equal(m.numpy(), want), (tag, i, off)
+                sums.append(float(m.sum()))
+        np.testing.assert_allclose(np.array(sums), g["sums_" + tag], rtol=1e-12)
+
+    check("epoch0")
+    ds.shuffle_data()
+    check("epoch1")
+
+
+def test_init_matches_reference_init_weights():
+    """init_weights (disentangled_vae.py:26-32, applied :195): every Linear xavier-uniform with bias 0.01, every Conv1d
+    xavier-uniform with bias 0; LSTMs keep torch's default U(-1/sqrt(H), 1/sqrt(H)); BatchNorm gamma 1 / beta 0 /
+    running stats (0, 1, 0)."""
+    import math
+    import dvae_amd
+    torch.manual_seed(0)
+    m = dvae_amd.DisentangledVAE(speaker_size=4, latent_dim=32, batch_size=4)
+    n_lin = n_conv = n_lstm = n_bn = 0
+    for name, p in m.named_parameters():
+        if "lstm" in name:
+            H = p.shape[0] // 4
+            b = 1.0 / math.sqrt(H)
+            p = p.detach()
+            assert float(p.abs().max()) <= b * (1 + 1e-6) and float(p.abs().max()) > 0.9 * b, name
+            if p.numel() >= 4096:                             # uniform, not e.g. normal clipped to the bound
+                assert abs(float(p.mean())) < 0.05 * b and abs(float(p.std()) - b / math.sqrt(3)) < 0.05 * b, name
+            n_lstm += 1
+        elif name.endswith(".1.weight"):                      # BatchNorm gamma
+            assert torch.equal(p.detach(), torch.ones_like(p)), name
+            n_bn += 1
+        elif name.endswith(".1.bias"):
+            assert torch.equal(p.detach(), torch.zeros_like(p)), name
+        elif p.dim() == 3:                                    # Conv1d weight [Cout, Cin, 5]
+            fan_in, fan_out = p.shape[1] * p.shape[2], p.shape[0] * p.shape[2]
+            bound = math.sqrt(6.0 / (fan_in + fan_out))
+            p = p.detach()
+            assert float(p.abs().max()) <= bound * (1 + 1e-6) and float(p.abs().max()) > 0.95 * bound, name
+            assert abs(float(p.std()) - bound / math.sqrt(3)) < 0.03 * bound, name
+            n_conv += 1
+        elif p.dim() == 2:                                    # Linear weight [out, in]
+            bound = math.sqrt(6.0 / (p.shape[0] + p.shape[1]))
+            p = p.detach()
+            assert float(p.abs().max()) <= bound * (1 + 1e-6) and float(p.abs().max()) > 0.9 * bound, name
+            assert abs(float(p.std()) - bound / math.sqrt(3)) < 0.05 * bound, name
+            n_lin += 1
+        elif "conv" in name or name.startswith("dec_modules"):   # Conv1d bias
+            assert torch.equal(p.detach(), torch.zeros_like(p)), name
+        else:                                                  # Linear bias
+            assert torch.equal(p.detach(), torch.full_like(p, 0.01)), name
+    assert (n_lin, n_conv, n_lstm, n_bn) == (6, 11, 28, 11)
+    for name, b in m.named_buffers():
+        want = 1.0 if name.endswith("running_var") else 0.0
+        assert float(b.float().abs().max() if want == 0.0 else (b - 1).abs().max()) == 0.0, name
+
+
 def test_load_last_model_picks_latest(tmp_path):
     import dvae_amd
     from dvae_amd.model.variational_base_vae import VariationalBaseModelVAE

@@ -9,7 +9,8 @@ import torch
 from oracle.dvae_ref import RefTrainer, loss_gvae2
 from oracle.fill import fill_state_dict, synthetic_pair
 
-CASES = ["c0_b4_t64", "b3_t64", "b2_t128"]
+# c1_b64_t128 is the benchmarked workload itself (BASELINE.json configs[1]); one oracle step is ~10 s on 8 threads
+CASES = ["c0_b4_t64", "b3_t64", "b2_t128", "c1_b64_t128"]
 FW = ["recons_x1", "recons_x2", "recons_x1_hat", "recons_x2_hat", "q_z1_mu", "q_z1_logvar",
       "q_z2_mu", "q_z2_logvar", "z_style_mu", "z_style_logvar"]
 
