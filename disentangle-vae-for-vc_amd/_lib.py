@@ -25,16 +25,21 @@ class LstmDir(C.Structure):
                 ("step_shift", i32), ("pad_", i32)]
 
 
+# DVAE_MODE_* of include/dvae_hip.h
+MODE_F32, MODE_BF16, MODE_F32X3 = 0, 1, 2
+COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16,
+                 "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
+
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
     "dvae_version": (i32, []),
     "dvae_last_hip_error": (i32, []),
-    "dvae_gemm_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
-    "dvae_conv5_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
-    "dvae_conv5_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_gemm_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv5_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv5_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_conv_pack_w": (i32, [vp, vp, i32, i32, vp]),
     "dvae_conv_pack_wt": (i32, [vp, vp, i32, i32, vp]),
-    "dvae_conv5_dgrad_t": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "dvae_conv5_dgrad_t": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dvae_conv_unpack_add_w": (i32, [vp, vp, i32, i32, vp]),
     "dvae_bn_ws_bytes": (i64, [i32, i32, i32]),
     "dvae_bn_stats_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
@@ -104,9 +109,11 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = h
-        mode = os.environ.get("DVAE_COMPUTE_DTYPE", "").lower()
-        if mode in ("bf16", "bfloat16"):     # same as ops.set_compute_dtype("bf16"), for scripts
-            h.dvae_set_compute_mode(1)
+        mode = os.environ.get("DVAE_COMPUTE_DTYPE", "").lower()   # same as ops.set_compute_dtype(...), for scripts
+        if mode in COMPUTE_MODES:
+            h.dvae_set_compute_mode(COMPUTE_MODES[mode])
+        elif mode:
+            raise RuntimeError(f"DVAE_COMPUTE_DTYPE={mode!r}: expected one of {sorted(COMPUTE_MODES)}")
     return _lib
 
 

@@ -24,7 +24,7 @@
 #include <type_traits>
 #include "common.h"
 
-int g_dvae_compute_mode = 0;   // 0: fp32 MFMA; 1: bf16 operands / fp32 accumulation (dvae_set_compute_mode)
+int g_dvae_compute_mode = 0;   // process default of the contraction mode (DVAE_MODE_*, dvae_set_compute_mode)
 
 #ifdef DVAE_GEMM_TS
 // Development probe (build with -DDVAE_GEMM_TS): wave 0 of every workgroup measures the s_memtime cycles of its whole
@@ -36,6 +36,26 @@ __device__ unsigned long long g_gemm_ts[1024 * 8];
 __device__ __attribute__((aligned(16))) float g_gemm_zero[4] = {0.f, 0.f, 0.f, 0.f};   // what masked lanes load
 
 namespace {
+
+// x[0..7] (fp32) -> three bf16x8 with x[i] == p[0][i] + p[1][i] + p[2][i] exactly (see the X3 note at the kernel):
+// round to nearest-even twice (v_cvt_pk_bf16_f32 packs two values per instruction), the last residual has <= 8
+// significant bits and converts exactly.
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&p)[3]) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = {x[2 * i], x[2 * i + 1]};
+    const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(h1, f32x2);
+    const bf16x2 h2 = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(h2, f32x2);
+    const bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
+    p[0][2 * i] = h1[0]; p[0][2 * i + 1] = h1[1];
+    p[1][2 * i] = h2[0]; p[1][2 * i + 1] = h2[1];
+    p[2][2 * i] = h3[0]; p[2][2 * i + 1] = h3[1];
+  }
+}
 
 // Workgroup = WG x WG waves (WG = 2: 128 x 64*NTW tile, 256 threads; WG = 4: 256 x 128*NTW tile, 1024 threads).
 // The large tile halves the global-load instructions per MFMA (measured: loads cost ~15 % of the small tile's time).
@@ -65,9 +85,20 @@ struct GemmParams {
 // fp32 accumulation.  Images: k-contiguous [rows][BK + 8] bf16 (80-B rows: conflict-free ds_read_b128 of 8 k values);
 // row-contiguous [BK][rows + 32] bf16 read with ds_read_b64_tr_b16 (the hardware transpose delivers 4 consecutive k
 // of one row per lane; 320-B / 192-B k-rows put the 4 k-rows of a read in 4 different 64-B bank quadrants).
-template <bool A_KC, bool B_KC, int NTW, int BK, int WG, bool BF = false>
+//
+// X3 = "fp32 on the bf16 matrix pipe" (dvae_set_compute_mode(2)): the fp32 MFMA runs at the VALU rate (157 TFLOP/s),
+// 1/16 of the bf16 MFMA.  Every fp32 operand x is split EXACTLY into three bf16 terms, x = x1 + x2 + x3 (x1 = rne(x),
+// x2 = rne(x - x1), x3 = x - x1 - x2: 3 x 8 significand bits + the sign of each residual cover all 24 bits of x), and
+// a product a*b is evaluated as the six partial products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, each EXACT in fp32
+// (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms are <= 2^-24 |ab| together
+// — below the rounding of one fp32 FMA — so the result is an fp32 contraction with a different summation order, at
+// 6/16 of the fp32-MFMA cost.  Images stay fp32 in LDS (same staging as MODE 0); the split runs in registers on the
+// fragment a lane has just read (~5.5 VALU operations per element, hidden under the 6 MFMAs per fragment pair).
+template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
+  constexpr bool BF = (MODE == 1), X3 = (MODE == 2);
   static_assert(!BF || (BK == 32 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
+  static_assert(!X3 || WG == 2, "split mode: 128 x 64*NTW tile only");
   constexpr int BM = 64 * WG, NTHR = 64 * WG * WG;
   constexpr int BN = 32 * NTW * WG;      // NTW = 32-wide n-tiles per wave
   constexpr int LD_KC = BF ? BK + 8 : BK + 4;          // row stride of a k-contiguous image
@@ -325,6 +356,52 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
           acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][1], bv[s2][nt], acc[1][nt], 0, 0, 0);
         }
       __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (X3) {
+      // lane (r = lane&31, h = lane>>5) of v_mfma_f32_32x32x16_bf16 holds k = 16s + 8h + j, j = 0..7, of row r: eight
+      // fp32 values from the image (two ds_read_b128 of a k-contiguous image, row stride BK+4 floats: conflict-free for
+      // the 16-lane groups; eight ds_read_b32 of a row-contiguous one), split into three bf16x8 fragments.
+      auto read8 = [&](const float* img, bool kc, int ld, int row0, int s2, float (&x)[8]) {
+        if (kc) {
+          const float* q0 = &img[(row0 + l31) * ld + 16 * s2 + 8 * kh];
+          const f32x4 u = *reinterpret_cast<const f32x4*>(q0), v = *reinterpret_cast<const f32x4*>(q0 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { x[e] = u[e]; x[4 + e] = v[e]; }
+        } else {
+          const float* q0 = &img[(16 * s2 + 8 * kh) * ld + row0 + l31];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = q0[e * ld];
+        }
+      };
+      constexpr int NS = BK / 16;
+      float xa[2][8], xb[NTW][8];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) read8(&As[cur][0], A_KC, LDA, wm * 64 + mt * 32, 0, xa[mt]);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) read8(&Bs[cur][0], B_KC, LDB, wn * 32 * NTW + nt * 32, 0, xb[nt]);
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        bf16x8 pa[2][3], pb[NTW][3];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) split3(xa[mt], pa[mt]);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) split3(xb[nt], pb[nt]);
+        if (s2 + 1 < NS) {   // next step's raw fragment: its LDS latency runs under this step's MFMAs
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) read8(&As[cur][0], A_KC, LDA, wm * 64 + mt * 32, s2 + 1, xa[mt]);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) read8(&Bs[cur][0], B_KC, LDB, wn * 32 * NTW + nt * 32, s2 + 1, xb[nt]);
+        }
+        // smallest partial products first
+#pragma unroll
+        for (int term = 0; term < 6; ++term) {
+          constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0][ia[term]], pb[nt][ib[term]], acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1][ia[term]], pb[nt][ib[term]], acc[1][nt], 0, 0, 0);
+          }
+        }
+      }
     } else {
     // ---- fragments in 8-deep k groups: group c, element e <-> k = 8c + 4*kh + e.  The reads of group c+1 are
     // issued BEFORE the 4*2*NTW MFMAs of group c (two register sets, order pinned with sched_barrier), so the LDS
@@ -436,10 +513,20 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 }
 
 template <bool AK, bool BKC>
-void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, bool big) {
-  if (g_dvae_compute_mode == 1) {   // bf16 operands, fp32 accumulation
-    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2, true>), grid, dim3(256), 0, s, p);
+void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, bool big, int mode) {
+  if (mode == DVAE_MODE_BF16) {   // bf16 operands, fp32 accumulation
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2, 1>), grid, dim3(256), 0, s, p);
+    return;
+  }
+  if (mode == DVAE_MODE_F32X3) {  // fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product
+    if (bk == 32) {
+      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2, 2>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2, 2>), grid, dim3(256), 0, s, p);
+    } else {
+      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, 2, 2>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, 2, 2>), grid, dim3(256), 0, s, p);
+    }
     return;
   }
   if (big) {   // 256 x 256 x 32 tile, 16 waves
@@ -456,7 +543,9 @@ void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, 
   }
 }
 
-int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
+int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
+  if (mode == DVAE_MODE_DEFAULT) mode = g_dvae_compute_mode;
+  if (mode != DVAE_MODE_F32 && mode != DVAE_MODE_BF16 && mode != DVAE_MODE_F32X3) return DVAE_EINVAL;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return DVAE_EINVAL;
   if (!p.A || !p.B || !p.C) return DVAE_EINVAL;
   if ((p.lda & 3) || (p.ldb & 3)) return DVAE_EINVAL;
@@ -475,7 +564,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   // 32-deep tiles: the last split takes what is left)
   int bk = ((kps % 32 == 0 && kps >= 64) || (p.split_k > 1 && kps >= 512)) ? 32 : 16;
   if (bk_env == 16 || bk_env == 32) bk = bk_env;
-  const bool bf = (g_dvae_compute_mode == 1);
+  const bool bf = (mode == DVAE_MODE_BF16);
   if (bf) bk = 32;                       // the bf16 kernel has one k-tile; ragged tails are zero-filled
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
@@ -486,7 +575,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
   bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0);
   if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0);
-  if (bf) big = false;
+  if (mode != DVAE_MODE_F32) big = false;   // the 16-wave tile exists for the fp32 MFMA only (128 registers per lane)
   const int bm = big ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
   // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
@@ -499,13 +588,13 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, hipStream_t s) {
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * (p.tap_mode ? p.taps : 1));
   if (a_kc && b_kc)
-    launch_variant<true, true>(p, grid, s, narrow, bk, big);
+    launch_variant<true, true>(p, grid, s, narrow, bk, big, mode);
   else if (a_kc && !b_kc)
-    launch_variant<true, false>(p, grid, s, narrow, bk, big);
+    launch_variant<true, false>(p, grid, s, narrow, bk, big, mode);
   else if (!a_kc && b_kc)
-    launch_variant<false, true>(p, grid, s, narrow, bk, big);
+    launch_variant<false, true>(p, grid, s, narrow, bk, big, mode);
   else
-    launch_variant<false, false>(p, grid, s, narrow, bk, big);
+    launch_variant<false, false>(p, grid, s, narrow, bk, big, mode);
   return dvae_check_launch();
 }
 
@@ -519,7 +608,7 @@ DVAE_API int dvae_probe_gemm_timeline(unsigned long long* host_out, int n_words)
 #endif
 
 DVAE_API int dvae_set_compute_mode(int mode) {
-  if (mode != 0 && mode != 1) return DVAE_EINVAL;
+  if (mode != DVAE_MODE_F32 && mode != DVAE_MODE_BF16 && mode != DVAE_MODE_F32X3) return DVAE_EINVAL;
   g_dvae_compute_mode = mode;
   return DVAE_OK;
 }
@@ -527,18 +616,18 @@ DVAE_API int dvae_get_compute_mode(void) { return g_dvae_compute_mode; }
 
 DVAE_API int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int act,
-                           int epi, int split_k, void* stream) {
+                           int epi, int split_k, int mode, void* stream) {
   GemmParams p{};
   p.A = A; p.B = B; p.C = C; p.bias = bias;
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.taps = 1; p.tap_mode = 0;
   p.split_k = split_k; p.act = act; p.epi = epi;
-  return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, (hipStream_t)stream);
+  return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
 }
 
 DVAE_API int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y, int R, int N,
-                            int Cin, int Cout, void* stream) {
+                            int Cin, int Cout, int mode, void* stream) {
   GemmParams p{};
   p.A = X; p.B = Wp; p.C = Y; p.bias = bias;
   p.M = R; p.N = Cout; p.K = Cin;
@@ -546,12 +635,12 @@ DVAE_API int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, 
   p.taps = 5; p.tap_mode = 1;
   p.a_row_shift = N; p.b_tap_stride = (int64_t)Cout * Cin;
   p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
-  return launch_gemm(p, true, true, (hipStream_t)stream);
+  return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 
 // data gradient: the weights packed as Wpt[5][Cin][Cout] (dvae_conv_pack_wt): both operands k-contiguous
 DVAE_API int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout,
-                                void* stream) {
+                                int mode, void* stream) {
   GemmParams p{};
   p.A = dY; p.B = Wpt; p.C = dX; p.bias = nullptr;
   p.M = R; p.N = Cin; p.K = Cout;
@@ -559,11 +648,11 @@ DVAE_API int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, in
   p.taps = 5; p.tap_mode = 1;
   p.a_row_shift = -(int64_t)N; p.b_tap_stride = (int64_t)Cout * Cin;
   p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
-  return launch_gemm(p, true, true, (hipStream_t)stream);
+  return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 
 DVAE_API int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp, int R, int N, int Cin, int Cout,
-                              int split_k, void* stream) {
+                              int split_k, int mode, void* stream) {
   GemmParams p{};
   p.A = dY; p.B = X; p.C = dWp; p.bias = nullptr;
   p.M = Cout; p.N = Cin; p.K = R;
@@ -571,5 +660,5 @@ DVAE_API int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp, int R
   p.taps = 5; p.tap_mode = 2;
   p.bk_row_shift = N; p.c_tap_stride = (int64_t)Cout * Cin;
   p.split_k = split_k; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_ATOMIC;
-  return launch_gemm(p, false, false, (hipStream_t)stream);
+  return launch_gemm(p, false, false, mode, (hipStream_t)stream);
 }

@@ -68,6 +68,7 @@ class MelFrontend:
         melw[:, :nb] = np.maximum(0.0, np.minimum(lower, upper)) * (2.0 / (mel_f[2:] - mel_f[:-2]))[:, None]
         f32 = lambda a: torch.from_numpy(a.astype(np.float32)).to(self.device).contiguous()
         self.window, self.dft_basis, self.mel_basis = f32(win), f32(basis), f32(melw)
+        self.mode = ops.MODE_F32
 
     # ---- utils.py:82-103
     def num_frames(self, length: int) -> int:
@@ -90,10 +91,12 @@ class MelFrontend:
             check(L.dvae_stft_frames(ptr(s), s.numel(), ptr(self.window), frames[r:].data_ptr(), m, self.fsize,
                                      self.hop, self.fsize - self.hop, stream()), "dvae_stft_frames")
             r += m
-        reim = ops.linear_fwd(frames, self.dft_basis, None)                  # [rows, 2*nbp]
+        # features must not depend on the training compute mode (bf16 would put a leakage floor ~50 dB under each frame's
+        # peak against a 100 dB normalisation range): both contractions are pinned to exact fp32 products
+        reim = ops.linear_fwd(frames, self.dft_basis, None, mode=self.mode)  # [rows, 2*nbp]
         mag = torch.empty((rows, self.nbp), device=self.device, dtype=torch.float32)
         check(L.dvae_stft_magnitude(ptr(reim), ptr(mag), rows, self.nbp, stream()), "dvae_stft_magnitude")
-        mel = ops.linear_fwd(mag, self.mel_basis, None)                      # [rows, 80]
+        mel = ops.linear_fwd(mag, self.mel_basis, None, mode=self.mode)      # [rows, 80]
         outs, r = [], 0
         for m in ms:
             out = torch.empty((self.n_mels, m), device=self.device, dtype=torch.float32)

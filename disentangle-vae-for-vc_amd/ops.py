@@ -134,18 +134,35 @@ def _tiles(m, n):
 
 
 # ----------------------------------------------------------------------------- compute mode
+MODE_F32, MODE_BF16, MODE_F32X3 = _lib.MODE_F32, _lib.MODE_BF16, _lib.MODE_F32X3
+_MODE_NAMES = {MODE_F32: "fp32", MODE_BF16: "bf16", MODE_F32X3: "fp32x3"}
+
+
 def set_compute_dtype(name: str):
-    """"fp32" (default; BASELINE configs[1]/[3]) or "bf16" (configs[2]/[4]): operands of every contraction — Linear,
-    Conv1d, LSTM input projection and recurrence, all weight gradients — are rounded to bf16 on their way into the
-    matrix cores and accumulated in fp32; tensors in HBM, BatchNorm, gates, losses, master weights and Adam stay fp32."""
-    modes = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
-    if name not in modes:
-        raise ValueError(f"compute dtype {name!r}: expected 'fp32' or 'bf16'")
-    check(lib().dvae_set_compute_mode(modes[name]), "dvae_set_compute_mode")
+    """Arithmetic of every contraction (Linear, Conv1d, LSTM input projection and recurrence, all weight gradients):
+    "fp32"    fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32; runs at the vector rate);
+    "fp32x3"  fp32 RESULTS on the bf16 matrix pipe: operands split exactly into three bf16 terms, six exact partial
+              products per product, fp32 accumulation (include/dvae_hip.h, DVAE_MODE_F32X3) — BASELINE configs[1]/[3];
+    "bf16"    operands rounded to bf16, fp32 accumulation — BASELINE configs[2]/[4].
+    Tensors in HBM, BatchNorm, gates, losses, master weights and Adam are fp32 in every mode.  The mode in force when
+    an op's FORWARD runs is recorded in its autograd context and used by its backward launches too."""
+    if name not in _lib.COMPUTE_MODES:
+        raise ValueError(f"compute dtype {name!r}: expected one of {sorted(_lib.COMPUTE_MODES)}")
+    check(lib().dvae_set_compute_mode(_lib.COMPUTE_MODES[name]), "dvae_set_compute_mode")
+
+
+def current_mode() -> int:
+    return lib().dvae_get_compute_mode()
 
 
 def get_compute_dtype() -> str:
-    return "bf16" if lib().dvae_get_compute_mode() == 1 else "fp32"
+    return _MODE_NAMES[current_mode()]
+
+
+def _mode(mode):
+    if mode is None:
+        return current_mode()
+    return _lib.COMPUTE_MODES[mode] if isinstance(mode, str) else int(mode)
 
 
 class compute_dtype:
@@ -163,12 +180,14 @@ class compute_dtype:
 
 
 # ----------------------------------------------------------------------------- raw launches
-def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi=EPI_STORE, split_k=1):
-    check(lib().dvae_gemm_f32(ptr(A), ptr(B), ptr(Cout), ptr(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),
-                              act, epi, split_k, stream()), "dvae_gemm_f32")
+def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi=EPI_STORE, split_k=1, mode=None):
+    """A, B, Cout, bias: tensors or raw device addresses (ints)."""
+    a = lambda t: t if (t is None or isinstance(t, int)) else t.data_ptr()
+    check(lib().dvae_gemm_f32(a(A), a(B), a(Cout), a(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),
+                              act, epi, split_k, _mode(mode), stream()), "dvae_gemm_f32")
 
 
-def linear_fwd(x, w, b, act=ACT_NONE):
+def linear_fwd(x, w, b, act=ACT_NONE, mode=None):
     """y[M,Nout] = act(x[M,K] @ w[Nout,K]^T + b)"""
     M, K = x.shape
     Nout = w.shape[0]
@@ -176,29 +195,29 @@ def linear_fwd(x, w, b, act=ACT_NONE):
     sk = _split_k(_tiles(M, Nout), K)
     if sk > 1:
         y.zero_()
-        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, ACT_NONE, EPI_ATOMIC, sk)
+        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, ACT_NONE, EPI_ATOMIC, sk, mode)
         if act != ACT_NONE:
             check(lib().dvae_act_fwd(ptr(y), y.numel(), act, stream()), "dvae_act_fwd")
     else:
-        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, act, EPI_STORE, 1)
+        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, act, EPI_STORE, 1, mode)
     return y
 
 
-def linear_dgrad(dy, w):
+def linear_dgrad(dy, w, mode=None):
     """dx[M,K] = dy[M,Nout] @ w[Nout,K]"""
     M, Nout = dy.shape
     K = w.shape[1]
     sk = _split_k(_tiles(M, K), Nout)
     if sk > 1:
         dx = torch.zeros((M, K), device=dy.device, dtype=torch.float32)
-        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, ACT_NONE, EPI_ATOMIC, sk)
+        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, ACT_NONE, EPI_ATOMIC, sk, mode)
     else:
         dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
-        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False)
+        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, mode=mode)
     return dx
 
 
-def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None):
+def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None, mode=None):
     """wgrad[Nout,K] += dy[rows,Nout]^T @ x[rows,K] (atomic accumulation, split over rows)"""
     Nout, K = wgrad.shape
     rows = dy.shape[0] if rows is None else rows
@@ -207,7 +226,7 @@ def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None):
     sk = _split_k(_tiles(Nout, K), rows)
     # one split: every element has one writer, a plain read-modify-write (coalesced 128-B rows) replaces the atomics
     epi = EPI_ATOMIC if (sk > 1 or os.environ.get("DVAE_WGRAD_ATOMIC") == "1") else EPI_ACCUM
-    gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, epi, sk)
+    gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, epi, sk, mode)
 
 
 def colsum_add(x, out1, out2=None, rows=None, cols=None, ld=None):
@@ -241,7 +260,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, act):
         _ok(x, weight, bias)
-        y = linear_fwd(x, weight, bias, act)
+        ctx.mode = current_mode()
+        y = linear_fwd(x, weight, bias, act, ctx.mode)
         ctx.save_for_backward(x, weight, bias, y if act != ACT_NONE else None)
         ctx.act = act
         return y
@@ -254,9 +274,9 @@ class LinearFn(torch.autograd.Function):
             du = torch.empty_like(dy)
             check(lib().dvae_act_bwd(ptr(dy), ptr(y), ptr(du), dy.numel(), ctx.act, stream()), "dvae_act_bwd")
             dy = du
-        dx = linear_dgrad(dy, weight) if ctx.needs_input_grad[0] else None
+        dx = linear_dgrad(dy, weight, ctx.mode) if ctx.needs_input_grad[0] else None
         with side_work(dy, x):
-            linear_wgrad_acc(dy, x, _grad_buf(weight))
+            linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode)
             colsum_add(dy, _grad_buf(bias))
         _ready(weight, bias)
         return dx, None, None, None
@@ -276,10 +296,11 @@ class ConvBnActFn(torch.autograd.Function):
         Cout = conv_w.shape[0]
         dev = x.device
         st = stream()
+        mode = current_mode()
         wp = torch.empty((5, Cout, Cin), device=dev, dtype=torch.float32)
         check(L.dvae_conv_pack_w(ptr(conv_w), ptr(wp), Cout, Cin, st), "dvae_conv_pack_w")
         y = torch.empty((R, Cout), device=dev, dtype=torch.float32)
-        check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, st), "dvae_conv5_fwd")
+        check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, st), "dvae_conv5_fwd")
         if training:
             G = groups
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
@@ -295,13 +316,13 @@ class ConvBnActFn(torch.autograd.Function):
         check(L.dvae_bn_apply_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(bn_w), ptr(bn_b), ptr(residual), ptr(z),
                                   R, n_seg, Cout, G, act, st), "dvae_bn_apply_fwd")
         ctx.save_for_backward(x, wp, y, z, mean, rstd, conv_w, conv_b, bn_w, bn_b)
-        ctx.cfg = (n_seg, G, act, training, residual is not None)
+        ctx.cfg = (n_seg, G, act, training, residual is not None, mode)
         return z
 
     @staticmethod
     def backward(ctx, dz):
         x, wp, y, z, mean, rstd, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
-        n_seg, G, act, training, has_res = ctx.cfg
+        n_seg, G, act, training, has_res, mode = ctx.cfg
         if not training:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the training path")
         L = lib()
@@ -324,12 +345,14 @@ class ConvBnActFn(torch.autograd.Function):
             # k-contiguous (the ds_read_b128 fragment path: 370 -> 330 us per 512->512 layer; the pack costs ~6 us)
             wpt = torch.empty((5, Cin, Cout), device=dev, dtype=torch.float32)
             check(L.dvae_conv_pack_wt(ptr(conv_w), ptr(wpt), Cout, Cin, st), "dvae_conv_pack_wt")
-            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, st), "dvae_conv5_dgrad_t")
+            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, mode, st),
+                  "dvae_conv5_dgrad_t")
         with side_work(dy, x):
             st2 = stream()
             dwp = torch.zeros((5, Cout, Cin), device=dev, dtype=torch.float32)
             sk = _split_k(5 * _tiles(Cout, Cin), R)
-            check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(dwp), R, n_seg, Cin, Cout, sk, st2), "dvae_conv5_wgrad")
+            check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(dwp), R, n_seg, Cin, Cout, sk, mode, st2),
+                  "dvae_conv5_wgrad")
             check(L.dvae_conv_unpack_add_w(ptr(dwp), ptr(_grad_buf(conv_w)), Cout, Cin, st2),
                   "dvae_conv_unpack_add_w")
             colsum_add(dy, _grad_buf(conv_b))
@@ -358,11 +381,13 @@ class LstmLayerFn(torch.autograd.Function):
         dirs = (_lib.LstmDir * ndir)()
         # bf16 compute mode: the recurrence runs on bf16 fragments where bf16 frame kernels exist (H = 512, 1024);
         # the H = 64 encoder recurrence (3 % of the FLOPs, weights resident in registers) stays fp32
-        bf = 1 if (get_compute_dtype() == "bf16" and H % 512 == 0) else 0
+        # (fp32x3 mode: the recurrence runs on the fp32 MFMA — it is bound by W_hh traffic, not by the matrix pipe)
+        mode = current_mode()
+        bf = 1 if (mode == MODE_BF16 and H % 512 == 0) else 0
         gates, cells, packs_b, keep = [], [], [], []
         for d, (wi, wh, bi, bh) in enumerate(params):
             g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
-            gemm(x, wi, g, bi + bh, R, 4 * H, In, In, In, 4 * H, True, True)
+            gemm(x, wi, g, bi + bh, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
             c = torch.empty((R, H), device=dev, dtype=torch.float32)
             # W_hh re-packed in MFMA fragment order (forward copy used now, backward copy saved)
             wp_f = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
@@ -384,13 +409,13 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].reverse = d
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
         ctx.save_for_backward(x, h_out, *gates, *cells, *packs_b, *[p for ps in params for p in ps])
-        ctx.cfg = (T, N, H, ndir, bf)
+        ctx.cfg = (T, N, H, ndir, bf, mode)
         del keep
         return h_out
 
     @staticmethod
     def backward(ctx, dh):
-        T, N, H, ndir, bf = ctx.cfg
+        T, N, H, ndir, bf, mode = ctx.cfg
         sv = ctx.saved_tensors
         x, h_out = sv[0], sv[1]
         gates = sv[2:2 + ndir]
@@ -431,12 +456,11 @@ class LstmLayerFn(torch.autograd.Function):
                 # fragment path; the transpose of a few MB is ~10 us, the big projections gain 30-70 us each)
                 wit = transpose2d(wi)                      # [In, 4H]
                 gemm(dgs[d], wit, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
-                     EPI_STORE if d == 0 else EPI_ACCUM)
+                     EPI_STORE if d == 0 else EPI_ACCUM, mode=mode)
         with side_work(x, h_out, *dgs):
-            st2 = stream()
             for d, (wi, wh, bi, bh) in enumerate(params):
                 dg = dgs[d]
-                linear_wgrad_acc(dg, x, _grad_buf(wi))
+                linear_wgrad_acc(dg, x, _grad_buf(wi), mode=mode)
                 gw = _grad_buf(wh)      # exists (zero) even when T == 1 leaves W_hh without a gradient
                 if T > 1:
                     rows = R - N
@@ -446,8 +470,7 @@ class LstmLayerFn(torch.autograd.Function):
                     else:
                         a_ptr, b_ptr = dg.data_ptr(), h_out.data_ptr() + 4 * (N * ldh + H)
                     sk = _split_k(_tiles(4 * H, H), rows)
-                    check(L.dvae_gemm_f32(a_ptr, b_ptr, ptr(gw), None, 4 * H, H, rows, 4 * H, ldh, H, 0, 0, ACT_NONE,
-                                          EPI_ATOMIC, sk, st2), "dvae_gemm_f32(dW_hh)")
+                    gemm(a_ptr, b_ptr, gw, None, 4 * H, H, rows, 4 * H, ldh, H, False, False, ACT_NONE, EPI_ATOMIC, sk, mode)
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         for (wi, wh, bi, bh) in params:
             _ready(wi, wh, bi, bh)
@@ -484,12 +507,13 @@ class LstmStack2Fn(torch.autograd.Function):
         R, In = x.shape
         H = w_hh1.shape[1]
         Tc = LstmStack2Fn.chunk(T)
-        bf = 1 if get_compute_dtype() == "bf16" else 0
+        mode = current_mode()
+        bf = 1 if mode == MODE_BF16 else 0
         f32 = dict(device=dev, dtype=torch.float32)
         g1, g2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
         c1, c2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
         h1, h2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
-        gemm(x, w_ih1, g1, b_ih1 + b_hh1, R, 4 * H, In, In, In, 4 * H, True, True)
+        gemm(x, w_ih1, g1, b_ih1 + b_hh1, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
         bias2 = b_ih2 + b_hh2
         packs = []
         for wh in (w_hh1, w_hh2):
@@ -505,17 +529,17 @@ class LstmStack2Fn(torch.autograd.Function):
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
                 r0 = (c0 - Tc) * N
-                check(L.dvae_gemm_f32(h1.data_ptr() + 4 * r0 * H, ptr(w_ih2), g2.data_ptr() + 4 * r0 * 4 * H, ptr(bias2),
-                                      rows, 4 * H, H, H, H, 4 * H, 1, 1, ACT_NONE, EPI_STORE, 1, st), "dvae_gemm_f32")
+                gemm(h1.data_ptr() + 4 * r0 * H, w_ih2, g2.data_ptr() + 4 * r0 * 4 * H, bias2,
+                     rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode)
             check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
         ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, packs[0][1], packs[1][1], w_ih1, w_hh1, b_ih1, b_hh1,
                               w_ih2, w_hh2, b_ih2, b_hh2)
-        ctx.cfg = (T, N, H, bf)
+        ctx.cfg = (T, N, H, bf, mode)
         return h2
 
     @staticmethod
     def backward(ctx, dh2):
-        T, N, H, bf = ctx.cfg
+        T, N, H, bf, mode = ctx.cfg
         (x, h1, h2, g1, g2, c1, c2, pb1, pb2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2) = ctx.saved_tensors
         L, st, dev = lib(), stream(), x.device
         R, In = x.shape
@@ -537,23 +561,22 @@ class LstmStack2Fn(torch.autograd.Function):
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 2 finished backward steps [c0-Tc, c0) = frames [T-c0, T-c0+Tc): dgrad into dh1
                 r0 = (T - c0) * N
-                check(L.dvae_gemm_f32(dg2.data_ptr() + 4 * r0 * 4 * H, ptr(w_ih2t), dh1.data_ptr() + 4 * r0 * H, None,
-                                      rows, H, 4 * H, 4 * H, 4 * H, H, 1, 1, ACT_NONE, EPI_STORE, 1, st), "dvae_gemm_f32")
+                gemm(dg2.data_ptr() + 4 * r0 * 4 * H, w_ih2t, dh1.data_ptr() + 4 * r0 * H, None,
+                     rows, H, 4 * H, 4 * H, 4 * H, H, True, True, mode=mode)
             check(L.dvae_lstm_seq_bwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_bwd_range")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), **f32)
-            gemm(dg1, transpose2d(w_ih1), dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True)
+            gemm(dg1, transpose2d(w_ih1), dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, mode=mode)
         with side_work(x, h1, h2, dg1, dg2):
-            st2 = stream()
             for dg, inp, hh, wi, wh, bi, bh in ((dg2, h1, h2, w_ih2, w_hh2, b_ih2, b_hh2),
                                                 (dg1, x, h1, w_ih1, w_hh1, b_ih1, b_hh1)):
-                linear_wgrad_acc(dg, inp, _grad_buf(wi))
+                linear_wgrad_acc(dg, inp, _grad_buf(wi), mode=mode)
                 gw = _grad_buf(wh)
                 rws = R - N
                 sk = _split_k(_tiles(4 * H, H), rws)
-                check(L.dvae_gemm_f32(dg.data_ptr() + 4 * N * 4 * H, ptr(hh), ptr(gw), None, 4 * H, H, rws, 4 * H, H, H,
-                                      0, 0, ACT_NONE, EPI_ATOMIC, sk, st2), "dvae_gemm_f32(dW_hh)")
+                gemm(dg.data_ptr() + 4 * N * 4 * H, hh, gw, None, 4 * H, H, rws, 4 * H, H, H, False, False, ACT_NONE,
+                     EPI_ATOMIC, sk, mode)
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         _ready(w_ih2, w_hh2, b_ih2, b_hh2)
         _ready(w_ih1, w_hh1, b_ih1, b_hh1)

@@ -44,11 +44,22 @@ extern "C" {
 
 int dvae_version(void);
 
-/* ---- compute mode of every contraction entry point below (process-wide, like torch's matmul precision):
- * 0 (default) fp32 operands on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 — BASELINE configs[1], [3];
- * 1 bf16 operands (fp32 tensors in HBM, rounded to nearest-even while staged into LDS / packed) with fp32
- *   accumulation on v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 — BASELINE configs[2], [4] ("bf16 compute").
- * Everything that is not a contraction (BatchNorm, gates, losses, Adam, master weights) stays fp32 in both modes. */
+/* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
+ * DVAE_MODE_F32    fp32 operands on v_mfma_f32_32x32x2_f32 / 16x16x4_f32 (the fp32 matrix pipe runs at the vector
+ *                  rate, 157 TFLOP/s);
+ * DVAE_MODE_F32X3  fp32 RESULTS on the bf16 matrix pipe: each fp32 operand is split exactly into three bf16 terms
+ *                  (x = x1 + x2 + x3) and a product is the sum of the six partial products whose weight is >= 2^-16,
+ *                  each exact in fp32, accumulated in fp32 — the dropped terms are below the rounding of one fp32 FMA,
+ *                  so this IS an fp32 contraction (same error against fp64 as DVAE_MODE_F32, tests/test_hip_x3.py) at
+ *                  6/16 of its MFMA cost — BASELINE configs[1], [3];
+ * DVAE_MODE_BF16   bf16 operands (rounded to nearest-even on their way into the matrix cores) with fp32 accumulation on
+ *                  v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 — BASELINE configs[2], [4] ("bf16 compute");
+ * DVAE_MODE_DEFAULT  whatever dvae_set_compute_mode() last set (process-wide default, initially DVAE_MODE_F32).
+ * Everything that is not a contraction (BatchNorm, gates, losses, Adam, master weights) is fp32 in every mode. */
+#define DVAE_MODE_DEFAULT (-1)
+#define DVAE_MODE_F32 0
+#define DVAE_MODE_BF16 1
+#define DVAE_MODE_F32X3 2
 int dvae_set_compute_mode(int mode);
 int dvae_get_compute_mode(void);
 /* hipError_t of the last failed launch (0 if none) */
@@ -65,7 +76,7 @@ int dvae_last_hip_error(void);
  */
 int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
                   int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
-                  int a_kcontig, int b_kcontig, int act, int epi, int split_k, void* stream);
+                  int a_kcontig, int b_kcontig, int act, int epi, int split_k, int mode, void* stream);
 
 /* ---- Conv1d(k=5, stride 1, pad 2) on frame-major data (disentangled_vae.py:111-114, 178-181) ----
  * Weights are used in PACKED form Wp[5][Cout][Cin] (see dvae_conv_pack_w).
@@ -75,15 +86,16 @@ int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
  * R = T*N rows, N = segments per frame.
  */
 int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y,
-                   int R, int N, int Cin, int Cout, void* stream);
+                   int R, int N, int Cin, int Cout, int mode, void* stream);
 int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp,
-                     int R, int N, int Cin, int Cout, int split_k, void* stream);
+                     int R, int N, int Cin, int Cout, int split_k, int mode, void* stream);
 /* W[Cout][Cin][5] (torch layout, state_dict contract) -> Wp[5][Cout][Cin] */
 int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void* stream);
 /* Wpt[5][Cin][Cout]: the transposed pack; with it the data gradient reads BOTH operands k-contiguously (the faster
  * ds_read_b128 fragment path of the contraction kernel). */
 int dvae_conv_pack_wt(const float* W, float* Wpt, int Cout, int Cin, void* stream);
-int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout, void* stream);
+int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout, int mode,
+                       void* stream);
 /* dW[Cout][Cin][5] += dWp[5][Cout][Cin] */
 int dvae_conv_unpack_add_w(const float* dWp, float* dW, int Cout, int Cin, void* stream);
 

@@ -33,19 +33,21 @@ def timeit(fn, flops, name, reps=100):
 
 
 L = lib()
+MODE = ops.current_mode()        # DVAE_COMPUTE_DTYPE=fp32|fp32x3|bf16
+print("compute mode:", ops.get_compute_dtype(), flush=True)
 tot = 0.0
 for cin, cout, cnt in ((80, 512, 2), (512, 512, 8), (512, 80, 1)):
     x, wp, b, y = t(R, cin), t(5, cout, cin), t(cout), torch.empty(R, cout, device=dev)
     fl = 2.0 * R * cin * cout * 5
-    tot += cnt * timeit(lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, cin, cout, stream()), ""),
+    tot += cnt * timeit(lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, cin, cout, MODE, stream()), ""),
                         fl, f"conv_fwd {cin}->{cout} x{cnt}")
     dx = torch.empty(R, cin, device=dev)
     wpt = t(5, cin, cout)
-    tot += cnt * timeit(lambda: check(L.dvae_conv5_dgrad_t(ptr(y), ptr(wpt), ptr(dx), R, N, cin, cout, stream()), ""),
+    tot += cnt * timeit(lambda: check(L.dvae_conv5_dgrad_t(ptr(y), ptr(wpt), ptr(dx), R, N, cin, cout, MODE, stream()), ""),
                         fl, f"conv_dgrad {cin}->{cout} x{cnt}")
     dwp = torch.zeros(5, cout, cin, device=dev)
     sk = ops._split_k(5 * ops._tiles(cout, cin), R)
-    tot += cnt * timeit(lambda: check(L.dvae_conv5_wgrad(ptr(y), ptr(x), ptr(dwp), R, N, cin, cout, sk, stream()), ""),
+    tot += cnt * timeit(lambda: check(L.dvae_conv5_wgrad(ptr(y), ptr(x), ptr(dwp), R, N, cin, cout, sk, MODE, stream()), ""),
                         fl, f"conv_wgrad {cin}->{cout} sk{sk} x{cnt}")
 for M, K, No, cnt, nm in ((R, 512, 256, 2, "enc_lstm0 inproj"), (R, 128, 256, 2, "enc_lstm1 inproj"),
                           (R, 128, 2048, 1, "dec_lstm1 inproj"), (R, 512, 4096, 1, "dec_lstm2.0 inproj"),

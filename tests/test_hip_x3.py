@@ -1,0 +1,128 @@
+"""DVAE_MODE_F32X3 — fp32 contractions evaluated on the bf16 matrix pipe (include/dvae_hip.h): every fp32 operand is
+split exactly into three bf16 terms and a product is the sum of six exact partial products, accumulated in fp32.
+The claim under test is that this IS fp32 arithmetic, not a reduced precision:
+  * identity products come back BIT-EXACT (x1 + x2 + x3 == x), where the bf16 mode returns rne_bf16(x);
+  * against an fp64 reference the error is no larger than that of the fp32-MFMA kernel (DVAE_MODE_F32) on the same
+    operands, for every operand layout, ragged shapes, split-K, conv taps included;
+  * the whole training step matches the goldens recorded from the reference at the same 1e-4 as the fp32-MFMA path
+    (tests/test_hip_model.py runs in this mode by default)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, wide=False):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(*shape, generator=g) * 2 - 1
+    if wide:    # seven decades of magnitude: the split must carry all 24 significand bits whatever the exponent
+        x = x * torch.pow(10.0, torch.rand(*shape, generator=g) * 7 - 4)
+    return x
+
+
+def err(got, ref):
+    ref = ref.double()
+    return float((got.detach().cpu().double() - ref).abs().max()) / max(1e-30, float(ref.abs().max()))
+
+
+def run(ops, A, B, M, N, K, a_kc, b_kc, mode, sk=1):
+    C = torch.zeros(M, N, device="cuda")
+    lda = K if a_kc else M
+    ldb = K if b_kc else N
+    ops.gemm(A.cuda().contiguous(), B.cuda().contiguous(), C, None, M, N, K, lda, ldb, N, a_kc, b_kc, 0,
+             ops.EPI_ATOMIC if sk > 1 else ops.EPI_STORE, sk, mode)
+    return C
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("n", [128, 200])
+def test_identity_product_is_bit_exact(ops, a_kc, b_kc, n):
+    x = rnd(n, n, seed=3, wide=True)
+    eye = torch.eye(n)
+    A = x if a_kc else x.t().contiguous()
+    got = run(ops, A, eye, n, n, n, a_kc, b_kc, ops.MODE_F32X3)
+    assert torch.equal(got.cpu(), x), "x1 + x2 + x3 != x"
+    got_b = run(ops, A, eye, n, n, n, a_kc, b_kc, ops.MODE_BF16)
+    assert torch.equal(got_b.cpu(), x.bfloat16().float()) and not torch.equal(got_b.cpu(), x)
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(128, 128, 32, 1), (200, 72, 80, 1), (130, 260, 516, 1), (1024, 1024, 4096, 1),
+                                      (256, 128, 8192, 8), (16384, 512, 128, 1)])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("wide", [False, True])
+def test_error_against_fp64_not_above_fp32_mfma(ops, M, N, K, sk, a_kc, b_kc, wide):
+    if not a_kc and (M % 4 or N % 4):
+        pytest.skip("row-contiguous operands need M, N multiples of 4")
+    if not b_kc and N % 4:
+        pytest.skip("row-contiguous B needs N % 4 == 0")
+    a, b = rnd(M, K, seed=1, wide=wide), rnd(K, N, seed=2, wide=wide)
+    ref = a.double() @ b.double()
+    A = a if a_kc else a.t().contiguous()
+    B = b.t().contiguous() if b_kc else b
+    e32 = err(run(ops, A, B, M, N, K, a_kc, b_kc, ops.MODE_F32, sk), ref)
+    ex3 = err(run(ops, A, B, M, N, K, a_kc, b_kc, ops.MODE_F32X3, sk), ref)
+    ebf = err(run(ops, A, B, M, N, K, a_kc, b_kc, ops.MODE_BF16, sk), ref)
+    # same class of error as the fp32 MFMA (different summation order only): within 1.5x + one ulp of the scale
+    assert ex3 <= 1.5 * e32 + 1.2e-7, (e32, ex3, ebf)
+    assert ex3 <= 2e-5 and ebf > 20 * ex3, (e32, ex3, ebf)
+
+
+@pytest.mark.parametrize("N,T,Cin,Cout", [(8, 64, 80, 512), (128, 16, 512, 512), (3, 5, 80, 80)])
+def test_conv5_all_three_products(ops, N, T, Cin, Cout):
+    from dvae_amd._lib import check, lib, ptr, stream
+    L = lib()
+    x = rnd(N, Cin, T, seed=1).double().requires_grad_()
+    w = (rnd(Cout, Cin, 5, seed=2) * 0.1).double().requires_grad_()
+    b = rnd(Cout, seed=3)
+    gy = rnd(N, Cout, T, seed=4)
+    y_ref = F.conv1d(x, w, b.double(), padding=2)
+    y_ref.backward(gy.double())
+    fr = lambda t: t.permute(2, 0, 1).reshape(T * N, -1).contiguous().float().cuda()
+    R = N * T
+    xf, gyf, wd = fr(x.detach()), fr(gy), w.detach().float().cuda()
+    wp, wpt = torch.empty(5, Cout, Cin, device="cuda"), torch.empty(5, Cin, Cout, device="cuda")
+    check(L.dvae_conv_pack_w(ptr(wd), ptr(wp), Cout, Cin, stream()), "pack")
+    check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
+    res = {}
+    for mode in (ops.MODE_F32, ops.MODE_F32X3):
+        y, dx = torch.empty(R, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
+        check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(b.cuda()), ptr(y), R, N, Cin, Cout, mode, stream()), "fwd")
+        check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx), R, N, Cin, Cout, mode, stream()), "dgrad")
+        dwp = torch.zeros(5, Cout, Cin, device="cuda")
+        check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 3, mode, stream()), "wgrad")
+        unfr = lambda t: t.cpu().reshape(T, N, -1).permute(1, 2, 0)
+        res[mode] = (err(unfr(y), y_ref.detach()), err(unfr(dx), x.grad), err(dwp.cpu().permute(1, 2, 0), w.grad))
+    for e32, ex3 in zip(res[ops.MODE_F32], res[ops.MODE_F32X3]):
+        assert ex3 <= 1.5 * e32 + 1.2e-7 and ex3 <= 2e-5, res
+
+
+def test_mode_is_fixed_at_forward(ops):
+    """The compute mode in force at FORWARD time is the one the backward launches use (autograd context), whatever
+    the process default has become in between."""
+    x = rnd(64, 256, seed=1).cuda().requires_grad_()
+    w = torch.nn.Parameter((rnd(128, 256, seed=2) * 0.1).cuda())
+    b = torch.nn.Parameter(torch.zeros(128, device="cuda"))
+    gy = rnd(64, 128, seed=3).cuda()
+    grads = {}
+    for name, flip in (("x3", None), ("x3_flipped", "bf16"), ("bf16", None)):
+        x.grad = None
+        w.grad = None
+        b.grad = None
+        with ops.compute_dtype("bf16" if name == "bf16" else "fp32x3"):
+            y = ops.LinearFn.apply(x, w, b, 0)
+            if flip:
+                ops.set_compute_dtype(flip)
+            y.backward(gy)
+        grads[name] = (x.grad.clone(), w.grad.clone())
+    assert torch.equal(grads["x3"][0], grads["x3_flipped"][0])
+    assert float((grads["x3"][1] - grads["x3_flipped"][1]).abs().max()) <= 1e-6 * float(grads["x3"][1].abs().max())
+    assert not torch.equal(grads["x3"][0], grads["bf16"][0])
