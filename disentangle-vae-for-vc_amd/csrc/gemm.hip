@@ -37,24 +37,15 @@ __device__ __attribute__((aligned(16))) float g_gemm_zero[4] = {0.f, 0.f, 0.f, 0
 
 namespace {
 
-// x[0..7] (fp32) -> three bf16x8 with x[i] == p[0][i] + p[1][i] + p[2][i] exactly (see the X3 note at the kernel):
-// round to nearest-even twice (v_cvt_pk_bf16_f32 packs two values per instruction), the last residual has <= 8
-// significant bits and converts exactly.
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&p)[3]) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const f32x2 v = {x[2 * i], x[2 * i + 1]};
-    const bf16x2 h1 = __builtin_convertvector(v, bf16x2);
-    const f32x2 r1 = v - __builtin_convertvector(h1, f32x2);
-    const bf16x2 h2 = __builtin_convertvector(r1, bf16x2);
-    const f32x2 r2 = r1 - __builtin_convertvector(h2, f32x2);
-    const bf16x2 h3 = __builtin_convertvector(r2, bf16x2);
-    p[0][2 * i] = h1[0]; p[0][2 * i + 1] = h1[1];
-    p[1][2 * i] = h2[0]; p[1][2 * i + 1] = h2[1];
-    p[2][2 * i] = h3[0]; p[2][2 * i + 1] = h3[1];
-  }
+// x (4 x fp32) -> three bf16x4 with x[i] == p[0][i] + p[1][i] + p[2][i] exactly (see the X3 note at the kernel):
+// round to nearest-even twice (v_cvt_pk_bf16_f32 packs two values per instruction; x - rne(x) is exact in fp32), the
+// last residual has <= 8 significant bits and converts exactly.
+__device__ __forceinline__ void split3(const f32x4& x, bf16x4 (&p)[3]) {
+  p[0] = __builtin_convertvector(x, bf16x4);
+  const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
+  p[1] = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(p[1], f32x4);
+  p[2] = __builtin_convertvector(r2, bf16x4);
 }
 
 // Workgroup = WG x WG waves (WG = 2: 128 x 64*NTW tile, 256 threads; WG = 4: 256 x 128*NTW tile, 1024 threads).
@@ -92,27 +83,32 @@ struct GemmParams {
 // a product a*b is evaluated as the six partial products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, each EXACT in fp32
 // (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms are <= 2^-24 |ab| together
 // — below the rounding of one fp32 FMA — so the result is an fp32 contraction with a different summation order, at
-// 6/16 of the fp32-MFMA cost.  Images stay fp32 in LDS (same staging as MODE 0); the split runs in registers on the
-// fragment a lane has just read (~5.5 VALU operations per element, hidden under the 6 MFMAs per fragment pair).
+// 6/16 of the fp32-MFMA cost.  The split runs ONCE per element per workgroup, while the k-tile is staged into LDS
+// (4.5 VALU operations per element: v_cvt_pk_bf16_f32, two bit operations and a packed subtract per level); LDS holds
+// three bf16 images per operand and the fragment reads are those of the bf16 mode, three per tile.  Splitting in
+// registers after the fragment read (fp32 images) measured 160 TFLOP/s: every element is then split by both waves
+// that read it and the VALU stream sits in front of each MFMA burst.
 template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
   constexpr bool BF = (MODE == 1), X3 = (MODE == 2);
   static_assert(!BF || (BK == 32 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
-  static_assert(!X3 || WG == 2, "split mode: 128 x 64*NTW tile only");
+  static_assert(!X3 || (BK == 16 && WG == 2), "split mode: 128 x 64*NTW x 16 tile only (3 images x 2 buffers in LDS)");
+  constexpr bool B16 = BF || X3;         // bf16 images in LDS
+  constexpr int NP = X3 ? 3 : 1;         // images per operand
   constexpr int BM = 64 * WG, NTHR = 64 * WG * WG;
   constexpr int BN = 32 * NTW * WG;      // NTW = 32-wide n-tiles per wave
-  constexpr int LD_KC = BF ? BK + 8 : BK + 4;          // row stride of a k-contiguous image
-  constexpr int LDA = A_KC ? LD_KC : (BF ? BM + 32 : BM + 4);
-  constexpr int LDB = B_KC ? LD_KC : (BF ? BN + 32 : BN + 4);
+  constexpr int LD_KC = B16 ? BK + 8 : BK + 4;         // row stride of a k-contiguous image
+  constexpr int LDA = A_KC ? LD_KC : (B16 ? BM + 32 : BM + 4);
+  constexpr int LDB = B_KC ? LD_KC : (B16 ? BN + 32 : BN + 4);
   constexpr int A_SZ = A_KC ? BM * LD_KC : BK * LDA;
   constexpr int B_SZ = B_KC ? BN * LD_KC : BK * LDB;
-  using lds_t = typename std::conditional<BF, __bf16, float>::type;
+  using lds_t = typename std::conditional<B16, __bf16, float>::type;
   constexpr int NLA = BM * BK / 4 / NTHR;   // float4 per thread per k-tile (A)
   constexpr int NLB = BN * BK / 4 / NTHR;   // (B)
   constexpr int KQ = BK / 4;                // float4 per row of a k-contiguous tile
   constexpr int NC = BK / 8;                // 8-deep k groups per tile
-  __shared__ __attribute__((aligned(16))) lds_t As[2][A_SZ];
-  __shared__ __attribute__((aligned(16))) lds_t Bs[2][B_SZ];
+  __shared__ __attribute__((aligned(16))) lds_t As[2][NP * A_SZ];
+  __shared__ __attribute__((aligned(16))) lds_t Bs[2][NP * B_SZ];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -249,9 +245,16 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
       const int idx = t + NTHR * j;
-      if constexpr (BF) {
+      if constexpr (B16) {
         const int off = A_KC ? (idx / KQ) * LDA + 4 * (idx % KQ) : (idx / (BM / 4)) * LDA + 4 * (idx % (BM / 4));
-        *reinterpret_cast<bf16x4*>(&As[buf][off]) = __builtin_convertvector(ra[j], bf16x4);
+        if constexpr (X3) {
+          bf16x4 pl[3];
+          split3(ra[j], pl);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&As[buf][q * A_SZ + off]) = pl[q];
+        } else {
+          *reinterpret_cast<bf16x4*>(&As[buf][off]) = __builtin_convertvector(ra[j], bf16x4);
+        }
       } else if (A_KC) {
         const int row = idx / KQ, kq = idx % KQ;
         *reinterpret_cast<f32x4*>(&As[buf][row * LDA + 4 * kq]) = ra[j];
@@ -263,9 +266,16 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       const int idx = t + NTHR * j;
-      if constexpr (BF) {
+      if constexpr (B16) {
         const int off = B_KC ? (idx / KQ) * LDB + 4 * (idx % KQ) : (idx / (BN / 4)) * LDB + 4 * (idx % (BN / 4));
-        *reinterpret_cast<bf16x4*>(&Bs[buf][off]) = __builtin_convertvector(rb[j], bf16x4);
+        if constexpr (X3) {
+          bf16x4 pl[3];
+          split3(rb[j], pl);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&Bs[buf][q * B_SZ + off]) = pl[q];
+        } else {
+          *reinterpret_cast<bf16x4*>(&Bs[buf][off]) = __builtin_convertvector(rb[j], bf16x4);
+        }
       } else if (B_KC) {
         const int row = idx / KQ, kq = idx % KQ;
         *reinterpret_cast<f32x4*>(&Bs[buf][row * LDB + 4 * kq]) = rb[j];
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       load_tiles(tap_n, kit_n);
       advance();
     }
-    if constexpr (BF) {
+    if constexpr (B16) {
       // v_mfma_f32_32x32x16_bf16: lane (r = lane&31, h = lane>>5) holds k = 16s + 8h + j, j = 0..7, of row r.
       // k-contiguous image: one ds_read_b128.  Row-contiguous image [k][rows]: two ds_read_b64_tr_b16; lane 4q+pq of
       // the 16-lane group g supplies &img[k0 + q][r0 + 4pq] (k0 = 16s + 8(g>>1) (+4), r0 = 16(g&1)) and receives
@@ -339,69 +349,31 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * ld));
         return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
       };
-      bf16x8 av[2][2], bv[2][NTW];
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) av[s2][mt] = frag(&As[cur][0], A_KC, LDA, wm * 64 + mt * 32, s2);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) bv[s2][nt] = frag(&Bs[cur][0], B_KC, LDB, wn * 32 * NTW + nt * 32, s2);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][0], bv[s2][nt], acc[0][nt], 0, 0, 0);
-          acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][1], bv[s2][nt], acc[1][nt], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    } else if constexpr (X3) {
-      // lane (r = lane&31, h = lane>>5) of v_mfma_f32_32x32x16_bf16 holds k = 16s + 8h + j, j = 0..7, of row r: eight
-      // fp32 values from the image (two ds_read_b128 of a k-contiguous image, row stride BK+4 floats: conflict-free for
-      // the 16-lane groups; eight ds_read_b32 of a row-contiguous one), split into three bf16x8 fragments.
-      auto read8 = [&](const float* img, bool kc, int ld, int row0, int s2, float (&x)[8]) {
-        if (kc) {
-          const float* q0 = &img[(row0 + l31) * ld + 16 * s2 + 8 * kh];
-          const f32x4 u = *reinterpret_cast<const f32x4*>(q0), v = *reinterpret_cast<const f32x4*>(q0 + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { x[e] = u[e]; x[4 + e] = v[e]; }
-        } else {
-          const float* q0 = &img[(16 * s2 + 8 * kh) * ld + row0 + l31];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[e] = q0[e * ld];
-        }
-      };
       constexpr int NS = BK / 16;
-      float xa[2][8], xb[NTW][8];
+      bf16x8 av[NS][2][NP], bv[NS][NTW][NP];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) read8(&As[cur][0], A_KC, LDA, wm * 64 + mt * 32, 0, xa[mt]);
+      for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) read8(&Bs[cur][0], B_KC, LDB, wn * 32 * NTW + nt * 32, 0, xb[nt]);
+        for (int q = 0; q < NP; ++q) {
 #pragma unroll
-      for (int s2 = 0; s2 < NS; ++s2) {
-        bf16x8 pa[2][3], pb[NTW][3];
+          for (int mt = 0; mt < 2; ++mt) av[s2][mt][q] = frag(&As[cur][q * A_SZ], A_KC, LDA, wm * 64 + mt * 32, s2);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) split3(xa[mt], pa[mt]);
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) split3(xb[nt], pb[nt]);
-        if (s2 + 1 < NS) {   // next step's raw fragment: its LDS latency runs under this step's MFMAs
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) read8(&As[cur][0], A_KC, LDA, wm * 64 + mt * 32, s2 + 1, xa[mt]);
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) read8(&Bs[cur][0], B_KC, LDB, wn * 32 * NTW + nt * 32, s2 + 1, xb[nt]);
+          for (int nt = 0; nt < NTW; ++nt) bv[s2][nt][q] = frag(&Bs[cur][q * B_SZ], B_KC, LDB, wn * 32 * NTW + nt * 32, s2);
         }
-        // smallest partial products first
+      __builtin_amdgcn_sched_barrier(0);
+      // X3: the six partial products of weight >= 2^-16, (a1,b1) first: it needs only the first image of each operand
+      constexpr int NT6 = X3 ? 6 : 1;
+      constexpr int ia[6] = {0, 0, 1, 1, 0, 2}, ib[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
-        for (int term = 0; term < 6; ++term) {
-          constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
+      for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+        for (int term = 0; term < NT6; ++term)
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
-            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[0][ia[term]], pb[nt][ib[term]], acc[0][nt], 0, 0, 0);
-            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[1][ia[term]], pb[nt][ib[term]], acc[1][nt], 0, 0, 0);
+            acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][0][ia[term]], bv[s2][nt][ib[term]], acc[0][nt], 0, 0, 0);
+            acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][1][ia[term]], bv[s2][nt][ib[term]], acc[1][nt], 0, 0, 0);
           }
-        }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     } else {
     // ---- fragments in 8-deep k groups: group c, element e <-> k = 8c + 4*kh + e.  The reads of group c+1 are
     // issued BEFORE the 4*2*NTW MFMAs of group c (two register sets, order pinned with sched_barrier), so the LDS
@@ -520,13 +492,8 @@ void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, 
     return;
   }
   if (mode == DVAE_MODE_F32X3) {  // fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product
-    if (bk == 32) {
-      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2, 2>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2, 2>), grid, dim3(256), 0, s, p);
-    } else {
-      if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, 2, 2>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, 2, 2>), grid, dim3(256), 0, s, p);
-    }
+    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 16, 2, 2>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 16, 2, 2>), grid, dim3(256), 0, s, p);
     return;
   }
   if (big) {   // 256 x 256 x 32 tile, 16 waves
@@ -566,6 +533,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   if (bk_env == 16 || bk_env == 32) bk = bk_env;
   const bool bf = (mode == DVAE_MODE_BF16);
   if (bf) bk = 32;                       // the bf16 kernel has one k-tile; ragged tails are zero-filled
+  if (mode == DVAE_MODE_F32X3) bk = 16;  // three images per operand: 16-deep tiles keep two workgroups per CU
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
   p.split_k = (p.K + kps - 1) / kps;

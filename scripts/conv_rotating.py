@@ -16,7 +16,7 @@ for nset in (1, S):
     def run(n):
         for i in range(n):
             x, wp, b, y = sets[i % nset]
-            check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, stream()), "")
+            check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, -1, stream()), "")
     run(200)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -13,7 +13,7 @@ L = lib()
 t = lambda *s: torch.randn(*s, device="cuda")
 if kind == "conv":
     x, wp, b, y = t(R, 512), t(5, 512, 512), t(512), torch.empty(R, 512, device="cuda")
-    fn = lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, stream()), "")
+    fn = lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, -1, stream()), "")
     nwg = 512
 elif kind == "lone":      # 256 workgroups: one per CU, no co-resident competitor
     x, w, y = t(R, 1024), t(256, 1024), torch.empty(R, 256, device="cuda")

@@ -12,7 +12,7 @@ L = lib()
 t = lambda *s: torch.randn(*s, device="cuda")
 if kind == "conv":
     x, wp, b, y = t(R, 512), t(5, 512, 512), t(512), torch.empty(R, 512, device="cuda")
-    fn = lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, stream()), "")
+    fn = lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, -1, stream()), "")
     fl = 2.0 * R * 512 * 512 * 5
 elif kind == "gemm2560":
     x, w, y = t(R, 2560), t(512, 2560), torch.empty(R, 512, device="cuda")

@@ -14,7 +14,7 @@ x, y = torch.randn(R, cin, device="cuda"), torch.randn(R, cout, device="cuda")
 dwp = torch.zeros(5, cout, cin, device="cuda")
 fl = 2.0 * R * cin * cout * 5
 for sk in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 19, 25, 32):
-    f = lambda: check(L.dvae_conv5_wgrad(ptr(y), ptr(x), ptr(dwp), R, N, cin, cout, sk, stream()), "")
+    f = lambda: check(L.dvae_conv5_wgrad(ptr(y), ptr(x), ptr(dwp), R, N, cin, cout, sk, -1, stream()), "")
     for _ in range(100):
         f()
     torch.cuda.synchronize()

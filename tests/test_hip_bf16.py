@@ -119,15 +119,15 @@ def test_conv5(ops, N, T, Cin, Cout):
     wp = torch.empty(5, Cout, Cin, device="cuda")
     check(L.dvae_conv_pack_w(ptr(wd), ptr(wp), Cout, Cin, stream()), "pack")
     y = torch.empty(R, Cout, device="cuda")
-    check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(dev(b)), ptr(y), R, N, Cin, Cout, stream()), "fwd")
+    check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(dev(b)), ptr(y), R, N, Cin, Cout, -1, stream()), "fwd")
     close(from_frames(y.cpu(), N, T), y_ref, name="bf16 conv_fwd")
     gyf = dev(to_frames(gy))
     wpt, dx2 = torch.empty(5, Cin, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
     check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
-    check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, stream()), "dgrad_t")
+    check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, -1, stream()), "dgrad_t")
     close(from_frames(dx2.cpu(), N, T), x.grad, name="bf16 conv_dgrad_t")
     dwp = torch.zeros(5, Cout, Cin, device="cuda")
-    check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 3, stream()), "wgrad")
+    check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 3, -1, stream()), "wgrad")
     dw = torch.zeros(Cout, Cin, 5, device="cuda")
     check(L.dvae_conv_unpack_add_w(ptr(dwp), ptr(dw), Cout, Cin, stream()), "unpack")
     close(dw, w.grad, name="bf16 conv_wgrad")

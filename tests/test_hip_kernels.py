@@ -115,18 +115,18 @@ def test_conv5_fwd_dgrad_wgrad(ops, N, T, Cin, Cout):
     check(L.dvae_conv_pack_w(ptr(wd), ptr(wp), Cout, Cin, stream()), "pack")
     close(wp, w.detach().permute(2, 0, 1), rel=0, name="pack")
     y = torch.empty(R, Cout, device="cuda")
-    check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(dev(b)), ptr(y), R, N, Cin, Cout, stream()), "fwd")
+    check(L.dvae_conv5_fwd(ptr(xf), ptr(wp), ptr(dev(b)), ptr(y), R, N, Cin, Cout, -1, stream()), "fwd")
     close(from_frames(y.cpu(), N, T), y_ref, name="conv_fwd")
 
     gyf = dev(to_frames(gy))
     wpt, dx2 = torch.empty(5, Cin, Cout, device="cuda"), torch.empty(R, Cin, device="cuda")
     check(L.dvae_conv_pack_wt(ptr(wd), ptr(wpt), Cout, Cin, stream()), "pack_t")
     close(wpt, w.detach().permute(2, 1, 0), rel=0, name="pack_t")
-    check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, stream()), "dgrad_t")
+    check(L.dvae_conv5_dgrad_t(ptr(gyf), ptr(wpt), ptr(dx2), R, N, Cin, Cout, -1, stream()), "dgrad_t")
     close(from_frames(dx2.cpu(), N, T), x.grad, name="conv_dgrad_t")
 
     dwp = torch.zeros(5, Cout, Cin, device="cuda")
-    check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 4, stream()), "wgrad")
+    check(L.dvae_conv5_wgrad(ptr(gyf), ptr(xf), ptr(dwp), R, N, Cin, Cout, 4, -1, stream()), "wgrad")
     dw = torch.zeros(Cout, Cin, 5, device="cuda")
     check(L.dvae_conv_unpack_add_w(ptr(dwp), ptr(dw), Cout, Cin, stream()), "unpack")
     close(dw, w.grad, name="conv_wgrad")
@@ -391,11 +391,12 @@ def test_abi_rejects_bad_arguments_without_crashing():
     L = lib()
     a = torch.zeros(64, 64, device="cuda")
     p, st = a.data_ptr(), stream()
-    assert L.dvae_gemm_f32(None, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, st) == -1          # null A
-    assert L.dvae_gemm_f32(p + 4, p, p, None, 64, 64, 60, 64, 64, 64, 1, 1, 0, 0, 1, st) == -1         # misaligned
-    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 62, 64, 64, 1, 1, 0, 0, 1, st) == -1             # lda % 4
-    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 1, 2, 4, st) == -1             # act + split-K
-    assert L.dvae_gemm_f32(p, p, p, None, 0, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, st) == -1              # empty
+    assert L.dvae_gemm_f32(None, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, -1, st) == -1          # null A
+    assert L.dvae_gemm_f32(p + 4, p, p, None, 64, 64, 60, 64, 64, 64, 1, 1, 0, 0, 1, -1, st) == -1         # misaligned
+    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 62, 64, 64, 1, 1, 0, 0, 1, -1, st) == -1             # lda % 4
+    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 1, 2, 4, -1, st) == -1             # act + split-K
+    assert L.dvae_gemm_f32(p, p, p, None, 0, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, -1, st) == -1              # empty
+    assert L.dvae_gemm_f32(p, p, p, None, 64, 64, 64, 64, 64, 64, 1, 1, 0, 0, 1, 3, st) == -1               # unknown mode
     assert L.dvae_bn_stats_fwd(p, p, p, None, None, None, p, 64, 8, 63, 2, 1e-5, 0.1, st) == -1        # C % 4
     assert L.dvae_bn_stats_fwd(p, p, p, None, None, None, p, 64, 7, 64, 2, 1e-5, 0.1, st) == -1        # R % N, N % G
     assert L.dvae_lstm_seq_fwd(None, 1, 4, 8, 64, 64, st) == -1
