@@ -25,6 +25,14 @@ class LstmDir(C.Structure):
                 ("step_shift", i32), ("pad_", i32)]
 
 
+class RepackDesc(C.Structure):
+    """dvae_repack_desc_t"""
+    _fields_ = [("kind", i32), ("d0", i32), ("d1", i32), ("d2", i32), ("src", vp), ("src2", vp), ("dst", vp),
+                ("dst2", vp)]
+
+
+REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2 = 0, 1, 2, 3
+
 # DVAE_MODE_* of include/dvae_hip.h
 MODE_F32, MODE_BF16, MODE_F32X3 = 0, 1, 2
 COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16,
@@ -47,6 +55,7 @@ SIGNATURES = {
     "dvae_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dvae_lstm_pack_w": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
+    "dvae_repack_all": (i32, [C.POINTER(RepackDesc), i32, i32, vp]),
     "dvae_lstm_seq_fwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_bwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_fwd_range": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, i32, i32, vp]),

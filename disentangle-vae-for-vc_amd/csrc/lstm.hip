@@ -842,62 +842,7 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   }
 }
 
-// W_hh [4H,H] -> fragment-packed copies.  fwd: [(g*n_j+jb)][kc][lane][4] <- W[g*H + jb*16 + r][kc*16 + 4q + e];
-// bwd: [(jb*4+w)][kc][lane][4] <- W[w*H + kc*16 + 4q + e][jb*16 + r]   (lane = q*16 + r)
-__global__ __launch_bounds__(256) void lstm_pack_w_kernel(const float* __restrict__ W, float* __restrict__ pf,
-                                                          float* __restrict__ pb, int H) {
-  const int n_j = H / 16, nkc = H / 16;
-  const int64_t total = (int64_t)4 * n_j * nkc * 64;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int lane = (int)(i & 63);
-    const int64_t c = i >> 6;
-    const int kc = (int)(c % nkc);
-    const int64_t gj = c / nkc;
-    const int r = lane & 15, q = lane >> 4;
-    if (pf) {
-      const int g = (int)(gj / n_j), jb = (int)(gj % n_j);
-      reinterpret_cast<f32x4*>(pf)[i] =
-          *reinterpret_cast<const f32x4*>(W + ((int64_t)g * H + jb * 16 + r) * H + kc * 16 + 4 * q);
-    }
-    if (pb) {
-      const int jb = (int)(gj / 4), w = (int)(gj % 4);
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = W[((int64_t)w * H + kc * 16 + 4 * q + e) * H + jb * 16 + r];
-      reinterpret_cast<f32x4*>(pb)[i] = v;
-    }
-  }
-}
-
-// bf16 fragment packing (v_mfma_f32_16x16x32_bf16): 32-deep chunks, lane (r, q) holds k = 32kc + 8q + j, j = 0..7.
-// fwd: [(g*n_j+jb)][kc][lane][8] <- W[g*H + jb*16 + r][32kc + 8q + j];  bwd: [(jb*4+w)][kc][lane][8] <- W[w*H + 32kc + 8q + j][jb*16 + r]
-__global__ __launch_bounds__(256) void lstm_pack_w_bf16_kernel(const float* __restrict__ W, __bf16* __restrict__ pf,
-                                                               __bf16* __restrict__ pb, int H) {
-  const int n_j = H / 16, nkc = H / 32;
-  const int64_t total = (int64_t)4 * n_j * nkc * 64;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int lane = (int)(i & 63);
-    const int64_t c = i >> 6;
-    const int kc = (int)(c % nkc);
-    const int64_t gj = c / nkc;
-    const int r = lane & 15, q = lane >> 4;
-    if (pf) {
-      const int g = (int)(gj / n_j), jb = (int)(gj % n_j);
-      const float* src = W + ((int64_t)g * H + jb * 16 + r) * H + kc * 32 + 8 * q;
-      bf16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)src[e];
-      reinterpret_cast<bf16x8*>(pf)[i] = v;
-    }
-    if (pb) {
-      const int jb = (int)(gj / 4), w = (int)(gj % 4);
-      bf16x8 v;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (__bf16)W[((int64_t)w * H + kc * 32 + 8 * q + e) * H + jb * 16 + r];
-      reinterpret_cast<bf16x8*>(pb)[i] = v;
-    }
-  }
-}
+// (the fragment packs of W_hh are produced by repack.hip: dvae_lstm_pack_w / dvae_repack_all)
 
 int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, bool bwd) {
   if (!dirs || ndir < 1 || ndir > 2 || T < 1 || N < 1 || H < 64 || (H & 63) || (ldh & 3)) return DVAE_EINVAL;
@@ -921,25 +866,6 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
 }
 
 }  // namespace
-
-DVAE_API int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream) {
-  if (!w_hh || (!packed_fwd && !packed_bwd) || H < 64 || (H & 63)) return DVAE_EINVAL;
-  const int64_t total = (int64_t)4 * (H / 16) * (H / 16) * 64;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(lstm_pack_w_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hh, packed_fwd, packed_bwd, H);
-  return dvae_check_launch();
-}
-
-DVAE_API int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream) {
-  if (!w_hh || (!packed_fwd && !packed_bwd) || H < 512 || (H % 512)) return DVAE_EINVAL;
-  const int64_t total = (int64_t)4 * (H / 16) * (H / 32) * 64;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(lstm_pack_w_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hh,
-                     (__bf16*)packed_fwd, (__bf16*)packed_bwd, H);
-  return dvae_check_launch();
-}
 
 namespace {
 // Three kernel families, chosen by H alone (every one of them is reached by tests/test_hip_kernels.py::test_lstm_layer):

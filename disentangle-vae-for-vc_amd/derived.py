@@ -1,0 +1,112 @@
+"""Weight-derived operand layouts of a DisentangledVAE, refreshed by ONE HIP launch (csrc/repack.hip,
+`dvae_repack_all`) at the start of every forward — i.e. once per training step, after Adam moved the weights:
+
+  * Conv1d: the transposed pack Wpt[5][Cin][Cout] the data gradient reads k-contiguously (the weights themselves LIVE
+    in the packed layout Wp[5][Cout][Cin], see model/disentangled_vae._Conv1dParams: no forward pack, and the weight
+    gradient accumulates straight into the flat gradient buffer);
+  * nn.LSTM: b_ih + b_hh, W_ih^T (input-projection data gradient), W_hh^T (backward recurrence at H = 64 / generic H)
+    and, for H a multiple of 512, W_hh in MFMA fragment order for the forward and backward frame kernels (bf16 fragments
+    in the bf16 compute mode).
+
+Round 1 produced these with one small launch per use (42 pack / transpose launches and 19 ATen bias adds per step,
+each into a fresh torch.empty).  The buffers are persistent; the descriptor table is rebuilt only when a source
+parameter has moved (FlatAdam re-homes parameters into its flat buffer after the model is built).
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, stream
+
+LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b")
+
+
+def _desc(kind, src, dst, d0, d1=0, src2=None, dst2=None):
+    d = _lib.RepackDesc()
+    d.kind, d.d0, d.d1, d.d2 = kind, d0, d1, 0
+    d.src, d.src2 = src.data_ptr(), (src2.data_ptr() if src2 is not None else None)
+    d.dst, d.dst2 = dst.data_ptr(), (dst2.data_ptr() if dst2 is not None else None)
+    return d
+
+
+def run_descs(descs: List, lstm_bf16: bool = False):
+    arr = (_lib.RepackDesc * len(descs))(*descs)
+    check(lib().dvae_repack_all(arr, len(descs), int(lstm_bf16), stream()), "dvae_repack_all")
+
+
+def conv_wpt_local(conv_wp: torch.Tensor) -> torch.Tensor:
+    """Wp[5][Cout][Cin] -> Wpt[5][Cin][Cout] (stand-alone use of ConvBnActFn: kernel tests, Postnet on its own)."""
+    _, cout, cin = conv_wp.shape
+    wpt = torch.empty((5, cin, cout), device=conv_wp.device, dtype=torch.float32)
+    run_descs([_desc(_lib.REPACK_CONV_T, conv_wp, wpt, cout, cin)])
+    return wpt
+
+
+def lstm_local(w_ih, w_hh, b_ih, b_hh, bf16: bool) -> LstmDerived:
+    """The derived operands of one (layer, direction), computed on the spot (stand-alone use of LstmLayerFn)."""
+    H, In = w_hh.shape[1], w_ih.shape[1]
+    f = dict(device=w_hh.device, dtype=torch.float32)
+    bias, wit, wht = torch.empty(4 * H, **f), torch.empty((In, 4 * H), **f), torch.empty((H, 4 * H), **f)
+    descs = [_desc(_lib.REPACK_ADD2, b_ih, bias, 4 * H, src2=b_hh),
+             _desc(_lib.REPACK_TRANSPOSE, w_ih, wit, 4 * H, In),
+             _desc(_lib.REPACK_TRANSPOSE, w_hh, wht, 4 * H, H)]
+    pf = pb = None
+    if H % 512 == 0:
+        pf, pb = torch.empty(4 * H * H, **f), torch.empty(4 * H * H, **f)
+        descs.append(_desc(_lib.REPACK_LSTM_PACK, w_hh, pf, H, dst2=pb))
+    run_descs(descs, bf16)
+    return LstmDerived(bias, wit, wht, pf, pb)
+
+
+class DerivedWeights:
+    def __init__(self, convs: Dict[str, torch.nn.Parameter], lstms: Dict[str, tuple]):
+        """convs: name -> packed conv weight parameter that needs a data gradient; lstms: name -> (w_ih, w_hh, b_ih,
+        b_hh) of one (layer, direction)."""
+        self._convs, self._lstms = convs, lstms
+        self._sig = None
+        self._descs = None
+        self.wpt: Dict[str, torch.Tensor] = {}
+        self.lstm: Dict[str, LstmDerived] = {}
+        self.refreshes = 0
+
+    def _signature(self):
+        return tuple(p.data_ptr() for p in self._convs.values()) + \
+            tuple(p.data_ptr() for ps in self._lstms.values() for p in ps)
+
+    def _build(self):
+        descs = []
+        for name, wp in self._convs.items():
+            _, cout, cin = wp.shape
+            if name not in self.wpt:
+                self.wpt[name] = torch.empty((5, cin, cout), device=wp.device, dtype=torch.float32)
+            descs.append(_desc(_lib.REPACK_CONV_T, wp, self.wpt[name], cout, cin))
+        for name, (w_ih, w_hh, b_ih, b_hh) in self._lstms.items():
+            H, In = w_hh.shape[1], w_ih.shape[1]
+            if name not in self.lstm:
+                f = dict(device=w_hh.device, dtype=torch.float32)
+                big = H % 512 == 0
+                self.lstm[name] = LstmDerived(torch.empty(4 * H, **f), torch.empty((In, 4 * H), **f),
+                                              torch.empty((H, 4 * H), **f),
+                                              torch.empty(4 * H * H, **f) if big else None,
+                                              torch.empty(4 * H * H, **f) if big else None)
+            d = self.lstm[name]
+            descs.append(_desc(_lib.REPACK_ADD2, b_ih, d.bias, 4 * H, src2=b_hh))
+            descs.append(_desc(_lib.REPACK_TRANSPOSE, w_ih, d.w_ih_t, 4 * H, In))
+            descs.append(_desc(_lib.REPACK_TRANSPOSE, w_hh, d.w_hh_t, 4 * H, H))
+            if d.pack_f is not None:
+                descs.append(_desc(_lib.REPACK_LSTM_PACK, w_hh, d.pack_f, H, dst2=d.pack_b))
+        self._descs = (_lib.RepackDesc * len(descs))(*descs)
+
+    def refresh(self, mode: int):
+        """One launch: every derived buffer from the current weights (asynchronous on the current stream)."""
+        sig = self._signature()
+        if sig != self._sig:
+            self._build()
+            self._sig = sig
+        check(lib().dvae_repack_all(self._descs, len(self._descs), int(mode == _lib.MODE_BF16), stream()),
+              "dvae_repack_all")
+        self.refreshes += 1

@@ -11,7 +11,12 @@ MI355X-first design decisions (none of them visible through the API):
     pair (2 groups), exactly as the reference's two separate calls produce them;
   * activations are frame-major [T, N, C]: a conv tap is a row shift, an LSTM frame is one
     contiguous slab, every GEMM-shaped op is one MFMA contraction over rows;
-  * parameters/gradients/moments live in flat buffers (optim.FlatAdam).
+  * parameters/gradients/moments live in flat buffers (optim.FlatAdam);
+  * Conv1d weights LIVE in the packed layout [5][Cout][Cin] the implicit-GEMM kernels read (no forward pack, the
+    weight gradient accumulates straight into the flat gradient buffer); `state_dict()` / `load_state_dict()` convert
+    to / from torch's [Cout][Cin][5], so checkpoints stay interchangeable with the reference;
+  * every other weight-derived operand layout (transposed conv packs, W_ih^T, W_hh^T, LSTM fragment packs,
+    b_ih + b_hh) is refreshed by ONE launch at the start of a forward (derived.DerivedWeights).
 
 Extra constructor argument `n_frames` (default 64) sizes the two layers the reference hard-codes
 to 8192 = 64*128 (disentangled_vae.py:165,171) so T = 128/256/512 work.
@@ -27,6 +32,7 @@ import torch.nn as nn
 from .. import ops
 from ..ops import (ACT_NONE, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, KlFn, L1SumFn, LatentFn, LinearFn,
                    LstmLayerFn, LstmStack2Fn, Permute102Fn, mel_to_frames)
+from ..derived import DerivedWeights
 from ..optim import FlatAdam
 from .variational_base_vae import VariationalBaseModelVAE
 
@@ -35,13 +41,41 @@ N_MEL = 80
 
 # ------------------------------------------------------------------ parameter containers
 class _Conv1dParams(nn.Module):
-    """weight [Cout, Cin, 5] + bias, torch Conv1d layout (state_dict contract)."""
+    """Conv1d(k=5) parameters.  `weight` is stored PACKED, [5][Cout][Cin] (one [Cout][Cin] matrix per tap: the B
+    operand of the implicit-GEMM kernel); `state_dict()` emits and `load_state_dict()` accepts torch's [Cout][Cin][5]
+    (the reference's checkpoint layout) through the two hooks below."""
 
     def __init__(self, cin, cout, k=5):
         super().__init__()
-        self.weight = nn.Parameter(torch.empty(cout, cin, k))
+        if k != 5:
+            raise ValueError("the HIP conv kernels are built for kernel_size 5 (every conv of the reference)")
+        self.cin, self.cout, self.k = cin, cout, k
+        self.weight = nn.Parameter(torch.empty(k, cout, cin))
         self.bias = nn.Parameter(torch.zeros(cout))
-        nn.init.xavier_uniform_(self.weight)
+        self.reset()
+        self._register_state_dict_hook(self._emit_torch_layout)
+        self._register_load_state_dict_pre_hook(self._accept_torch_layout)
+
+    def reset(self):
+        """xavier-uniform over the torch layout's fans (fan_in = Cin*5, fan_out = Cout*5), bias 0 (init_weights)."""
+        w = torch.empty(self.cout, self.cin, self.k)
+        nn.init.xavier_uniform_(w)
+        with torch.no_grad():
+            self.weight.copy_(w.permute(2, 0, 1))
+            self.bias.fill_(0)
+
+    @staticmethod
+    def _emit_torch_layout(module, state_dict, prefix, local_metadata):
+        state_dict[prefix + "weight"] = state_dict[prefix + "weight"].permute(1, 2, 0).contiguous()
+
+    def _accept_torch_layout(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        k = prefix + "weight"
+        if k in state_dict and tuple(state_dict[k].shape) == (self.cout, self.cin, self.k):
+            state_dict[k] = state_dict[k].permute(2, 0, 1).contiguous()
+
+    def torch_layout(self, t):
+        """A tensor shaped like `weight` (the weight itself, its gradient, an Adam moment) as [Cout][Cin][5]."""
+        return t.permute(1, 2, 0)
 
 
 class ConvNorm(nn.Module):
@@ -118,8 +152,7 @@ def init_weights(m):
         nn.init.xavier_uniform_(m.weight)
         m.bias.data.fill_(0.01)
     if isinstance(m, _Conv1dParams):
-        nn.init.xavier_uniform_(m.weight)
-        m.bias.data.fill_(0)
+        m.reset()
 
 
 class Postnet(nn.Module):
@@ -130,14 +163,16 @@ class Postnet(nn.Module):
         ch = [N_MEL, 512, 512, 512, 512, N_MEL]
         self.convolutions = nn.ModuleList(_conv_bn(ch[i], ch[i + 1], keyed=True) for i in range(5))
 
-    def forward_frames(self, y, n_seg, groups, residual=None):
-        """y [T*N, 80] frame-major -> postnet(y) (+ residual fused into the last BatchNorm apply)."""
+    def forward_frames(self, y, n_seg, groups, residual=None, wpt=None):
+        """y [T*N, 80] frame-major -> postnet(y) (+ residual fused into the last BatchNorm apply).
+        `wpt`: the five transposed conv packs from the owning model's DerivedWeights (None: made in backward)."""
         last = len(self.convolutions) - 1
         for i, blk in enumerate(self.convolutions):
             c, bn = _conv_of(blk), blk[1]
             y = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
-                                  ACT_TANH if i < last else ACT_NONE, self.training)
+                                  ACT_TANH if i < last else ACT_NONE, self.training,
+                                  None if wpt is None else wpt[i])
         return y
 
     def forward(self, x):
@@ -196,6 +231,7 @@ class DisentangledVAE(nn.Module):
         self.dec_lstm2 = _LSTMParams(dim_pre, 1024, 2)
         self.dec_linear2 = LinearNorm(1024, N_MEL)
         self.apply(init_weights)
+        self._derived: Optional[DerivedWeights] = None
 
         # explicit reparameterisation noise for parity runs: (eps_content1, eps_content2, eps_style),
         # the reference's three normal_() draws in call order (disentangled_vae.py:252,255,261)
@@ -223,6 +259,36 @@ class DisentangledVAE(nn.Module):
         assert len(order) == len(list(self.parameters()))
         return order
 
+    # ---- weight-derived operand layouts (one launch per forward, see derived.py)
+    def _lstm_names(self):
+        for mname in ("enc_lstm", "dec_lstm1", "dec_lstm2"):
+            mod = getattr(self, mname)
+            for l in range(mod.num_layers):
+                ps = mod.layer(l)
+                yield f"{mname}.{l}.0", ps[:4]
+                if mod.bidirectional:
+                    yield f"{mname}.{l}.1", ps[4:]
+
+    def _refresh_derived(self):
+        if self._derived is None:
+            convs = {}
+            for i in range(1, 3):                                   # enc_modules[0] reads the mel: no data gradient
+                convs[f"enc_modules.{i}"] = _conv_of(self.enc_modules[i]).weight
+            for i in range(3):
+                convs[f"dec_modules.{i}"] = _conv_of(self.dec_modules[i]).weight
+            for i in range(5):
+                convs[f"postnet.{i}"] = _conv_of(self.postnet.convolutions[i]).weight
+            self._derived = DerivedWeights(convs, dict(self._lstm_names()))
+        self._derived.refresh(ops.current_mode())
+        return self._derived
+
+    def _wpt(self, name):
+        return self._derived.wpt.get(name) if self._derived is not None else None
+
+    def _lstm_der(self, mname, l, bidirectional):
+        d = self._derived.lstm
+        return [d[f"{mname}.{l}.0"]] + ([d[f"{mname}.{l}.1"]] if bidirectional else [])
+
     # ---- frame-major building blocks
     def _check(self, x):
         if not x.is_cuda:
@@ -231,20 +297,23 @@ class DisentangledVAE(nn.Module):
         if x.shape[1] != N_MEL or x.shape[2] != self.n_frames:
             raise ValueError(f"expected [B, {N_MEL}, {self.n_frames}] mel segments, got {tuple(x.shape)}")
 
-    def _lstm(self, mod, x, T, n_seg):
+    def _lstm(self, mname, x, T, n_seg):
+        mod = getattr(self, mname)
         if LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
             # two stacked layers of equal width share their frame launches (ops.LstmStack2Fn)
-            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4])
+            der = self._lstm_der(mname, 0, False) + self._lstm_der(mname, 1, False)
+            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4], der)
         for l in range(mod.num_layers):
-            x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l))
+            x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l), self._lstm_der(mname, l, mod.bidirectional))
         return x
 
     def _encode_frames(self, x, T, n_seg, groups):
-        for blk in self.enc_modules:
+        for i, blk in enumerate(self.enc_modules):
             c, bn = _conv_of(blk), blk[1]
             x = ConvBnActFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training)
-        h = self._lstm(self.enc_lstm, x, T, n_seg)                       # [T*N, 128]
+                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
+                                  self._wpt(f"enc_modules.{i}"))
+        h = self._lstm("enc_lstm", x, T, n_seg)                          # [T*N, 128]
         d2 = 2 * self.dim_neck
         flat = Permute102Fn.apply(h, T, n_seg, d2, (n_seg, T * d2))     # index t*128+d as in :209
         lin = self.enc_linear.linear_layer
@@ -258,12 +327,13 @@ class DisentangledVAE(nn.Module):
         h = LinearFn.apply(h, p2.weight, p2.bias, ACT_NONE)              # [N, T*128]  (no activation, :232-233)
         d2 = 2 * self.dim_neck
         h = Permute102Fn.apply(h, n_seg, T, d2, (T * n_seg, d2))
-        h = self._lstm(self.dec_lstm1, h, T, n_seg)
-        for blk in self.dec_modules:
+        h = self._lstm("dec_lstm1", h, T, n_seg)
+        for i, blk in enumerate(self.dec_modules):
             c, bn = blk[0], blk[1]
             h = ConvBnActFn.apply(h, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training)
-        h = self._lstm(self.dec_lstm2, h, T, n_seg)
+                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
+                                  self._wpt(f"dec_modules.{i}"))
+        h = self._lstm("dec_lstm2", h, T, n_seg)
         lin = self.dec_linear2.linear_layer
         return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE)        # [T*N, 80]
 
@@ -271,6 +341,7 @@ class DisentangledVAE(nn.Module):
     def encode(self, x):
         """x [B,80,T] -> (style_mu, style_logvar, content_mu, content_logvar)  (disentangled_vae.py:198-220)"""
         self._check(x)
+        self._refresh_derived()
         B, _, T = x.shape
         style, content = self._encode_frames(mel_to_frames(x.contiguous()), T, B, 1)
         s, c = self.speaker_size, self.latent_dim - self.speaker_size
@@ -279,6 +350,7 @@ class DisentangledVAE(nn.Module):
     def encode_heads(self, x):
         """x [B,80,T] -> (style [B, 2S] = mu|logvar, content [B, 2Cn] = mu|logvar): encode() without the column split."""
         self._check(x)
+        self._refresh_derived()
         B, _, T = x.shape
         return self._encode_frames(mel_to_frames(x.contiguous()), T, B, 1)
 
@@ -294,6 +366,7 @@ class DisentangledVAE(nn.Module):
         """z [B, latent] -> [B,80,T]  (disentangled_vae.py:230-248)"""
         if not z.is_cuda:
             raise RuntimeError("DisentangledVAE.decode runs only on the HIP device")
+        self._refresh_derived()
         B, T = z.shape[0], self.n_frames
         y = self._decode_frames(z.contiguous(), T, B, 1)
         return FramesToMelFn.apply(y, B, N_MEL, T)
@@ -312,6 +385,7 @@ class DisentangledVAE(nn.Module):
         z_style_mu, z_style_logvar)   (disentangled_vae.py:250-279)"""
         self._check(x1)
         self._check(x2)
+        self._refresh_derived()
         Bh, _, T = x1.shape
         N = 2 * Bh
         S, Cn = self.speaker_size, self.latent_dim - self.speaker_size
@@ -320,11 +394,20 @@ class DisentangledVAE(nn.Module):
         eps_c, eps_s = self._eps(Bh, x1.device, train)
         z, q_mu, q_lv, s_mu, s_lv = LatentFn.apply(style, content, eps_c, eps_s, Bh, S, Cn)
         y = self._decode_frames(z, T, N, 2)                              # [T*N, 80]
-        y_hat = self.postnet.forward_frames(y, N, 2, residual=y)         # y + postnet(y)
+        y_hat = self.postnet.forward_frames(y, N, 2, residual=y,         # y + postnet(y)
+                                            wpt=[self._wpt(f"postnet.{i}") for i in range(5)])
         rec = FramesToMelFn.apply(y, N, N_MEL, T)
         rec_hat = FramesToMelFn.apply(y_hat, N, N_MEL, T)
         return (rec[:Bh], rec[Bh:], rec_hat[:Bh], rec_hat[Bh:], q_mu[:Bh], q_lv[:Bh], q_mu[Bh:], q_lv[Bh:],
                 s_mu, s_lv)
+
+    def reference_layout(self, name, tensor):
+        """`tensor` shaped like parameter `name` (its gradient, a moment, ...) in the REFERENCE's layout: conv weights
+        are stored packed [5][Cout][Cin] here and [Cout][Cin][5] in the reference; everything else is identical."""
+        mod = self.get_submodule(name.rsplit(".", 1)[0])
+        if isinstance(mod, _Conv1dParams) and name.endswith(".weight"):
+            return mod.torch_layout(tensor)
+        return tensor
 
     def update_c(self):
         self._c += self._c_delta

@@ -285,22 +285,26 @@ class LinearFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------- Conv1d(k5) + BatchNorm + act
 class ConvBnActFn(torch.autograd.Function):
     """act(BatchNorm1d_train(Conv1d_k5_p2(x))) [+ residual] on frame-major rows.
-    Reference blocks: encoder :151-162/:201-202, decoder :175-191/:242-243, Postnet :43-87."""
+    Reference blocks: encoder :151-162/:201-202, decoder :175-191/:242-243, Postnet :43-87.
+    `conv_wp` is the conv weight in the PACKED layout [5][Cout][Cin] (the layout the parameter lives in, see
+    model/disentangled_vae._Conv1dParams); its gradient is accumulated in the same layout.  `wpt` is the transposed
+    pack [5][Cin][Cout] for the data gradient (derived.DerivedWeights) or None (computed in backward if needed)."""
 
     @staticmethod
-    def forward(ctx, x, conv_w, conv_b, bn_w, bn_b, running_mean, running_var, nbt, residual,
-                n_seg, groups, act, training):
-        _ok(x, conv_w, conv_b, bn_w, bn_b, residual)
+    def forward(ctx, x, conv_wp, conv_b, bn_w, bn_b, running_mean, running_var, nbt, residual,
+                n_seg, groups, act, training, wpt=None):
+        _ok(x, conv_wp, conv_b, bn_w, bn_b, residual)
         L = lib()
         R, Cin = x.shape
-        Cout = conv_w.shape[0]
+        if conv_wp.dim() != 3 or conv_wp.shape[0] != 5 or conv_wp.shape[2] != Cin:
+            raise ValueError(f"conv weight must be packed [5, Cout, Cin={Cin}], got {tuple(conv_wp.shape)}")
+        Cout = conv_wp.shape[1]
         dev = x.device
         st = stream()
         mode = current_mode()
-        wp = torch.empty((5, Cout, Cin), device=dev, dtype=torch.float32)
-        check(L.dvae_conv_pack_w(ptr(conv_w), ptr(wp), Cout, Cin, st), "dvae_conv_pack_w")
         y = torch.empty((R, Cout), device=dev, dtype=torch.float32)
-        check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, st), "dvae_conv5_fwd")
+        check(L.dvae_conv5_fwd(ptr(x), ptr(conv_wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, st),
+              "dvae_conv5_fwd")
         if training:
             G = groups
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
@@ -315,13 +319,13 @@ class ConvBnActFn(torch.autograd.Function):
         z = torch.empty((R, Cout), device=dev, dtype=torch.float32)
         check(L.dvae_bn_apply_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(bn_w), ptr(bn_b), ptr(residual), ptr(z),
                                   R, n_seg, Cout, G, act, st), "dvae_bn_apply_fwd")
-        ctx.save_for_backward(x, wp, y, z, mean, rstd, conv_w, conv_b, bn_w, bn_b)
+        ctx.save_for_backward(x, y, z, mean, rstd, conv_wp, conv_b, bn_w, bn_b, wpt)
         ctx.cfg = (n_seg, G, act, training, residual is not None, mode)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, wp, y, z, mean, rstd, conv_w, conv_b, bn_w, bn_b = ctx.saved_tensors
+        x, y, z, mean, rstd, conv_wp, conv_b, bn_w, bn_b, wpt = ctx.saved_tensors
         n_seg, G, act, training, has_res, mode = ctx.cfg
         if not training:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the training path")
@@ -341,33 +345,41 @@ class ConvBnActFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)
-            # the data gradient contracts over Cout: with the weights re-packed [5][Cin][Cout] both operands are
-            # k-contiguous (the ds_read_b128 fragment path: 370 -> 330 us per 512->512 layer; the pack costs ~6 us)
-            wpt = torch.empty((5, Cin, Cout), device=dev, dtype=torch.float32)
-            check(L.dvae_conv_pack_wt(ptr(conv_w), ptr(wpt), Cout, Cin, st), "dvae_conv_pack_wt")
+            # the data gradient contracts over Cout: against the transposed pack [5][Cin][Cout] both operands are
+            # k-contiguous (the ds_read_b128 fragment path)
+            if wpt is None:
+                from .derived import conv_wpt_local
+                wpt = conv_wpt_local(conv_wp)
             check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, mode, st),
                   "dvae_conv5_dgrad_t")
         with side_work(dy, x):
-            st2 = stream()
-            dwp = torch.zeros((5, Cout, Cin), device=dev, dtype=torch.float32)
+            # the weight gradient goes straight into the (packed) gradient view: atomic split-K epilogue
             sk = _split_k(5 * _tiles(Cout, Cin), R)
-            check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(dwp), R, n_seg, Cin, Cout, sk, mode, st2),
+            check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(_grad_buf(conv_wp)), R, n_seg, Cin, Cout, sk, mode, stream()),
                   "dvae_conv5_wgrad")
-            check(L.dvae_conv_unpack_add_w(ptr(dwp), ptr(_grad_buf(conv_w)), Cout, Cin, st2),
-                  "dvae_conv_unpack_add_w")
             colsum_add(dy, _grad_buf(conv_b))
-        _ready(conv_w, conv_b, bn_w, bn_b)
+        _ready(conv_wp, conv_b, bn_w, bn_b)
         dres = dz if has_res else None
-        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None)
+        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------- LSTM layer
+def _lstm_derived(derived, params, bf):
+    """Per direction: (bias sum, W_ih^T, W_hh^T, fragment packs) — from the model's DerivedWeights when given, else
+    computed on the spot (stand-alone use)."""
+    if derived is not None:
+        return list(derived)
+    from .derived import lstm_local
+    return [lstm_local(wi, wh, bi, bh, bool(bf)) for (wi, wh, bi, bh) in params]
+
+
 class LstmLayerFn(torch.autograd.Function):
     """One nn.LSTM layer (1 or 2 directions) over frame-major rows: x[T*N, In] -> h[T*N, ndir*H].
-    Reference: enc_lstm :163/:208, dec_lstm1 :172/:238, dec_lstm2 :193/:246."""
+    Reference: enc_lstm :163/:208, dec_lstm1 :172/:238, dec_lstm2 :193/:246.
+    `derived`: list of derived.LstmDerived, one per direction (or None)."""
 
     @staticmethod
-    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, derived=None):
         _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         L = lib()
         st = stream()
@@ -380,37 +392,29 @@ class LstmLayerFn(torch.autograd.Function):
         params = [(w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r)][:ndir]
         dirs = (_lib.LstmDir * ndir)()
         # bf16 compute mode: the recurrence runs on bf16 fragments where bf16 frame kernels exist (H = 512, 1024);
-        # the H = 64 encoder recurrence (3 % of the FLOPs, weights resident in registers) stays fp32
-        # (fp32x3 mode: the recurrence runs on the fp32 MFMA — it is bound by W_hh traffic, not by the matrix pipe)
+        # the H = 64 encoder recurrence (3 % of the FLOPs, weights resident in registers) stays fp32.
+        # fp32x3 mode: the recurrence runs on the fp32 MFMA — it is bound by W_hh traffic, not by the matrix pipe.
         mode = current_mode()
         bf = 1 if (mode == MODE_BF16 and H % 512 == 0) else 0
-        gates, cells, packs_b, keep = [], [], [], []
+        der = _lstm_derived(derived, params, bf)
+        gates, cells = [], []
         for d, (wi, wh, bi, bh) in enumerate(params):
             g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
-            gemm(x, wi, g, bi + bh, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
+            gemm(x, wi, g, der[d].bias, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
             c = torch.empty((R, H), device=dev, dtype=torch.float32)
-            # W_hh re-packed in MFMA fragment order (forward copy used now, backward copy saved)
-            wp_f = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
-            wp_b = torch.empty((4 * H * H,), device=dev, dtype=torch.float32)
-            if bf:
-                check(L.dvae_lstm_pack_w_bf16(ptr(wh), ptr(wp_f), ptr(wp_b), H, st), "dvae_lstm_pack_w_bf16")
-            else:
-                check(L.dvae_lstm_pack_w(ptr(wh), ptr(wp_f), ptr(wp_b), H, st), "dvae_lstm_pack_w")
             gates.append(g)
             cells.append(c)
-            packs_b.append(wp_b)
-            keep.append(wp_f)
             dirs[d].gates = ptr(g)
             dirs[d].w_hh = ptr(wh)
-            dirs[d].w_packed = ptr(wp_f)
+            dirs[d].w_packed = ptr(der[d].pack_f)
             dirs[d].packed_bf16 = bf
             dirs[d].h_out = h_out.data_ptr() + 4 * d * H
             dirs[d].c_all = ptr(c)
             dirs[d].reverse = d
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
-        ctx.save_for_backward(x, h_out, *gates, *cells, *packs_b, *[p for ps in params for p in ps])
+        ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
+        ctx.der = der
         ctx.cfg = (T, N, H, ndir, bf, mode)
-        del keep
         return h_out
 
     @staticmethod
@@ -420,9 +424,9 @@ class LstmLayerFn(torch.autograd.Function):
         x, h_out = sv[0], sv[1]
         gates = sv[2:2 + ndir]
         cells = sv[2 + ndir:2 + 2 * ndir]
-        packs_b = sv[2 + 2 * ndir:2 + 3 * ndir]
-        flat = sv[2 + 3 * ndir:]
+        flat = sv[2 + 2 * ndir:]
         params = [flat[4 * d:4 * d + 4] for d in range(ndir)]
+        der = ctx.der
         L = lib()
         st = stream()
         dev = x.device
@@ -432,15 +436,14 @@ class LstmLayerFn(torch.autograd.Function):
         dirs = (_lib.LstmDir * ndir)()
         keep = []
         dgs = []
-        for d, (wi, wh, bi, bh) in enumerate(params):
-            wht = transpose2d(wh)  # [H, 4H]
+        for d in range(ndir):
             dg = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
             dc = torch.empty((N, H), device=dev, dtype=torch.float32)
-            keep += [wht, dc]
+            keep.append(dc)
             dgs.append(dg)
             dirs[d].gates = ptr(gates[d])
-            dirs[d].w_hh = ptr(wht)
-            dirs[d].w_packed = ptr(packs_b[d])
+            dirs[d].w_hh = ptr(der[d].w_hh_t)       # [H, 4H]
+            dirs[d].w_packed = ptr(der[d].pack_b)
             dirs[d].packed_bf16 = bf
             dirs[d].c_all = ptr(cells[d])
             dirs[d].dh_out = dh.data_ptr() + 4 * d * H
@@ -451,11 +454,9 @@ class LstmLayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), device=dev, dtype=torch.float32)
-            for d, (wi, wh, bi, bh) in enumerate(params):
-                # dx = dgates @ W_ih contracts over 4H: against W_ih^T both operands are k-contiguous (the faster
-                # fragment path; the transpose of a few MB is ~10 us, the big projections gain 30-70 us each)
-                wit = transpose2d(wi)                      # [In, 4H]
-                gemm(dgs[d], wit, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
+            for d in range(ndir):
+                # dx = dgates @ W_ih contracts over 4H: against W_ih^T both operands are k-contiguous
+                gemm(dgs[d], der[d].w_ih_t, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
                      EPI_STORE if d == 0 else EPI_ACCUM, mode=mode)
         with side_work(x, h_out, *dgs):
             for d, (wi, wh, bi, bh) in enumerate(params):
@@ -475,7 +476,7 @@ class LstmLayerFn(torch.autograd.Function):
         for (wi, wh, bi, bh) in params:
             _ready(wi, wh, bi, bh)
         del keep
-        return (dx,) + (None,) * 10
+        return (dx,) + (None,) * 11
 
 
 class LstmStack2Fn(torch.autograd.Function):
@@ -484,7 +485,8 @@ class LstmStack2Fn(torch.autograd.Function):
     chunk c+1, layer 2 runs chunk c in the SAME launches (dvae_lstm_seq_*_range with step_shift), after layer 1's
     chunk-c outputs went through layer 2's input projection.  Same arithmetic per frame as two LstmLayerFn calls —
     only the launch schedule changes: T + CHUNK launches of 2x the workgroups instead of 2T, two workgroups resident
-    per CU so one layer's load latency hides under the other's MFMAs.  Backward mirrors it (layer 2 ahead)."""
+    per CU so one layer's load latency hides under the other's MFMAs.  Backward mirrors it (layer 2 ahead).
+    `derived`: [LstmDerived of layer 1, LstmDerived of layer 2] (or None)."""
 
     CHUNK = int(os.environ.get("DVAE_LSTM_CHUNK", "-1"))      # frames per chunk; -1: two chunks (T/2), 0: off
     # measured at T = 128 (ms/step): unstacked 34.35, chunks of 16 / 32 / 64 frames 34.25 / 34.06 / 34.03
@@ -501,7 +503,7 @@ class LstmStack2Fn(torch.autograd.Function):
         return layers == 2 and not bidirectional and H % 512 == 0 and Tc > 0 and T % Tc == 0 and T // Tc >= 2
 
     @staticmethod
-    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2):
+    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, derived=None):
         _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
         L, st, dev = lib(), stream(), x.device
         R, In = x.shape
@@ -509,38 +511,34 @@ class LstmStack2Fn(torch.autograd.Function):
         Tc = LstmStack2Fn.chunk(T)
         mode = current_mode()
         bf = 1 if mode == MODE_BF16 else 0
+        der = _lstm_derived(derived, [(w_ih1, w_hh1, b_ih1, b_hh1), (w_ih2, w_hh2, b_ih2, b_hh2)], bf)
         f32 = dict(device=dev, dtype=torch.float32)
         g1, g2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
         c1, c2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
         h1, h2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
-        gemm(x, w_ih1, g1, b_ih1 + b_hh1, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
-        bias2 = b_ih2 + b_hh2
-        packs = []
-        for wh in (w_hh1, w_hh2):
-            pf, pb = torch.empty((4 * H * H,), **f32), torch.empty((4 * H * H,), **f32)
-            check((L.dvae_lstm_pack_w_bf16 if bf else L.dvae_lstm_pack_w)(ptr(wh), ptr(pf), ptr(pb), H, st), "lstm_pack_w")
-            packs.append((pf, pb))
+        gemm(x, w_ih1, g1, der[0].bias, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
         dirs = (_lib.LstmDir * 2)()
         for d, (g, wh, h, c) in enumerate(((g1, w_hh1, h1, c1), (g2, w_hh2, h2, c2))):
-            dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed = ptr(g), ptr(wh), ptr(packs[d][0])
+            dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed = ptr(g), ptr(wh), ptr(der[d].pack_f)
             dirs[d].h_out, dirs[d].c_all = ptr(h), ptr(c)
             dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
         rows = Tc * N
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
                 r0 = (c0 - Tc) * N
-                gemm(h1.data_ptr() + 4 * r0 * H, w_ih2, g2.data_ptr() + 4 * r0 * 4 * H, bias2,
+                gemm(h1.data_ptr() + 4 * r0 * H, w_ih2, g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias,
                      rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode)
             check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
-        ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, packs[0][1], packs[1][1], w_ih1, w_hh1, b_ih1, b_hh1,
-                              w_ih2, w_hh2, b_ih2, b_hh2)
+        ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
+        ctx.der = der
         ctx.cfg = (T, N, H, bf, mode)
         return h2
 
     @staticmethod
     def backward(ctx, dh2):
         T, N, H, bf, mode = ctx.cfg
-        (x, h1, h2, g1, g2, c1, c2, pb1, pb2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2) = ctx.saved_tensors
+        (x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2) = ctx.saved_tensors
+        der = ctx.der
         L, st, dev = lib(), stream(), x.device
         R, In = x.shape
         Tc = LstmStack2Fn.chunk(T)
@@ -549,25 +547,23 @@ class LstmStack2Fn(torch.autograd.Function):
         dg1, dg2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
         dh1 = torch.empty((R, H), **f32)                   # gradient w.r.t. layer 1's outputs = layer 2's dgrad
         dcs = [torch.empty((N, H), **f32) for _ in range(2)]
-        whts = [transpose2d(w_hh1), transpose2d(w_hh2)]
         # backward step s handles frame T-1-s.  Entry 0 = layer 2 (ahead), entry 1 = layer 1 (a chunk behind).
         dirs = (_lib.LstmDir * 2)()
-        for d, (g, wht, pb, c, dho, dg) in enumerate(((g2, whts[1], pb2, c2, dh2, dg2), (g1, whts[0], pb1, c1, dh1, dg1))):
-            dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed, dirs[d].c_all = ptr(g), ptr(wht), ptr(pb), ptr(c)
+        for d, (g, dd, c, dho, dg) in enumerate(((g2, der[1], c2, dh2, dg2), (g1, der[0], c1, dh1, dg1))):
+            dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed, dirs[d].c_all = ptr(g), ptr(dd.w_hh_t), ptr(dd.pack_b), ptr(c)
             dirs[d].dh_out, dirs[d].dgates, dirs[d].dc_ws = ptr(dho), ptr(dg), ptr(dcs[d])
             dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
         rows = Tc * N
-        w_ih2t = transpose2d(w_ih2)      # [H, 4H]: both operands of the data gradients k-contiguous (see LstmLayerFn)
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 2 finished backward steps [c0-Tc, c0) = frames [T-c0, T-c0+Tc): dgrad into dh1
                 r0 = (T - c0) * N
-                gemm(dg2.data_ptr() + 4 * r0 * 4 * H, w_ih2t, dh1.data_ptr() + 4 * r0 * H, None,
+                gemm(dg2.data_ptr() + 4 * r0 * 4 * H, der[1].w_ih_t, dh1.data_ptr() + 4 * r0 * H, None,
                      rows, H, 4 * H, 4 * H, 4 * H, H, True, True, mode=mode)
             check(L.dvae_lstm_seq_bwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_bwd_range")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), **f32)
-            gemm(dg1, transpose2d(w_ih1), dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, mode=mode)
+            gemm(dg1, der[0].w_ih_t, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, mode=mode)
         with side_work(x, h1, h2, dg1, dg2):
             for dg, inp, hh, wi, wh, bi, bh in ((dg2, h1, h2, w_ih2, w_hh2, b_ih2, b_hh2),
                                                 (dg1, x, h1, w_ih1, w_hh1, b_ih1, b_hh1)):
@@ -580,8 +576,8 @@ class LstmStack2Fn(torch.autograd.Function):
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         _ready(w_ih2, w_hh2, b_ih2, b_hh2)
         _ready(w_ih1, w_hh1, b_ih1, b_hh1)
-        del whts, dcs
-        return (dx,) + (None,) * 10
+        del dcs
+        return (dx,) + (None,) * 11
 
 
 # ----------------------------------------------------------------------------- layout

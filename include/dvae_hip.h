@@ -149,6 +149,27 @@ typedef struct {
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
 /* bf16 compute mode: the same copies rounded to bf16 (each 4H*H bf16 values = 2*4H*H bytes) */
 int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream);
+/* ---- all weight-derived operand layouts of a model in ONE launch (once per training step, after Adam) ----
+ * kind CONV_T    src Wp[5][d0=Cout][d1=Cin]                 -> dst Wpt[5][Cin][Cout]  (operand of dvae_conv5_dgrad_t)
+ *      LSTM_PACK src W_hh[4*d0][d0], d0 = H                 -> dst packed_fwd, dst2 packed_bwd (either may be null);
+ *                                                              bf16 fragments instead of fp32 ones when lstm_bf16 != 0
+ *                                                              and H % 512 == 0 (see dvae_lstm_pack_w[_bf16])
+ *      TRANSPOSE src W[d0][d1]                              -> dst W^T[d1][d0]
+ *      ADD2      src, src2 [d0]                             -> dst = src + src2        (b_ih + b_hh)
+ * `descs` is a HOST array of n <= 56 entries (copied into the launch); the device buffers are the caller's. */
+#define DVAE_REPACK_CONV_T 0
+#define DVAE_REPACK_LSTM_PACK 1
+#define DVAE_REPACK_TRANSPOSE 2
+#define DVAE_REPACK_ADD2 3
+typedef struct {
+  int kind, d0, d1, d2;
+  const void* src;
+  const void* src2;
+  void* dst;
+  void* dst2;
+} dvae_repack_desc_t;
+int dvae_repack_all(const dvae_repack_desc_t* descs, int n, int lstm_bf16, void* stream);
+
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 /* launches of global steps [step_begin, step_end) only (H a multiple of 512, packed weights); the `dirs` entries may be

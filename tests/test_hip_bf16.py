@@ -202,6 +202,7 @@ def test_model_bf16_stage_by_stage(ops):
     m.load_state_dict(fill_state_dict(m.state_dict()))
     m.train()
     hm = _make(B, T).model
+    hm._refresh_derived()
     got = {}
     with torch.no_grad():
         x = x1
@@ -213,7 +214,7 @@ def test_model_bf16_stage_by_stage(ops):
             got[f"enc conv block {i}"] = (_dist(_unframes(y, B, T), ref), 1e-5)
             x = ref
         seq = R.lstm(m.enc_lstm, x.transpose(1, 2))
-        got["enc_lstm"] = (_dist(_unframes(hm._lstm(hm.enc_lstm, _frames(x), T, B), B, T), seq.transpose(1, 2)), 2e-4)
+        got["enc_lstm"] = (_dist(_unframes(hm._lstm("enc_lstm", _frames(x), T, B), B, T), seq.transpose(1, 2)), 2e-4)
         flat = seq.reshape(B, -1)
         lin = hm.enc_linear.linear_layer
         got["enc_linear"] = (_dist(LinearFn.apply(flat.cuda().contiguous(), lin.weight, lin.bias, ACT_RELU),
@@ -228,7 +229,7 @@ def test_model_bf16_stage_by_stage(ops):
         hh = h2.view(B, T, 128)
         ref = R.lstm(m.dec_lstm1, hh)
         got["dec_lstm1 (H=512, bf16 recurrence)"] = (
-            _dist(_unframes(hm._lstm(hm.dec_lstm1, _frames(hh.transpose(1, 2)), T, B), B, T), ref.transpose(1, 2)), 2e-3)
+            _dist(_unframes(hm._lstm("dec_lstm1", _frames(hh.transpose(1, 2)), T, B), B, T), ref.transpose(1, 2)), 2e-3)
         x = ref.transpose(1, 2)
         for i, (blk, hblk) in enumerate(zip(m.dec_modules, hm.dec_modules)):
             ref = F.relu(R._conv_bn(blk, x))
@@ -239,7 +240,7 @@ def test_model_bf16_stage_by_stage(ops):
             x = ref
         ref = R.lstm(m.dec_lstm2, x.transpose(1, 2))
         got["dec_lstm2 (2 x H=1024, bf16 recurrence)"] = (
-            _dist(_unframes(hm._lstm(hm.dec_lstm2, _frames(x), T, B), B, T), ref.transpose(1, 2)), 5e-3)
+            _dist(_unframes(hm._lstm("dec_lstm2", _frames(x), T, B), B, T), ref.transpose(1, 2)), 5e-3)
         yv = R._lin(m.dec_linear2, ref)
         lin = hm.dec_linear2.linear_layer
         got["dec_linear2"] = (_dist(_unframes(LinearFn.apply(_frames(ref.transpose(1, 2)), lin.weight, lin.bias,
@@ -285,7 +286,7 @@ def test_model_bf16_losses_and_gradients(ops, B, T):
     for k, p in w.model.named_parameters():
         if ".0.conv.bias" in k or k.endswith(".0.bias"):        # pre-BatchNorm conv biases: pure round-off
             continue
-        g16, g32, gh = grads["bf16"][k], grads["fp32"][k], p.grad.cpu()
+        g16, g32, gh = grads["bf16"][k], grads["fp32"][k], w.model.reference_layout(k, p.grad).cpu()
         noise = _dist(g16, g32)                                  # what bf16 rounding does to this gradient
         assert _dist(gh, g16) <= max(3e-2, 1.6 * noise), (k, _dist(gh, g16), noise)
         cos = float((gh.double() * g16.double()).sum() / (gh.double().norm() * g16.double().norm()))

@@ -154,7 +154,8 @@ def test_conv_bn_act_block(ops, N, T, Cc, G, act):
     z_ref.backward(gz)
 
     P = lambda t: torch.nn.Parameter(dev(t.detach().clone()))
-    cw, cb, bw, bb = P(conv.weight), P(conv.bias), P(torch.ones(Cc)), P(torch.zeros(Cc))
+    # conv weights are handed to the op in the packed layout [5][Cout][Cin] the parameter lives in
+    cw, cb, bw, bb = P(conv.weight.permute(2, 0, 1).contiguous()), P(conv.bias), P(torch.ones(Cc)), P(torch.zeros(Cc))
     with torch.no_grad():
         bw.copy_(bn.weight)
         bb.copy_(bn.bias)
@@ -168,7 +169,7 @@ def test_conv_bn_act_block(ops, N, T, Cc, G, act):
     assert int(nbt.item()) == G
     z.backward(dev(to_frames(gz)))
     close(from_frames(xf.grad.cpu(), N, T), xr.grad, rel=5e-4, name="bn_dx")
-    close(cw.grad, conv.weight.grad, rel=5e-4, name="conv_w.grad")
+    close(cw.grad.permute(1, 2, 0), conv.weight.grad, rel=5e-4, name="conv_w.grad")
     close(bw.grad, bn.weight.grad, rel=5e-4, name="bn_w.grad")
     close(bb.grad, bn.bias.grad, rel=5e-4, name="bn_b.grad")
     assert float(cb.grad.abs().max()) < 1e-2 * max(1.0, float(gz.abs().sum()) ** 0.5)  # ~0 (cancels in BN)
@@ -178,14 +179,15 @@ def test_bn_residual(ops):
     N, T, Cc = 4, 16, 80
     x = rnd(N, Cc, T, seed=1)
     P = lambda t: torch.nn.Parameter(dev(t))
-    cw, cb = P(rnd(Cc, Cc, 5, seed=2) * 0.2), P(torch.zeros(Cc))
+    w_t = rnd(Cc, Cc, 5, seed=2) * 0.2                               # torch layout [Cout][Cin][5]
+    cw, cb = P(w_t.permute(2, 0, 1).contiguous()), P(torch.zeros(Cc))  # packed [5][Cout][Cin]
     bw, bb = P(torch.ones(Cc)), P(torch.zeros(Cc))
     xf = dev(to_frames(x)).requires_grad_()
     nbt = torch.zeros((), dtype=torch.long, device="cuda")
     z = ops.ConvBnActFn.apply(xf, cw, cb, bw, bb, torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda"),
                               nbt, xf, N, 1, 0, True)
     ref_in = x.clone().requires_grad_()
-    ref = ref_in + F.batch_norm(F.conv1d(ref_in, cw.detach().cpu(), None, padding=2), None, None, training=True)
+    ref = ref_in + F.batch_norm(F.conv1d(ref_in, w_t, None, padding=2), None, None, training=True)
     close(from_frames(z.detach().cpu(), N, T), ref, name="residual_fwd")
     gz = rnd(N, Cc, T, seed=3)
     z.backward(dev(to_frames(gz)))
@@ -412,7 +414,7 @@ def test_bn_one_group_equals_two_separate_calls(ops):
     N, T, Cc = 8, 16, 512
     x = rnd(N, 80, T, seed=1)
     P = lambda t: torch.nn.Parameter(dev(t))
-    cw, cb = P(rnd(Cc, 80, 5, seed=2) * 0.2), P(rnd(Cc, seed=3))
+    cw, cb = P((rnd(Cc, 80, 5, seed=2) * 0.2).permute(2, 0, 1).contiguous()), P(rnd(Cc, seed=3))
     bw, bb = P(rnd(Cc, seed=4, lo=0.5, hi=1.5)), P(rnd(Cc, seed=5) * 0.1)
     def run(xs, G, rm, rv, nbt):
         return ops.ConvBnActFn.apply(dev(to_frames(xs)), cw, cb, bw, bb, rm, rv, nbt, None, xs.shape[0], G, 2, True)

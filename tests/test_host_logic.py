@@ -163,8 +163,9 @@ def test_init_matches_reference_init_weights():
             n_bn += 1
         elif name.endswith(".1.bias"):
             assert torch.equal(p.detach(), torch.zeros_like(p)), name
-        elif p.dim() == 3:                                    # Conv1d weight [Cout, Cin, 5]
-            fan_in, fan_out = p.shape[1] * p.shape[2], p.shape[0] * p.shape[2]
+        elif p.dim() == 3:                                    # Conv1d weight, stored packed [5, Cout, Cin]
+            assert p.shape[0] == 5 and tuple(m.state_dict()[name].shape) == (p.shape[1], p.shape[2], 5), name
+            fan_in, fan_out = p.shape[2] * 5, p.shape[1] * 5
             bound = math.sqrt(6.0 / (fan_in + fan_out))
             p = p.detach()
             assert float(p.abs().max()) <= bound * (1 + 1e-6) and float(p.abs().max()) > 0.95 * bound, name
