@@ -12,7 +12,7 @@ import subprocess
 import torch  # noqa: F401  (loads torch's bundled libamdhip64.so.7 first, so ours binds to the same runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvae_hip.so")
+LIB_PATH = os.environ.get("DVAE_LIB_PATH") or os.path.join(_HERE, "libdvae_hip.so")   # env: experimental builds (scripts/)
 _lib = None
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -37,6 +37,8 @@ REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2 = 0, 1, 2, 3
 MODE_F32, MODE_BF16, MODE_F32X3 = 0, 1, 2
 COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16": MODE_BF16, "bfloat16": MODE_BF16,
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
+
+DEFAULT_COMPUTE_DTYPE = "fp32x3"
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
@@ -90,6 +92,8 @@ SIGNATURES = {
     "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
     "dvae_prof_enable": (i32, [i32]),
     "dvae_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
+    "dvae_prof_collect_tags": (i32, [C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), i32]),
 }
 
 
@@ -118,7 +122,9 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = h
-        mode = os.environ.get("DVAE_COMPUTE_DTYPE", "").lower()   # same as ops.set_compute_dtype(...), for scripts
+        # process default of the contraction arithmetic (ops.set_compute_dtype changes it): fp32 results on the bf16
+        # matrix pipe unless the environment says otherwise
+        mode = os.environ.get("DVAE_COMPUTE_DTYPE", DEFAULT_COMPUTE_DTYPE).lower()
         if mode in COMPUTE_MODES:
             h.dvae_set_compute_mode(COMPUTE_MODES[mode])
         elif mode:

@@ -12,7 +12,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-extern int g_dvae_compute_mode;   // gemm.hip: 0 fp32 MFMA, 1 bf16 operands with fp32 accumulation
+extern int g_dvae_compute_mode;   // gemm.hip: process default of the contraction arithmetic (DVAE_MODE_*)
 
 extern int g_dvae_last_hip_error;
 
@@ -26,7 +26,7 @@ static inline int dvae_check_launch() {
 }
 
 // ---- profiling hooks (prof.cpp) ----
-void dvae_prof_begin(int family, hipStream_t s, double flops);
+void dvae_prof_begin(int family, hipStream_t s, double flops, unsigned tag, double bytes);
 void dvae_prof_end(int family, hipStream_t s);
 extern int g_dvae_prof_family;
 
@@ -34,9 +34,9 @@ struct ProfScope {
   int fam;
   hipStream_t s;
   bool on;
-  ProfScope(int family, hipStream_t st, double flops) : fam(family), s(st) {
+  ProfScope(int family, hipStream_t st, double flops, unsigned tag = 0, double bytes = 0.0) : fam(family), s(st) {
     on = (g_dvae_prof_family == family);
-    if (on) dvae_prof_begin(family, s, flops);
+    if (on) dvae_prof_begin(family, s, flops, tag, bytes);
   }
   ~ProfScope() {
     if (on) dvae_prof_end(fam, s);

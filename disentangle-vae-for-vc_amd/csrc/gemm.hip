@@ -24,6 +24,10 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef DVAE_X3_PD
+#define DVAE_X3_PD 2   // k-tiles in flight ahead of the one being computed (split mode), see the kernel
+#endif
+
 int g_dvae_compute_mode = 0;   // process default of the contraction mode (DVAE_MODE_*, dvae_set_compute_mode)
 
 #ifdef DVAE_GEMM_TS
@@ -198,14 +202,19 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   }
   const int64_t b_shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
 
-  f32x4 ra[NLA], rb[NLB];
+  // PD = prefetch distance in k-tiles = number of register sets.  A 16-deep split-mode tile is only 24 MFMAs (768
+  // cycles) per wave: one tile of cover is shorter than the L2 / Infinity-Cache latency under load (measured: 3 900
+  // cycles per k-tile with PD = 1 against 1 536 of MFMA issue for the two co-resident waves), so tile t+PD is fetched
+  // while tile t computes; the sets are small (4 float4 per thread) in this mode.
+  constexpr int PD = X3 ? DVAE_X3_PD : 1;
+  f32x4 ra_[PD][NLA], rb_[PD][NLB];
 
   // (tap, kit) of the tile being fetched; uniform
   // Branch-free loads: a lane whose element does not exist (ragged edge, conv padding, k tail) reads 16 bytes of zeros
   // (g_gemm_zero) instead.  With `if (ok) load` hipcc gives every load its own basic block (s_and_saveexec + branch)
   // and a vmcnt(0) at the loop head, and nothing in the load phase can be scheduled next to an MFMA.
   const float* __restrict__ zsrc = g_gemm_zero;
-  auto load_tiles = [&](int tap, int kit) {
+  auto load_tiles = [&](f32x4 (&ra)[NLA], f32x4 (&rb)[NLB], int tap, int kit) {
     const int kofs = kit * BK;
     const int64_t a_tap = (p.tap_mode == 1) ? (int64_t)(tap - 2) * p.a_row_shift * p.lda : 0;
     const int64_t b_tap = (p.tap_mode == 1) ? (int64_t)tap * p.b_tap_stride : 0;
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, f32x4 (&ra)[NLA], f32x4 (&rb)[NLB]) {
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
       const int idx = t + NTHR * j;
@@ -314,9 +323,16 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     }
   };
   if (n_iters > 0) {
-    load_tiles(tap_n, kit_n);
+    load_tiles(ra_[0], rb_[0], tap_n, kit_n);
     advance();
-    store_tiles(0);
+    store_tiles(0, ra_[0], rb_[0]);
+  }
+  if constexpr (PD > 1) {   // tiles 1 .. PD-1 in flight before the loop
+#pragma unroll
+    for (int u = 1; u < PD; ++u) {
+      load_tiles(ra_[u], rb_[u], tap_n, kit_n);
+      advance();
+    }
   }
   __syncthreads();
 
@@ -328,12 +344,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #ifdef DVAE_GEMM_TS
   const unsigned long long ts_t0 = TS_NOW();
 #endif
-  for (int it = 0; it < n_iters; ++it) {
-    const bool more = (it + 1 < n_iters);
-    if (more) {
-      load_tiles(tap_n, kit_n);
-      advance();
-    }
+  auto compute_tile = [&]() {
     if constexpr (B16) {
       // v_mfma_f32_32x32x16_bf16: lane (r = lane&31, h = lane>>5) holds k = 16s + 8h + j, j = 0..7, of row r.
       // k-contiguous image: one ds_read_b128.  Row-contiguous image [k][rows]: two ds_read_b64_tr_b16; lane 4q+pq of
@@ -429,9 +440,37 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-    if (more) store_tiles(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+  };
+  if constexpr (PD == 1) {
+    for (int it = 0; it < n_iters; ++it) {
+      const bool more = (it + 1 < n_iters);
+      if (more) {
+        load_tiles(ra_[0], rb_[0], tap_n, kit_n);
+        advance();
+      }
+      compute_tile();
+      if (more) store_tiles(cur ^ 1, ra_[0], rb_[0]);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    // tile t lives in set t % PD: fetched at the top of iteration t - PD, staged into LDS at the end of iteration t - 1.
+    // The loop body is branch-free: the iteration count is rounded up to a multiple of PD and tiles past the end load
+    // zeros (the k bound check of load_tiles) — at most PD-1 wasted tiles per workgroup — so the PD iterations of a trip
+    // are one basic block: the accumulators stay in place and the compiler keeps COUNTED vmcnt waits (the stage of tile
+    // it+1 waits for its own loads only, the younger sets stay in flight across the barrier).
+    for (int it0 = 0; it0 < n_iters; it0 += PD) {
+#pragma unroll
+      for (int u = 0; u < PD; ++u) {
+        // set u is free (tile it0+u was staged an iteration ago): tile it0 + u + PD goes there
+        load_tiles(ra_[u], rb_[u], tap_n, kit_n);
+        advance();
+        compute_tile();
+        store_tiles(cur ^ 1, ra_[(u + 1) % PD], rb_[(u + 1) % PD]);
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
   }
 #ifdef DVAE_GEMM_TS
   if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0) {
@@ -554,7 +593,14 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   static const int xcd_env = getenv("DVAE_GEMM_XCDMAP") ? atoi(getenv("DVAE_GEMM_XCDMAP")) : 1;
   p.xcd_map = (xcd_env && (p.tiles_m % 8 == 0) && (xcd_env == 2 || p.tap_mode == 1)) ? 1 : 0;
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
-  ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * (p.tap_mode ? p.taps : 1));
+  // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
+  const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
+                       ((big ? 4u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15);
+  // algorithmic bytes: every operand element once (the activation matrix of a conv once, not once per tap)
+  const double ntap = p.tap_mode ? p.taps : 1;
+  const double alg_bytes = 4.0 * ((double)p.M * p.K + (double)p.K * p.N * (p.tap_mode == 1 ? ntap : 1.0) +
+                                  (double)p.M * p.N * (p.tap_mode == 2 ? ntap : 1.0));
+  ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap, tag, alg_bytes);
   if (a_kc && b_kc)
     launch_variant<true, true>(p, grid, s, narrow, bk, big, mode);
   else if (a_kc && !b_kc)

@@ -24,6 +24,19 @@
 #include <type_traits>
 #include "common.h"
 
+// Streaming operands of a frame (pre-activations, cell state, h, dgates: touched once per frame) can be tagged
+// non-temporal so that they do not push the re-used W_hh fragments out of the XCD's L2.
+#ifndef DVAE_LSTM_NT
+#define DVAE_LSTM_NT 0
+#endif
+#if DVAE_LSTM_NT
+#define LD_S(p) __builtin_nontemporal_load(p)
+#define ST_S(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define LD_S(p) (*(p))
+#define ST_S(p, v) (*(p) = (v))
+#endif
+
 namespace {
 
 struct StepDir {
@@ -364,8 +377,8 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
   const bool eok = (tid < MT * 256) && (en < N);
   float pre[4], cp;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) pre[g] = eok ? G[(int64_t)en * 4 * H + g * H + ej] : 0.f;
-  cp = (eok && step > 0) ? d.c_all[((int64_t)tp * N + en) * H + ej] : 0.f;
+  for (int g = 0; g < 4; ++g) pre[g] = eok ? LD_S(&G[(int64_t)en * 4 * H + g * H + ej]) : 0.f;
+  cp = (eok && step > 0) ? LD_S(&d.c_all[((int64_t)tp * N + en) * H + ej]) : 0.f;
 
   f32x4 acc[MT];
 #pragma unroll
@@ -467,11 +480,11 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
     const float gg = gate_tanh(sm[2][row][col] + sm[6][row][col] + pre[2]);
     const float go = gate_sigmoid(sm[3][row][col] + sm[7][row][col] + pre[3]);
     const float c = gf * cp + gi * gg;
-    g[0] = gi;
-    g[H] = gf;
-    g[2 * H] = gg;
-    g[3 * H] = go;
-    d.c_all[((int64_t)t * N + en) * H + ej] = c;
+    ST_S(&g[0], gi);
+    ST_S(&g[H], gf);
+    ST_S(&g[2 * H], gg);
+    ST_S(&g[3 * H], go);
+    ST_S(&d.c_all[((int64_t)t * N + en) * H + ej], c);
     d.h_out[((int64_t)t * N + en) * a.ldh + ej] = go * gate_tanh(c);
   }
 }

@@ -9,21 +9,26 @@ int g_dvae_prof_family = 0;
 namespace {
 struct Rec {
   hipEvent_t a, b;
+  unsigned tag;      // which instantiation of the family this launch ran (dvae_prof_collect_tags)
+  double flops, bytes;
 };
 std::vector<Rec> g_pool;   // grows on demand while profiling is enabled
 size_t g_used = 0;
 double g_flops = 0.0;
 }  // namespace
 
-void dvae_prof_begin(int family, hipStream_t s, double flops) {
+void dvae_prof_begin(int family, hipStream_t s, double flops, unsigned tag, double bytes) {
   (void)family;
   if (g_used == g_pool.size()) {
-    Rec r;
+    Rec r{};
     (void)hipEventCreate(&r.a);
     (void)hipEventCreate(&r.b);
     g_pool.push_back(r);
   }
   g_flops += flops;
+  g_pool[g_used].tag = tag;
+  g_pool[g_used].flops = flops;
+  g_pool[g_used].bytes = bytes;
   (void)hipEventRecord(g_pool[g_used].a, s);
 }
 
@@ -38,6 +43,28 @@ DVAE_API int dvae_prof_enable(int family) {
   g_used = 0;
   g_flops = 0.0;
   return DVAE_OK;
+}
+
+// per-instantiation breakdown of what dvae_prof_collect would return; does NOT reset (call dvae_prof_collect after it).
+// Returns the number of distinct tags (<= max_tags are written).
+DVAE_API int dvae_prof_collect_tags(unsigned* tags, double* ms, int64_t* launches, double* flops, double* bytes,
+                                    int max_tags) {
+  if (!tags || !ms || !launches || !flops || !bytes || max_tags < 1) return DVAE_EINVAL;
+  int n = 0;
+  for (size_t i = 0; i < g_used; ++i) {
+    (void)hipEventSynchronize(g_pool[i].b);
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, g_pool[i].a, g_pool[i].b);
+    int k = 0;
+    while (k < n && tags[k] != g_pool[i].tag) ++k;
+    if (k == n) {
+      if (n == max_tags) continue;
+      tags[n] = g_pool[i].tag; ms[n] = 0.0; launches[n] = 0; flops[n] = 0.0; bytes[n] = 0.0;
+      ++n;
+    }
+    ms[k] += t; launches[k] += 1; flops[k] += g_pool[i].flops; bytes[k] += g_pool[i].bytes;
+  }
+  return n;
 }
 
 DVAE_API int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops) {

@@ -135,14 +135,16 @@ def _tiles(m, n):
 
 # ----------------------------------------------------------------------------- compute mode
 MODE_F32, MODE_BF16, MODE_F32X3 = _lib.MODE_F32, _lib.MODE_BF16, _lib.MODE_F32X3
+DEFAULT_COMPUTE_DTYPE = _lib.DEFAULT_COMPUTE_DTYPE      # "fp32x3" (DVAE_COMPUTE_DTYPE in the environment overrides)
 _MODE_NAMES = {MODE_F32: "fp32", MODE_BF16: "bf16", MODE_F32X3: "fp32x3"}
 
 
 def set_compute_dtype(name: str):
     """Arithmetic of every contraction (Linear, Conv1d, LSTM input projection and recurrence, all weight gradients):
     "fp32"    fp32 operands on the fp32 MFMA (v_mfma_f32_32x32x2_f32 / 16x16x4_f32; runs at the vector rate);
-    "fp32x3"  fp32 RESULTS on the bf16 matrix pipe: operands split exactly into three bf16 terms, six exact partial
-              products per product, fp32 accumulation (include/dvae_hip.h, DVAE_MODE_F32X3) — BASELINE configs[1]/[3];
+    "fp32x3"  (default) fp32 RESULTS on the bf16 matrix pipe: operands split exactly into three bf16 terms, six exact
+              partial products per product, fp32 accumulation (include/dvae_hip.h, DVAE_MODE_F32X3) — BASELINE
+              configs[1]/[3];
     "bf16"    operands rounded to bf16, fp32 accumulation — BASELINE configs[2]/[4].
     Tensors in HBM, BatchNorm, gates, losses, master weights and Adam are fp32 in every mode.  The mode in force when
     an op's FORWARD runs is recorded in its autograd context and used by its backward launches too."""
@@ -703,6 +705,23 @@ class L1SumFn(torch.autograd.Function):
 
 def prof_enable(family: int):
     check(lib().dvae_prof_enable(family), "dvae_prof_enable")
+
+
+def prof_collect_tags(max_tags: int = 64):
+    """Per-instantiation breakdown [(tag dict, ms, launches, flops)] of the profiled family; call before prof_collect()."""
+    tags, ms = (C.c_uint * max_tags)(), (C.c_double * max_tags)()
+    n_l, fl, by = (C.c_int64 * max_tags)(), (C.c_double * max_tags)(), (C.c_double * max_tags)()
+    n = lib().dvae_prof_collect_tags(tags, ms, n_l, fl, by, max_tags)
+    if n < 0:
+        raise _lib.DvaeHipError(f"dvae_prof_collect_tags failed: rc={n}")
+    out = []
+    for i in range(n):
+        t = int(tags[i])
+        name = (f"gemm_f32_kernel<A_KC={t & 1}, B_KC={(t >> 1) & 1}, NTW={(t >> 2) & 3}, BK={(t >> 4) & 63}, "
+                f"WG={(t >> 10) & 7}, MODE={(t >> 13) & 3}> tap_mode={(t >> 15) & 3}")
+        out.append({"tag": t, "kernel": name, "ms": float(ms[i]), "launches": int(n_l[i]), "flops": float(fl[i]),
+                    "bytes": float(by[i])})
+    return sorted(out, key=lambda d: -d["ms"])
 
 
 def prof_collect():

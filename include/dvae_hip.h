@@ -266,6 +266,11 @@ int dvae_mel_db_normalize(const float* mel, float* out, int M, int n_mels, int64
  * dvae_prof_collect: synchronises the recorded events, returns total ms, launch count and algorithmic FLOPs. */
 int dvae_prof_enable(int family);
 int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
+/* the same, split by kernel instantiation (call BEFORE dvae_prof_collect, which resets).  Contraction family: tag =
+ * a_kcontig | b_kcontig << 1 | NTW << 2 | BK << 4 | WG << 10 | mode << 13 | tap_mode << 15, i.e. the template arguments
+ * of gemm_f32_kernel<A_KC, B_KC, NTW, BK, WG, MODE>; bytes = algorithmic operand bytes (each element once).  Returns the
+ * number of distinct tags (<= max_tags written). */
+int dvae_prof_collect_tags(unsigned* tags, double* ms, int64_t* launches, double* flops, double* bytes, int max_tags);
 /* experiments: n back-to-back launches of an empty kernel (launch-floor probe, scripts/launch_floor.py) */
 int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
 /* experiments: register-only MFMA chains (shape 32 -> 32x32x2 f32, else 16x16x4 f32): the matrix-pipe ceiling of THIS chip */

@@ -17,7 +17,7 @@ def ops():
     from dvae_amd import ops as o
     o.set_compute_dtype("bf16")
     yield o
-    o.set_compute_dtype("fp32")
+    o.set_compute_dtype(o.DEFAULT_COMPUTE_DTYPE)
 
 
 def dev(t):

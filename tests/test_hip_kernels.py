@@ -11,11 +11,15 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["fp32x3", "fp32"])
+def ops(request):
+    """Every kernel test runs under both fp32 arithmetics: the default ("fp32x3": exact three-way bf16 split on the bf16
+    matrix pipe) and the fp32 MFMA ("fp32") — same tolerances."""
     import dvae_amd  # noqa: F401
     from dvae_amd import ops as o
-    return o
+    o.set_compute_dtype(request.param)
+    yield o
+    o.set_compute_dtype(o.DEFAULT_COMPUTE_DTYPE)
 
 
 def dev(t):

@@ -218,7 +218,7 @@ def test_compute_mode_switch_is_host_side_state():
     import dvae_amd  # noqa: F401
     from dvae_amd import ops
     from dvae_amd._lib import lib
-    assert ops.get_compute_dtype() == "fp32"
+    assert ops.get_compute_dtype() == ops.DEFAULT_COMPUTE_DTYPE == "fp32x3"
     try:
         ops.set_compute_dtype("bf16")
         assert lib().dvae_get_compute_mode() == 1 and ops.get_compute_dtype() == "bf16"
@@ -229,8 +229,10 @@ def test_compute_mode_switch_is_host_side_state():
         assert ops.get_compute_dtype() == "bf16"
         with pytest.raises(ValueError):
             ops.set_compute_dtype("fp8")
+        ops.set_compute_dtype("fp32x3")
+        assert lib().dvae_get_compute_mode() == 2
     finally:
-        ops.set_compute_dtype("fp32")
+        ops.set_compute_dtype(ops.DEFAULT_COMPUTE_DTYPE)
 
 
 def test_split_k_chooser():
