@@ -29,6 +29,15 @@
 #ifndef DVAE_LSTM_NT
 #define DVAE_LSTM_NT 0
 #endif
+#ifndef DVAE_LSTM_PF
+#define DVAE_LSTM_PF 2     // rounds of operands in flight in the backward frame kernel (2 or 4)
+#endif
+#ifndef DVAE_LSTM_ROT
+#define DVAE_LSTM_ROT 1
+#endif
+#ifndef DVAE_LSTM_PFF
+#define DVAE_LSTM_PFF 2    // ... and in the forward frame kernel
+#endif
 #if DVAE_LSTM_NT
 #define LD_S(p) __builtin_nontemporal_load(p)
 #define ST_S(p, v) __builtin_nontemporal_store((v), (p))
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
 // BF: bf16 compute mode -- W_hh packed as bf16 in the fragment order of v_mfma_f32_16x16x32_bf16 (lane (r, q) holds
 // k = 32c + 8q + j, j = 0..7, of gate column r: still one 1-KiB burst per wave per chunk, now 32 deep), the h tile
 // rounded to bf16 while it is staged into LDS (272-B rows: conflict-free ds_read_b128), fp32 accumulation and gates.
-template <int MT, int KR, bool BF = false>
+template <int MT, int KR, bool BF = false, int PF = 2>
 __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
   constexpr int NW = 8;
   constexpr int KC = BF ? 32 : 16;                 // k depth of one packed chunk
@@ -391,11 +400,17 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
     const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / KC) + (int64_t)kh * (H / KC / 2)) * 256 + lane * 4;
     // staging: threads 0..255 stage k-half 0, 256..511 k-half 1; 16 lanes per 256-B row segment
     const int skh = tid >> 8, srow = (tid & 255) >> 4, sc4 = tid & 15;
-    auto loadW = [&](f32x4 (&w)[NS], int rd) {
+    // every j-block of an m-block reads the SAME h rows, and a frame's workgroups run in lockstep: started at the same
+    // k they would all pull the same 256-B columns (one L2 channel) at the same moment.  Each j-block therefore walks
+    // the k rounds in its own rotation (the sum over k does not care); nr is a power of two.
+    const int rot = DVAE_LSTM_ROT ? (jb & (nr - 1)) : 0;
+    auto loadW = [&](f32x4 (&w)[NS], int rd_) {
+      const int rd = (rd_ + rot) & (nr - 1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS + s) * 256);
     };
-    auto loadA = [&](f32x4 (&st)[NST], int rd) {
+    auto loadA = [&](f32x4 (&st)[NST], int rd_) {
+      const int rd = (rd_ + rot) & (nr - 1);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int n = min(m0 + srow + 16 * i, N - 1);
@@ -440,29 +455,25 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
       }
       }
     };
-    f32x4 wA[NS], wB[NS], sA[NST], sB[NST];
-    loadA(sA, 0);
-    loadW(wA, 0);
-    storeA(0, sA);
+    // PF register sets (W fragments + h rows of PF rounds) in flight, see the backward kernel; PF divides nr
+    f32x4 wS[PF][NS], sS[PF][NST];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      loadA(sS[u], min(u, last));
+      loadW(wS[u], min(u, last));
+    }
+    storeA(0, sS[0]);
     __syncthreads();
-    if (nr == 1) {
-      compute(0, wA);
-    } else {
-      for (int rd = 0; rd < nr; rd += 2) {   // nr even
-        loadA(sB, rd + 1);
-        loadW(wB, rd + 1);
+    for (int rd0 = 0; rd0 < nr; rd0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads where they are issued (hipcc otherwise sinks them)
+        compute(u & 1, wS[u]);
         __builtin_amdgcn_sched_barrier(0);
-        compute(0, wA);
-        __builtin_amdgcn_sched_barrier(0);
-        storeA(1, sB);
+        storeA((u + 1) & 1, sS[(u + 1) % PF]);
         __syncthreads();
-        loadA(sA, min(rd + 2, last));
-        loadW(wA, min(rd + 2, last));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1, wB);
-        __builtin_amdgcn_sched_barrier(0);
-        storeA(0, sA);
-        __syncthreads();
+        loadA(sS[u], min(rd0 + u + PF, last));
+        loadW(wS[u], min(rd0 + u + PF, last));
       }
     }
   }
@@ -545,7 +556,9 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
       arow[i] = d.dgates + ((int64_t)tn * N + n) * H4 + koff + 4 * lc4;
     }
     const int nr = H / 2 / KR, last = nr - 1;
-    auto loadA = [&](f32x4 (&st)[4 * MT][KR / 64], int rd) {
+    const int rot = DVAE_LSTM_ROT ? (jb & (nr - 1)) : 0;     // see the forward kernel: dG[t+1] rows are shared by all j-blocks
+    auto loadA = [&](f32x4 (&st)[4 * MT][KR / 64], int rd_) {
+      const int rd = (rd_ + rot) & (nr - 1);
 #pragma unroll
       for (int i = 0; i < 4 * MT; ++i)
 #pragma unroll
@@ -563,7 +576,8 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
             *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
         }
     };
-    auto loadB = [&](f32x4 (&b)[NS], int rd) {
+    auto loadB = [&](f32x4 (&b)[NS], int rd_) {
+      const int rd = (rd_ + rot) & (nr - 1);
 #pragma unroll
       for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS + s) * 256);
     };
@@ -591,29 +605,28 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
       }
       }
     };
-    f32x4 bA[NS], bB[NS], sA[4 * MT][KR / 64], sB[4 * MT][KR / 64];
-    loadA(sA, 0);
-    loadB(bA, 0);
-    storeA(0, sA);
+    // PF register sets (dG rows + W fragments of PF rounds) in flight: a 64-deep round is only 16*MT MFMAs per wave
+    // (~1-2 k cycles), shorter than the latency of a load that misses L2 while every CU streams; with PF = 2 (one round
+    // of cover) a round measured ~5 k cycles against 2 k of MFMA issue.  Loads are unconditional (round index clamped).
+    constexpr int PF = DVAE_LSTM_PF;
+    f32x4 bS[PF][NS], sS[PF][4 * MT][KR / 64];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      loadA(sS[u], min(u, last));
+      loadB(bS[u], min(u, last));
+    }
+    storeA(0, sS[0]);
     __builtin_amdgcn_wave_barrier();
-    if (nr == 1) {
-      compute(0, bA);
-    } else {
-      for (int rd = 0; rd < nr; rd += 2) {   // nr even
-        loadA(sB, rd + 1);
-        loadB(bB, rd + 1);
+    for (int rd0 = 0; rd0 < nr; rd0 += PF) {   // nr is a multiple of 4 (H a multiple of 512), PF divides it
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
         __builtin_amdgcn_sched_barrier(0);
-        compute(0, bA);
+        compute(u & 1, bS[u]);
         __builtin_amdgcn_sched_barrier(0);
-        storeA(1, sB);
+        storeA((u + 1) & 1, sS[(u + 1) % PF]);     // the next round's rows, fetched PF-1 rounds ago
         __builtin_amdgcn_wave_barrier();
-        loadA(sA, min(rd + 2, last));
-        loadB(bA, min(rd + 2, last));
-        __builtin_amdgcn_sched_barrier(0);
-        compute(1, bB);
-        __builtin_amdgcn_sched_barrier(0);
-        storeA(0, sA);
-        __builtin_amdgcn_wave_barrier();
+        loadA(sS[u], min(rd0 + u + PF, last));     // set u is free again
+        loadB(bS[u], min(rd0 + u + PF, last));
       }
     }
   }
@@ -928,9 +941,10 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
       if (a.bf16) {
         if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
         else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      } else if (p.mt5 == 2 && p.shifted) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 64>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      } else if (p.mt5 == 2 && p.shifted) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 64, false, DVAE_LSTM_PFF>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      else if (p.mt5 == 2 && H % 1024 == 0) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, false, DVAE_LSTM_PFF>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
       else if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 64, false, DVAE_LSTM_PFF>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
     }
     return dvae_check_launch();
   }

@@ -55,9 +55,11 @@ def main():
     out["stats"] = red.stats
     out["views_intact"] = bool(a.optimizer.views_intact() and b.optimizer.views_intact())
     out["t"] = [a.optimizer.t, b.optimizer.t]
-    pa = [float(p.detach().double().norm()) for p in a.optimizer.params]
-    pb = [float(p.detach().double().norm()) for p in b.optimizer.params]
-    out["param_norm_rel"] = max(abs(x - y) / max(1e-12, abs(x)) for x, y in zip(pa, pb))
+    # distance of the two parameter vectors (Adam's first updates are lr * sign(g): every gradient element that is zero
+    # up to round-off moves its weight by +-lr independently in the two trainers, so the trajectories are not bitwise equal)
+    out["param_dist_rel"] = float((a.optimizer.flat_p - b.optimizer.flat_p).double().norm() /
+                                  a.optimizer.flat_p.double().norm())
+    out["param_moved_rel"] = float(lr * steps * (a.optimizer.numel ** 0.5) / a.optimizer.flat_p.double().norm())
     ma, mb = a.optimizer.exp_avg, b.optimizer.exp_avg
     out["exp_avg_rel"] = float((ma - mb).norm() / ma.norm())
     print("DDPCHILD " + json.dumps(out), flush=True)
