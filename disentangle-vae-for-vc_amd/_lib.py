@@ -21,7 +21,7 @@ vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
-                ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_bf16", i32),
+                ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_mode", i32),
                 ("step_shift", i32), ("pad_", i32)]
 
 
@@ -57,7 +57,8 @@ SIGNATURES = {
     "dvae_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "dvae_lstm_pack_w": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
-    "dvae_repack_all": (i32, [C.POINTER(RepackDesc), i32, i32, vp]),
+    "dvae_lstm_pack_w_x3": (i32, [vp, vp, vp, i32, vp]),
+    "dvae_repack_all": (i32, [C.POINTER(RepackDesc), i32, vp]),
     "dvae_lstm_seq_fwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_bwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_fwd_range": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, i32, i32, vp]),

@@ -32,9 +32,6 @@
 #ifndef DVAE_LSTM_PF
 #define DVAE_LSTM_PF 2     // rounds of operands in flight in the backward frame kernel (2 or 4)
 #endif
-#ifndef DVAE_LSTM_ROT
-#define DVAE_LSTM_ROT 1
-#endif
 #ifndef DVAE_LSTM_PFF
 #define DVAE_LSTM_PFF 2    // ... and in the forward frame kernel
 #endif
@@ -47,6 +44,15 @@
 #endif
 
 namespace {
+
+// x (4 x fp32) -> three bf16x4 planes with x == p[0] + p[1] + p[2] exactly (see gemm.hip, split3)
+__device__ __forceinline__ void split3_bf16(const f32x4& x, bf16x4 (&p)[3]) {
+  p[0] = __builtin_convertvector(x, bf16x4);
+  const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
+  p[1] = __builtin_convertvector(r1, bf16x4);
+  const f32x4 r2 = r1 - __builtin_convertvector(p[1], f32x4);
+  p[2] = __builtin_convertvector(r2, bf16x4);
+}
 
 struct StepDir {
   float* gates;         // [T,N,4H]
@@ -65,7 +71,7 @@ struct StepArgs {
   StepDir d[2];
   int T, N, H;
   int64_t ldh;
-  int bf16;  // packed weights are bf16 fragments (dvae_lstm_pack_w_bf16): bf16 operands, fp32 accumulation
+  int pm;    // precision mode of the packed weights: 0 fp32 fragments, 1 bf16 (dvae_lstm_pack_w_bf16), 2 three bf16 planes (.._x3)
 };
 
 constexpr int KC = 64;   // k-chunk
@@ -350,15 +356,23 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
 // Eight waves = 4 gates (fwd) / k-quarters (bwd) x 2 k-halves give both: two waves per SIMD AND the
 // small traffic; the k-halves meet in the LDS reduction that the epilogue needs anyway.
 // =====================================================================================================
-// BF: bf16 compute mode -- W_hh packed as bf16 in the fragment order of v_mfma_f32_16x16x32_bf16 (lane (r, q) holds
-// k = 32c + 8q + j, j = 0..7, of gate column r: still one 1-KiB burst per wave per chunk, now 32 deep), the h tile
-// rounded to bf16 while it is staged into LDS (272-B rows: conflict-free ds_read_b128), fp32 accumulation and gates.
-template <int MT, int KR, bool BF = false, int PF = 2>
-__global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
+// PM (precision mode of the recurrent product):
+//   0  fp32: W_hh fragments for v_mfma_f32_16x16x4_f32, fp32 h tile in LDS;
+//   1  bf16 compute mode: W_hh packed as bf16 in the fragment order of v_mfma_f32_16x16x32_bf16 (lane (r, q) holds
+//      k = 32c + 8q + j, j = 0..7, of gate column r: one 1-KiB burst per wave per chunk, 32 deep), the h tile rounded to
+//      bf16 while it is staged into LDS (272-B rows: conflict-free ds_read_b128), fp32 accumulation and gates;
+//   2  fp32x3: fp32 RESULTS on the bf16 pipe (see gemm.hip): W_hh packed as THREE bf16 planes (w = w1 + w2 + w3 exactly,
+//      dvae_lstm_pack_w_x3), the h tile split the same way while it is staged (three LDS planes), six exact partial
+//      products per (tile, chunk).  The fp32 MFMA is 16x slower than the bf16 one: at 70 % efficiency it was 9.7 us of a
+//      14.5 us H = 1024 frame; the price is 1.5x the W_hh bytes.
+template <int MT, int KR, int PM = 0, int PF = 2>
+__global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_fwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
   constexpr int NW = 8;
-  constexpr int KC = BF ? 32 : 16;                 // k depth of one packed chunk
-  constexpr int NS = KR / KC, LDA = KR + (BF ? 8 : 4);
-  using lds_t = typename std::conditional<BF, __bf16, float>::type;
+  constexpr bool B16 = (PM != 0);
+  constexpr int NP = (PM == 2) ? 3 : 1;            // bf16 planes per operand
+  constexpr int KC = B16 ? 32 : 16;                // k depth of one packed chunk
+  constexpr int NS = KR / KC, LDA = KR + (B16 ? 8 : 4);
+  using lds_t = typename std::conditional<B16, __bf16, float>::type;
   constexpr int NST = MT * KR / 64;     // float4 per thread per round (activation stage, both k-halves together)
   const StepDir& d = a.d[blockIdx.z];
   const int step = gstep - d.shift;
@@ -373,21 +387,30 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
   const int gate = wave & 3, kh = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
 
-  // h tiles [buffer][k-half][16*MT rows][LDA]; the gate tiles of the epilogue (sm) reuse the same bytes once the last
-  // round has been computed (every round ends with a workgroup barrier), so two workgroups fit in a CU's 160 KB
-  constexpr int AS_BYTES = 2 * 2 * 16 * MT * LDA * (int)sizeof(lds_t), SM_BYTES = NW * MT * 16 * 17 * 4;
+  // h tiles [buffer][k-half][plane][16*MT rows][LDA]; the gate tiles of the epilogue (sm) reuse the same bytes once the
+  // last round has been computed (every round ends with a workgroup barrier), so two workgroups fit in a CU's 160 KB
+  constexpr int PL = 16 * MT * LDA;                 // elements of one plane
+  constexpr int AS_BYTES = 2 * 2 * NP * PL * (int)sizeof(lds_t), SM_BYTES = NW * MT * 16 * 17 * 4;
   __shared__ __attribute__((aligned(16))) char lds_raw[AS_BYTES > SM_BYTES ? AS_BYTES : SM_BYTES];
-  lds_t (*As)[2][16 * MT * LDA] = reinterpret_cast<lds_t (*)[2][16 * MT * LDA]>(lds_raw);
+  lds_t (*As)[2][NP * PL] = reinterpret_cast<lds_t (*)[2][NP * PL]>(lds_raw);
   float (*sm)[MT * 16][17] = reinterpret_cast<float (*)[MT * 16][17]>(lds_raw);
 
-  // epilogue operands: one (segment, unit) element per thread
+  // epilogue operands: (segment, unit) elements of this thread (MT*256 of them over 512 threads)
+  constexpr int NE = (MT * 256 + 511) / 512;
   float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
-  const int en = m0 + (tid >> 4), ej = j0 + (tid & 15);
-  const bool eok = (tid < MT * 256) && (en < N);
-  float pre[4], cp;
+  int en[NE], ej[NE];
+  bool eok[NE];
+  float pre[NE][4], cp[NE];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) pre[g] = eok ? LD_S(&G[(int64_t)en * 4 * H + g * H + ej]) : 0.f;
-  cp = (eok && step > 0) ? LD_S(&d.c_all[((int64_t)tp * N + en) * H + ej]) : 0.f;
+  for (int e = 0; e < NE; ++e) {
+    const int idx = tid + 512 * e;
+    en[e] = m0 + (idx >> 4);
+    ej[e] = j0 + (idx & 15);
+    eok[e] = (idx < MT * 256) && (en[e] < N);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[e][g] = eok[e] ? LD_S(&G[(int64_t)en[e] * 4 * H + g * H + ej[e]]) : 0.f;
+    cp[e] = (eok[e] && step > 0) ? LD_S(&d.c_all[((int64_t)tp * N + en[e]) * H + ej[e]]) : 0.f;
+  }
 
   f32x4 acc[MT];
 #pragma unroll
@@ -396,21 +419,15 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
   if (step > 0) {
     const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
     const int nr = H / KR / 2, last = nr - 1;           // rounds per k-half
-    // packed W: [(gate*n_j + jb)][k-chunk of 16][lane][4]; this wave's chunks start at kh*(H/32)
-    const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / KC) + (int64_t)kh * (H / KC / 2)) * 256 + lane * 4;
+    // packed W: [(gate*n_j + jb)][k-chunk][plane][lane][4 dwords]; this wave's chunks start at kh*(H/KC/2)
+    const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / KC) + (int64_t)kh * (H / KC / 2)) * (256 * NP) + lane * 4;
     // staging: threads 0..255 stage k-half 0, 256..511 k-half 1; 16 lanes per 256-B row segment
     const int skh = tid >> 8, srow = (tid & 255) >> 4, sc4 = tid & 15;
-    // every j-block of an m-block reads the SAME h rows, and a frame's workgroups run in lockstep: started at the same
-    // k they would all pull the same 256-B columns (one L2 channel) at the same moment.  Each j-block therefore walks
-    // the k rounds in its own rotation (the sum over k does not care); nr is a power of two.
-    const int rot = DVAE_LSTM_ROT ? (jb & (nr - 1)) : 0;
-    auto loadW = [&](f32x4 (&w)[NS], int rd_) {
-      const int rd = (rd_ + rot) & (nr - 1);
+    auto loadW = [&](f32x4 (&w)[NS * NP], int rd) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS + s) * 256);
+      for (int s = 0; s < NS * NP; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS * NP + s) * 256);
     };
-    auto loadA = [&](f32x4 (&st)[NST], int rd_) {
-      const int rd = (rd_ + rot) & (nr - 1);
+    auto loadA = [&](f32x4 (&st)[NST], int rd) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int n = min(m0 + srow + 16 * i, N - 1);
@@ -424,22 +441,38 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int q = 0; q < KR / 64; ++q) {
-          if constexpr (BF)
-            *reinterpret_cast<bf16x4*>(&As[buf][skh][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) =
-                __builtin_convertvector(st[i * (KR / 64) + q], bf16x4);
-          else
-            *reinterpret_cast<f32x4*>(&As[buf][skh][(srow + 16 * i) * LDA + 64 * q + 4 * sc4]) = st[i * (KR / 64) + q];
+          const int off = (srow + 16 * i) * LDA + 64 * q + 4 * sc4;
+          const f32x4 v = st[i * (KR / 64) + q];
+          if constexpr (PM == 2) {
+            bf16x4 pl[3];
+            split3_bf16(v, pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&As[buf][skh][p * PL + off]) = pl[p];
+          } else if constexpr (PM == 1) {
+            *reinterpret_cast<bf16x4*>(&As[buf][skh][off]) = __builtin_convertvector(v, bf16x4);
+          } else {
+            *reinterpret_cast<f32x4*>(&As[buf][skh][off]) = v;
+          }
         }
     };
-    auto compute = [&](int buf, f32x4 (&w)[NS]) {
-      if constexpr (BF) {
+    auto compute = [&](int buf, f32x4 (&w)[NS * NP]) {
+      if constexpr (B16) {
         const lds_t* __restrict__ al = &As[buf][kh][r * LDA + 8 * kq];
+        // fp32x3: the six partial products of weight >= 2^-16 (h plane, W plane)
+        constexpr int NT6 = (PM == 2) ? 6 : 1;
+        constexpr int ia[6] = {0, 0, 1, 1, 0, 2}, ib[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                *reinterpret_cast<const bf16x8*>(al + mt * 16 * LDA + 32 * s), __builtin_bit_cast(bf16x8, w[s]), acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 av[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[p] = *reinterpret_cast<const bf16x8*>(al + p * PL + mt * 16 * LDA + 32 * s);
+#pragma unroll
+            for (int term = 0; term < NT6; ++term)
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], __builtin_bit_cast(bf16x8, w[s * NP + ib[term]]),
+                                                                acc[mt], 0, 0, 0);
+          }
       } else {
       const lds_t* __restrict__ al = &As[buf][kh][r * LDA + 4 * kq];
 #pragma unroll
@@ -456,7 +489,7 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
       }
     };
     // PF register sets (W fragments + h rows of PF rounds) in flight, see the backward kernel; PF divides nr
-    f32x4 wS[PF][NS], sS[PF][NST];
+    f32x4 wS[PF][NS * NP], sS[PF][NST];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       loadA(sS[u], min(u, last));
@@ -483,32 +516,43 @@ __global__ __launch_bounds__(512, (KR <= 64 ? 4 : 2)) void lstm_step_fwd_v5(cons
     for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
   __syncthreads();
 
-  if (eok) {
-    const int row = tid >> 4, col = tid & 15;
-    float* g = G + (int64_t)en * 4 * H + ej;
-    const float gi = gate_sigmoid(sm[0][row][col] + sm[4][row][col] + pre[0]);
-    const float gf = gate_sigmoid(sm[1][row][col] + sm[5][row][col] + pre[1]);
-    const float gg = gate_tanh(sm[2][row][col] + sm[6][row][col] + pre[2]);
-    const float go = gate_sigmoid(sm[3][row][col] + sm[7][row][col] + pre[3]);
-    const float c = gf * cp + gi * gg;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    if (!eok[e]) continue;
+    const int idx = tid + 512 * e;
+    const int row = idx >> 4, col = idx & 15;
+    float* g = G + (int64_t)en[e] * 4 * H + ej[e];
+    const float gi = gate_sigmoid(sm[0][row][col] + sm[4][row][col] + pre[e][0]);
+    const float gf = gate_sigmoid(sm[1][row][col] + sm[5][row][col] + pre[e][1]);
+    const float gg = gate_tanh(sm[2][row][col] + sm[6][row][col] + pre[e][2]);
+    const float go = gate_sigmoid(sm[3][row][col] + sm[7][row][col] + pre[e][3]);
+    const float c = gf * cp[e] + gi * gg;
     ST_S(&g[0], gi);
     ST_S(&g[H], gf);
     ST_S(&g[2 * H], gg);
     ST_S(&g[3 * H], go);
-    ST_S(&d.c_all[((int64_t)t * N + en) * H + ej], c);
-    d.h_out[((int64_t)t * N + en) * a.ldh + ej] = go * gate_tanh(c);
+    ST_S(&d.c_all[((int64_t)t * N + en[e]) * H + ej[e]], c);
+    d.h_out[((int64_t)t * N + en[e]) * a.ldh + ej[e]] = go * gate_tanh(c);
   }
 }
 
 // (An "all loads of the frame in flight up front" variant -- 217 VGPRs, no spills -- measured 17.1 us/frame against
 // 15.9 us for the just-in-time prefetch above: flooding the L2 queues delays the first tile of every workgroup.)
 
-template <int MT, int KR, bool BF = false>
+// PM as in the forward kernel.  KR = k depth of a round (64; 32 in fp32x3 mode, where the wave-private staging holds three
+// planes per buffer: 8 waves x 2 buffers x 3 planes x 32 rows x 40 bf16 = 123 KB).
+template <int MT, int KR, int PM = 0>
 __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
   constexpr int NW = 8;
-  constexpr int KC = BF ? 32 : 16;
-  constexpr int NS = KR / KC, LDA = KR + (BF ? 8 : 4);
-  using lds_t = typename std::conditional<BF, __bf16, float>::type;
+  constexpr bool B16 = (PM != 0);
+  constexpr int NP = (PM == 2) ? 3 : 1;
+  constexpr int KC = B16 ? 32 : 16;
+  constexpr int NS = KR / KC, LDA = KR + (B16 ? 8 : 4);
+  constexpr int PL = 16 * MT * LDA;                       // elements of one plane of one buffer
+  constexpr int KRW = KR >= 64 ? 64 : KR;                 // floats of a row one load instruction covers
+  constexpr int LPR = KRW / 4, RPI = 64 / LPR;            // lanes per row, rows per instruction
+  constexpr int NRI = 16 * MT / RPI, NQ = KR / KRW;       // row groups, instructions per row
+  using lds_t = typename std::conditional<B16, __bf16, float>::type;
   const StepDir& d = a.d[blockIdx.z];
   const int step = gstep - d.shift;
   if (step < 0 || step >= a.T) return;
@@ -524,7 +568,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
   const int quarter = wave >> 1, part = wave & 1;      // k range: [quarter*H + part*H/2, +H/2)
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) lds_t Ast[NW][2 * 16 * MT * LDA];   // per wave, two buffers
+  __shared__ __attribute__((aligned(16))) lds_t Ast[NW][2 * NP * PL];   // per wave, two buffers of NP planes
   __shared__ float sm[NW][MT * 16][17];
 
   const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
@@ -545,53 +589,64 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
   if (step > 0) {
     const int H4 = 4 * H;
     const int koff = quarter * H + part * (H / 2);
-    // packed W^T: [(jb*4 + quarter)][k-chunk of 16 inside the quarter][lane][4]
-    const float* __restrict__ bpk = d.wp + (((int64_t)jb * 4 + quarter) * (H / KC) + (int64_t)part * (H / KC / 2)) * 256 + lane * 4;
+    // packed W^T: [(jb*4 + quarter)][k-chunk inside the quarter][plane][lane][4 dwords]
+    const float* __restrict__ bpk = d.wp + (((int64_t)jb * 4 + quarter) * (H / KC) + (int64_t)part * (H / KC / 2)) * (256 * NP) + lane * 4;
     lds_t* __restrict__ stg = &Ast[wave][0];
-    const int lrow = lane >> 4, lc4 = lane & 15;
-    const float* arow[4 * MT];
+    const int lrow = lane / LPR, lc4 = lane % LPR;
+    const float* arow[NRI];
 #pragma unroll
-    for (int i = 0; i < 4 * MT; ++i) {
-      const int n = min(m0 + lrow + 4 * i, N - 1);
+    for (int i = 0; i < NRI; ++i) {
+      const int n = min(m0 + lrow + RPI * i, N - 1);
       arow[i] = d.dgates + ((int64_t)tn * N + n) * H4 + koff + 4 * lc4;
     }
     const int nr = H / 2 / KR, last = nr - 1;
-    const int rot = DVAE_LSTM_ROT ? (jb & (nr - 1)) : 0;     // see the forward kernel: dG[t+1] rows are shared by all j-blocks
-    auto loadA = [&](f32x4 (&st)[4 * MT][KR / 64], int rd_) {
-      const int rd = (rd_ + rot) & (nr - 1);
+    auto loadA = [&](f32x4 (&st)[NRI][NQ], int rd) {
 #pragma unroll
-      for (int i = 0; i < 4 * MT; ++i)
+      for (int i = 0; i < NRI; ++i)
 #pragma unroll
-        for (int q = 0; q < KR / 64; ++q) st[i][q] = *reinterpret_cast<const f32x4*>(arow[i] + rd * KR + 64 * q);
+        for (int q = 0; q < NQ; ++q) st[i][q] = *reinterpret_cast<const f32x4*>(arow[i] + rd * KR + KRW * q);
     };
-    auto storeA = [&](int buf, f32x4 (&st)[4 * MT][KR / 64]) {
+    auto storeA = [&](int buf, f32x4 (&st)[NRI][NQ]) {
 #pragma unroll
-      for (int i = 0; i < 4 * MT; ++i)
+      for (int i = 0; i < NRI; ++i)
 #pragma unroll
-        for (int q = 0; q < KR / 64; ++q) {
-          if constexpr (BF)
-            *reinterpret_cast<bf16x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) =
-                __builtin_convertvector(st[i][q], bf16x4);
-          else
-            *reinterpret_cast<f32x4*>(stg + buf * (16 * MT * LDA) + (lrow + 4 * i) * LDA + 64 * q + 4 * lc4) = st[i][q];
+        for (int q = 0; q < NQ; ++q) {
+          lds_t* dst = stg + buf * (NP * PL) + (lrow + RPI * i) * LDA + KRW * q + 4 * lc4;
+          if constexpr (PM == 2) {
+            bf16x4 pl[3];
+            split3_bf16(st[i][q], pl);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(dst + p * PL) = pl[p];
+          } else if constexpr (PM == 1) {
+            *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(st[i][q], bf16x4);
+          } else {
+            *reinterpret_cast<f32x4*>(dst) = st[i][q];
+          }
         }
     };
-    auto loadB = [&](f32x4 (&b)[NS], int rd_) {
-      const int rd = (rd_ + rot) & (nr - 1);
+    auto loadB = [&](f32x4 (&b)[NS * NP], int rd) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS + s) * 256);
+      for (int s = 0; s < NS * NP; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS * NP + s) * 256);
     };
-    auto compute = [&](int buf, f32x4 (&b)[NS]) {
-      if constexpr (BF) {
-        const lds_t* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 8 * kq;
+    auto compute = [&](int buf, f32x4 (&b)[NS * NP]) {
+      if constexpr (B16) {
+        const lds_t* __restrict__ al = stg + buf * (NP * PL) + r * LDA + 8 * kq;
+        constexpr int NT6 = (PM == 2) ? 6 : 1;
+        constexpr int ia[6] = {0, 0, 1, 1, 0, 2}, ib[6] = {0, 1, 0, 1, 2, 0};
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                *reinterpret_cast<const bf16x8*>(al + mt * 16 * LDA + 32 * s), __builtin_bit_cast(bf16x8, b[s]), acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 av[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[p] = *reinterpret_cast<const bf16x8*>(al + p * PL + mt * 16 * LDA + 32 * s);
+#pragma unroll
+            for (int term = 0; term < NT6; ++term)
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], __builtin_bit_cast(bf16x8, b[s * NP + ib[term]]),
+                                                                acc[mt], 0, 0, 0);
+          }
       } else {
-      const lds_t* __restrict__ al = stg + buf * (16 * MT * LDA) + r * LDA + 4 * kq;
+      const lds_t* __restrict__ al = stg + buf * (NP * PL) + r * LDA + 4 * kq;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         f32x4 av[MT];
@@ -605,11 +660,11 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
       }
       }
     };
-    // PF register sets (dG rows + W fragments of PF rounds) in flight: a 64-deep round is only 16*MT MFMAs per wave
-    // (~1-2 k cycles), shorter than the latency of a load that misses L2 while every CU streams; with PF = 2 (one round
-    // of cover) a round measured ~5 k cycles against 2 k of MFMA issue.  Loads are unconditional (round index clamped).
+    // PF register sets (dG rows + W fragments of PF rounds) in flight (ring; loads unconditional, round index clamped).
+    // Measured at H = 1024: PF = 4 is SLOWER than 2 (20.4 vs 18.0 us per frame: more loads in flight only deepen the
+    // queues), so the frame kernels are throughput-, not latency-bound; see DESIGN.md.
     constexpr int PF = DVAE_LSTM_PF;
-    f32x4 bS[PF][NS], sS[PF][4 * MT][KR / 64];
+    f32x4 bS[PF][NS * NP], sS[PF][NRI][NQ];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       loadA(sS[u], min(u, last));
@@ -883,10 +938,11 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
     if (s.step_shift < 0) return DVAE_EINVAL;
   }
   if (ndir == 1) a.d[1] = a.d[0];
-  a.bf16 = dirs[0].packed_bf16 ? 1 : 0;
+  a.pm = dirs[0].packed_mode;
+  if (a.pm != DVAE_MODE_F32 && a.pm != DVAE_MODE_BF16 && a.pm != DVAE_MODE_F32X3) return DVAE_EINVAL;
   for (int i = 0; i < ndir; ++i)
-    if ((dirs[i].packed_bf16 ? 1 : 0) != a.bf16 || (a.bf16 && !dirs[i].w_packed)) return DVAE_EINVAL;
-  if (a.bf16 && (H % 512)) return DVAE_EINVAL;        // bf16 frame kernels exist for H = 512, 1024, ...
+    if (dirs[i].packed_mode != a.pm || (a.pm && !dirs[i].w_packed)) return DVAE_EINVAL;
+  if (a.pm && (H % 512)) return DVAE_EINVAL;          // bf16 / fp32x3 frame kernels exist for H = 512, 1024, ...
   a.T = T; a.N = N; a.H = H; a.ldh = ldh;
   return DVAE_OK;
 }
@@ -938,17 +994,21 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
     // stacked entries (a shift): the 64-deep variant keeps TWO workgroups resident per CU, so the two layers' frames
     // really overlap (one's load latency under the other's MFMAs) instead of alternating
     for (int step = g0; step < g1; ++step) {
-      if (a.bf16) {
-        if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-        else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      } else if (p.mt5 == 2 && p.shifted) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 64, false, DVAE_LSTM_PFF>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      else if (p.mt5 == 2 && H % 1024 == 0) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, false, DVAE_LSTM_PFF>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      else if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 64, false, DVAE_LSTM_PFF>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+#define FWD5(MT_, KR_, PM_) hipLaunchKernelGGL((lstm_step_fwd_v5<MT_, KR_, PM_, 2>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5)
+      if (a.pm == DVAE_MODE_BF16) {
+        if (p.mt5 == 2) FWD5(2, 128, 1); else FWD5(1, 128, 1);
+      } else if (a.pm == DVAE_MODE_F32X3) {
+        // (64-row tiles, which read W_hh twice per frame instead of 4x, measured SLOWER: 15.3 vs 12.5 us per layer-frame
+        // for the two stacked H = 1024 layers — one workgroup per CU hides less latency than the bytes it saves)
+        if (p.mt5 == 2) FWD5(2, 64, 2); else FWD5(1, 64, 2);
+      } else if (p.mt5 == 2 && p.shifted) FWD5(2, 64, 0);
+      else if (p.mt5 == 2) FWD5(2, 128, 0);
+      else FWD5(1, 64, 0);
+#undef FWD5
     }
     return dvae_check_launch();
   }
-  if (!p.whole || a.bf16) return DVAE_EINVAL;   // step ranges / stacked entries / bf16 exist for the eight-wave kernels only
+  if (!p.whole || a.pm) return DVAE_EINVAL;   // step ranges / stacked entries / bf16 / fp32x3 exist for the eight-wave kernels only
   const int n_m = (N + 15) / 16;
   for (int step = 0; step < T; ++step)
     hipLaunchKernelGGL((lstm_step_fwd_kernel<1>), dim3(p.n_j * n_m, 1, ndir), dim3(256), 0, s, a, step, p.n_j, n_m);
@@ -983,15 +1043,18 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
     if (!a.d[0].wp || !a.d[ndir - 1].wp) return DVAE_EINVAL;
     dim3 grid5(p.n_j * p.n_m5, 1, ndir), block5(512);
     for (int step = g0; step < g1; ++step) {
-      if (a.bf16) {
-        if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-        else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      } else if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
-      else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+#define BWD5(MT_, KR_, PM_) hipLaunchKernelGGL((lstm_step_bwd_v5<MT_, KR_, PM_>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5)
+      if (a.pm == DVAE_MODE_BF16) {
+        if (p.mt5 == 2) BWD5(2, 64, 1); else BWD5(1, 64, 1);
+      } else if (a.pm == DVAE_MODE_F32X3) {
+        if (p.mt5 == 2) BWD5(2, 32, 2); else BWD5(1, 64, 2);
+      } else if (p.mt5 == 2) BWD5(2, 64, 0);
+      else BWD5(1, 64, 0);
+#undef BWD5
     }
     return dvae_check_launch();
   }
-  if (!p.whole || a.bf16) return DVAE_EINVAL;
+  if (!p.whole || a.pm) return DVAE_EINVAL;
   const int n_m = (N + 15) / 16;
   for (int step = 0; step < T; ++step)
     hipLaunchKernelGGL((lstm_step_bwd_kernel<1>), dim3(p.n_j * n_m, 1, ndir), dim3(256), 0, s, a, step, p.n_j, n_m);

@@ -6,8 +6,8 @@
 // small launch per use (round 1: 42 pack / transpose launches + 19 ATen bias adds per step):
 //   CONV_T     Wp[5][Cout][Cin] (the layout conv weights live in, see model/disentangled_vae.py) -> Wpt[5][Cin][Cout]
 //              for the data gradient;
-//   LSTM_PACK  W_hh[4H][H] -> forward / backward fragment packs (fp32 for v_mfma_f32_16x16x4_f32, or bf16 for
-//              v_mfma_f32_16x16x32_bf16 when the table says so);
+//   LSTM_PACK  W_hh[4H][H] -> forward / backward fragment packs (fp32 for v_mfma_f32_16x16x4_f32, bf16 or three bf16
+//              planes for v_mfma_f32_16x16x32_bf16, per pack as the descriptor says);
 //   TRANSPOSE  W[R][C] -> W^T[C][R]   (W_ih^T for the input-projection data gradients, W_hh^T for the H = 64 and
 //              generic backward recurrences);
 //   ADD2       b_ih + b_hh (nn.LSTM keeps two bias vectors; the kernels add one).
@@ -26,7 +26,7 @@ struct Desc {
   float* dst2;
 };
 struct Table {
-  int n, lstm_bf16;
+  int n, pad_;
   int blk_begin[MAX_DESC + 1];
   Desc d[MAX_DESC];
 };
@@ -108,6 +108,56 @@ __device__ __forceinline__ void lstm_pack_bf16(const float* __restrict__ W, __bf
   }
 }
 
+// fp32x3 fragment packing: as the bf16 packing with THREE planes per (chunk, lane): w = p0 + p1 + p2 exactly (two
+// round-to-nearest splits, the last residual is exact in bf16).  [..][kc][plane][lane][8]
+__device__ __forceinline__ void split3_scalar(float x, __bf16& a, __bf16& b, __bf16& c) {
+  a = (__bf16)x;
+  const float r1 = x - (float)a;
+  b = (__bf16)r1;
+  c = (__bf16)(r1 - (float)b);
+}
+__device__ __forceinline__ void lstm_pack_x3(const float* __restrict__ W, __bf16* __restrict__ pf,
+                                             __bf16* __restrict__ pb, int H, int64_t first, int64_t stride) {
+  const int n_j = H / 16, nkc = H / 32;
+  const int64_t total = (int64_t)4 * n_j * nkc * 64;
+  for (int64_t i = first; i < total; i += stride) {
+    const int lane = (int)(i & 63);
+    const int64_t c = i >> 6;                       // (group, chunk)
+    const int kc = (int)(c % nkc);
+    const int64_t gj = c / nkc;
+    const int r = lane & 15, q = lane >> 4;
+    if (pf) {
+      const int g = (int)(gj / n_j), jb = (int)(gj % n_j);
+      const float* src = W + ((int64_t)g * H + jb * 16 + r) * H + kc * 32 + 8 * q;
+      bf16x8 v[3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 p0, p1, p2;
+        split3_scalar(src[e], p0, p1, p2);
+        v[0][e] = p0; v[1][e] = p1; v[2][e] = p2;
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) reinterpret_cast<bf16x8*>(pf)[(c * 3 + p) * 64 + lane] = v[p];
+    }
+    if (pb) {
+      const int jb = (int)(gj / 4), w = (int)(gj % 4);
+      bf16x8 v[3];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        __bf16 p0, p1, p2;
+        split3_scalar(W[((int64_t)w * H + kc * 32 + 8 * q + e) * H + jb * 16 + r], p0, p1, p2);
+        v[0][e] = p0; v[1][e] = p1; v[2][e] = p2;
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) reinterpret_cast<bf16x8*>(pb)[(c * 3 + p) * 64 + lane] = v[p];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lstm_pack_w_x3_kernel(const float* __restrict__ W, __bf16* __restrict__ pf,
+                                                             __bf16* __restrict__ pb, int H) {
+  lstm_pack_x3(W, pf, pb, H, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
+}
 __global__ __launch_bounds__(256) void lstm_pack_w_kernel(const float* __restrict__ W, float* __restrict__ pf,
                                                           float* __restrict__ pb, int H) {
   lstm_pack_f32(W, pf, pb, H, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
@@ -129,12 +179,20 @@ __global__ __launch_bounds__(256) void repack_all_kernel(const Table t) {
       for (int tap = 0; tap < 5; ++tap) transpose_tiles(d.src + tap * cc, d.dst + tap * cc, d.d0, d.d1, lb, nb, tile);
       break;
     }
-    case DVAE_REPACK_LSTM_PACK:   // d0 = H
-      if (t.lstm_bf16 && (d.d0 % 512) == 0)
-        lstm_pack_bf16(d.src, (__bf16*)d.dst, (__bf16*)d.dst2, d.d0, (int64_t)lb * 256 + threadIdx.x, (int64_t)nb * 256);
-      else
-        lstm_pack_f32(d.src, d.dst, d.dst2, d.d0, (int64_t)lb * 256 + threadIdx.x, (int64_t)nb * 256);
+    case DVAE_REPACK_LSTM_PACK: {   // d0 = H, d1 / d2 = DVAE_MODE_* of the forward / backward pack
+      const int64_t first = (int64_t)lb * 256 + threadIdx.x, stride = (int64_t)nb * 256;
+      for (int which = 0; which < 2; ++which) {
+        float* dst = which ? d.dst2 : d.dst;
+        const int m = which ? d.d2 : d.d1;
+        if (!dst) continue;
+        float* pf = which ? nullptr : dst;
+        float* pb = which ? dst : nullptr;
+        if (m == DVAE_MODE_BF16) lstm_pack_bf16(d.src, (__bf16*)pf, (__bf16*)pb, d.d0, first, stride);
+        else if (m == DVAE_MODE_F32X3) lstm_pack_x3(d.src, (__bf16*)pf, (__bf16*)pb, d.d0, first, stride);
+        else lstm_pack_f32(d.src, pf, pb, d.d0, first, stride);
+      }
       break;
+    }
     case DVAE_REPACK_TRANSPOSE:   // d0 = R, d1 = C
       transpose_tiles(d.src, d.dst, d.d0, d.d1, lb, nb, tile);
       break;
@@ -167,11 +225,20 @@ DVAE_API int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* pa
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_repack_all(const dvae_repack_desc_t* descs, int n, int lstm_bf16, void* stream) {
+DVAE_API int dvae_lstm_pack_w_x3(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream) {
+  if (!w_hh || (!packed_fwd && !packed_bwd) || H < 512 || (H % 512)) return DVAE_EINVAL;
+  const int64_t total = (int64_t)4 * (H / 16) * (H / 32) * 64;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(lstm_pack_w_x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_hh,
+                     (__bf16*)packed_fwd, (__bf16*)packed_bwd, H);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream) {
   if (!descs || n < 1 || n > MAX_DESC) return DVAE_EINVAL;
   Table t{};
   t.n = n;
-  t.lstm_bf16 = lstm_bf16 ? 1 : 0;
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
     const dvae_repack_desc_t& s = descs[i];
@@ -183,6 +250,9 @@ DVAE_API int dvae_repack_all(const dvae_repack_desc_t* descs, int n, int lstm_bf
         break;
       case DVAE_REPACK_LSTM_PACK:
         if (!s.src || (!s.dst && !s.dst2) || s.d0 < 64 || (s.d0 & 63)) return DVAE_EINVAL;
+        for (int m : {s.d1, s.d2})
+          if ((m != DVAE_MODE_F32 && m != DVAE_MODE_BF16 && m != DVAE_MODE_F32X3) || (m != DVAE_MODE_F32 && (s.d0 % 512)))
+            return DVAE_EINVAL;
         elems = (int64_t)4 * s.d0 * s.d0;
         break;
       case DVAE_REPACK_TRANSPOSE:

@@ -5,8 +5,8 @@
     in the packed layout Wp[5][Cout][Cin], see model/disentangled_vae._Conv1dParams: no forward pack, and the weight
     gradient accumulates straight into the flat gradient buffer);
   * nn.LSTM: b_ih + b_hh, W_ih^T (input-projection data gradient), W_hh^T (backward recurrence at H = 64 / generic H)
-    and, for H a multiple of 512, W_hh in MFMA fragment order for the forward and backward frame kernels (bf16 fragments
-    in the bf16 compute mode).
+    and, for H a multiple of 512, W_hh in MFMA fragment order for the forward and backward frame kernels (fp32, bf16 or
+    three-plane bf16 fragments, as the compute mode in force says).
 
 Round 1 produced these with one small launch per use (42 pack / transpose launches and 19 ATen bias adds per step,
 each into a fresh torch.empty).  The buffers are persistent; the descriptor table is rebuilt only when a source
@@ -25,17 +25,31 @@ from ._lib import check, lib, stream
 LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b")
 
 
-def _desc(kind, src, dst, d0, d1=0, src2=None, dst2=None):
+def lstm_pack_modes(mode: int, H: int):
+    """(forward pack mode, backward pack mode) of an LSTM layer under compute mode `mode`: bf16 mode runs both
+    recurrences on bf16 fragments; fp32x3 runs the FORWARD recurrence on three-plane fragments (measured 12.5 vs 14.6 us
+    per H = 1024 layer-frame) and keeps the backward one on the fp32 MFMA (17.6 vs 18.1 at H = 1024, slower at H = 512:
+    it is bound by the dG[t+1] rows it streams, which the split does not shrink).  H not a multiple of 512: fp32."""
+    if H % 512:
+        return _lib.MODE_F32, _lib.MODE_F32
+    if mode == _lib.MODE_BF16:
+        return _lib.MODE_BF16, _lib.MODE_BF16
+    if mode == _lib.MODE_F32X3:
+        return _lib.MODE_F32X3, _lib.MODE_F32
+    return _lib.MODE_F32, _lib.MODE_F32
+
+
+def _desc(kind, src, dst, d0, d1=0, src2=None, dst2=None, d2=0):
     d = _lib.RepackDesc()
-    d.kind, d.d0, d.d1, d.d2 = kind, d0, d1, 0
+    d.kind, d.d0, d.d1, d.d2 = kind, d0, d1, d2
     d.src, d.src2 = src.data_ptr(), (src2.data_ptr() if src2 is not None else None)
     d.dst, d.dst2 = dst.data_ptr(), (dst2.data_ptr() if dst2 is not None else None)
     return d
 
 
-def run_descs(descs: List, lstm_bf16: bool = False):
+def run_descs(descs: List):
     arr = (_lib.RepackDesc * len(descs))(*descs)
-    check(lib().dvae_repack_all(arr, len(descs), int(lstm_bf16), stream()), "dvae_repack_all")
+    check(lib().dvae_repack_all(arr, len(descs), stream()), "dvae_repack_all")
 
 
 def conv_wpt_local(conv_wp: torch.Tensor) -> torch.Tensor:
@@ -46,7 +60,7 @@ def conv_wpt_local(conv_wp: torch.Tensor) -> torch.Tensor:
     return wpt
 
 
-def lstm_local(w_ih, w_hh, b_ih, b_hh, bf16: bool) -> LstmDerived:
+def lstm_local(w_ih, w_hh, b_ih, b_hh, mode: int) -> LstmDerived:
     """The derived operands of one (layer, direction), computed on the spot (stand-alone use of LstmLayerFn)."""
     H, In = w_hh.shape[1], w_ih.shape[1]
     f = dict(device=w_hh.device, dtype=torch.float32)
@@ -56,9 +70,10 @@ def lstm_local(w_ih, w_hh, b_ih, b_hh, bf16: bool) -> LstmDerived:
              _desc(_lib.REPACK_TRANSPOSE, w_hh, wht, 4 * H, H)]
     pf = pb = None
     if H % 512 == 0:
-        pf, pb = torch.empty(4 * H * H, **f), torch.empty(4 * H * H, **f)
-        descs.append(_desc(_lib.REPACK_LSTM_PACK, w_hh, pf, H, dst2=pb))
-    run_descs(descs, bf16)
+        pf, pb = torch.empty(6 * H * H, **f), torch.empty(6 * H * H, **f)      # 6 bytes per element (three bf16 planes)
+        mf, mb = lstm_pack_modes(mode, H)
+        descs.append(_desc(_lib.REPACK_LSTM_PACK, w_hh, pf, H, d1=mf, dst2=pb, d2=mb))
+    run_descs(descs)
     return LstmDerived(bias, wit, wht, pf, pb)
 
 
@@ -77,7 +92,7 @@ class DerivedWeights:
         return tuple(p.data_ptr() for p in self._convs.values()) + \
             tuple(p.data_ptr() for ps in self._lstms.values() for p in ps)
 
-    def _build(self):
+    def _build(self, mode):
         descs = []
         for name, wp in self._convs.items():
             _, cout, cin = wp.shape
@@ -91,22 +106,22 @@ class DerivedWeights:
                 big = H % 512 == 0
                 self.lstm[name] = LstmDerived(torch.empty(4 * H, **f), torch.empty((In, 4 * H), **f),
                                               torch.empty((H, 4 * H), **f),
-                                              torch.empty(4 * H * H, **f) if big else None,
-                                              torch.empty(4 * H * H, **f) if big else None)
+                                              torch.empty(6 * H * H, **f) if big else None,     # up to 3 bf16 planes
+                                              torch.empty(6 * H * H, **f) if big else None)
             d = self.lstm[name]
             descs.append(_desc(_lib.REPACK_ADD2, b_ih, d.bias, 4 * H, src2=b_hh))
             descs.append(_desc(_lib.REPACK_TRANSPOSE, w_ih, d.w_ih_t, 4 * H, In))
             descs.append(_desc(_lib.REPACK_TRANSPOSE, w_hh, d.w_hh_t, 4 * H, H))
             if d.pack_f is not None:
-                descs.append(_desc(_lib.REPACK_LSTM_PACK, w_hh, d.pack_f, H, dst2=d.pack_b))
+                mf, mb = lstm_pack_modes(mode, H)
+                descs.append(_desc(_lib.REPACK_LSTM_PACK, w_hh, d.pack_f, H, d1=mf, dst2=d.pack_b, d2=mb))
         self._descs = (_lib.RepackDesc * len(descs))(*descs)
 
     def refresh(self, mode: int):
         """One launch: every derived buffer from the current weights (asynchronous on the current stream)."""
-        sig = self._signature()
+        sig = self._signature() + (int(mode),)
         if sig != self._sig:
-            self._build()
+            self._build(int(mode))
             self._sig = sig
-        check(lib().dvae_repack_all(self._descs, len(self._descs), int(mode == _lib.MODE_BF16), stream()),
-              "dvae_repack_all")
+        check(lib().dvae_repack_all(self._descs, len(self._descs), stream()), "dvae_repack_all")
         self.refreshes += 1

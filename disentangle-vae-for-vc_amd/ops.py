@@ -366,13 +366,13 @@ class ConvBnActFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- LSTM layer
-def _lstm_derived(derived, params, bf):
+def _lstm_derived(derived, params, mode):
     """Per direction: (bias sum, W_ih^T, W_hh^T, fragment packs) — from the model's DerivedWeights when given, else
     computed on the spot (stand-alone use)."""
     if derived is not None:
         return list(derived)
     from .derived import lstm_local
-    return [lstm_local(wi, wh, bi, bh, bool(bf)) for (wi, wh, bi, bh) in params]
+    return [lstm_local(wi, wh, bi, bh, int(mode)) for (wi, wh, bi, bh) in params]
 
 
 class LstmLayerFn(torch.autograd.Function):
@@ -393,12 +393,13 @@ class LstmLayerFn(torch.autograd.Function):
         h_out = torch.empty((R, ldh), device=dev, dtype=torch.float32)
         params = [(w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r)][:ndir]
         dirs = (_lib.LstmDir * ndir)()
-        # bf16 compute mode: the recurrence runs on bf16 fragments where bf16 frame kernels exist (H = 512, 1024);
-        # the H = 64 encoder recurrence (3 % of the FLOPs, weights resident in registers) stays fp32.
-        # fp32x3 mode: the recurrence runs on the fp32 MFMA — it is bound by W_hh traffic, not by the matrix pipe.
+        # bf16 / fp32x3 compute modes: the recurrence runs on bf16 fragments (one plane / three planes) where such frame
+        # kernels exist (H = 512, 1024); the H = 64 encoder recurrence (3 % of the FLOPs, weights resident in registers)
+        # stays on the fp32 MFMA
         mode = current_mode()
-        bf = 1 if (mode == MODE_BF16 and H % 512 == 0) else 0
-        der = _lstm_derived(derived, params, bf)
+        from .derived import lstm_pack_modes
+        bf, bfb = lstm_pack_modes(mode, H)      # (forward, backward) precision of the recurrent product
+        der = _lstm_derived(derived, params, mode)
         gates, cells = [], []
         for d, (wi, wh, bi, bh) in enumerate(params):
             g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
@@ -409,14 +410,14 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].gates = ptr(g)
             dirs[d].w_hh = ptr(wh)
             dirs[d].w_packed = ptr(der[d].pack_f)
-            dirs[d].packed_bf16 = bf
+            dirs[d].packed_mode = bf
             dirs[d].h_out = h_out.data_ptr() + 4 * d * H
             dirs[d].c_all = ptr(c)
             dirs[d].reverse = d
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
         ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
         ctx.der = der
-        ctx.cfg = (T, N, H, ndir, bf, mode)
+        ctx.cfg = (T, N, H, ndir, bfb, mode)
         return h_out
 
     @staticmethod
@@ -446,7 +447,7 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].gates = ptr(gates[d])
             dirs[d].w_hh = ptr(der[d].w_hh_t)       # [H, 4H]
             dirs[d].w_packed = ptr(der[d].pack_b)
-            dirs[d].packed_bf16 = bf
+            dirs[d].packed_mode = bf
             dirs[d].c_all = ptr(cells[d])
             dirs[d].dh_out = dh.data_ptr() + 4 * d * H
             dirs[d].dgates = ptr(dg)
@@ -512,8 +513,9 @@ class LstmStack2Fn(torch.autograd.Function):
         H = w_hh1.shape[1]
         Tc = LstmStack2Fn.chunk(T)
         mode = current_mode()
-        bf = 1 if mode == MODE_BF16 else 0
-        der = _lstm_derived(derived, [(w_ih1, w_hh1, b_ih1, b_hh1), (w_ih2, w_hh2, b_ih2, b_hh2)], bf)
+        from .derived import lstm_pack_modes
+        bf, bfb = lstm_pack_modes(mode, H)
+        der = _lstm_derived(derived, [(w_ih1, w_hh1, b_ih1, b_hh1), (w_ih2, w_hh2, b_ih2, b_hh2)], mode)
         f32 = dict(device=dev, dtype=torch.float32)
         g1, g2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
         c1, c2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
@@ -523,7 +525,7 @@ class LstmStack2Fn(torch.autograd.Function):
         for d, (g, wh, h, c) in enumerate(((g1, w_hh1, h1, c1), (g2, w_hh2, h2, c2))):
             dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed = ptr(g), ptr(wh), ptr(der[d].pack_f)
             dirs[d].h_out, dirs[d].c_all = ptr(h), ptr(c)
-            dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
+            dirs[d].reverse, dirs[d].packed_mode, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
         rows = Tc * N
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
@@ -533,7 +535,7 @@ class LstmStack2Fn(torch.autograd.Function):
             check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
         ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
         ctx.der = der
-        ctx.cfg = (T, N, H, bf, mode)
+        ctx.cfg = (T, N, H, bfb, mode)
         return h2
 
     @staticmethod
@@ -554,7 +556,7 @@ class LstmStack2Fn(torch.autograd.Function):
         for d, (g, dd, c, dho, dg) in enumerate(((g2, der[1], c2, dh2, dg2), (g1, der[0], c1, dh1, dg1))):
             dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed, dirs[d].c_all = ptr(g), ptr(dd.w_hh_t), ptr(dd.pack_b), ptr(c)
             dirs[d].dh_out, dirs[d].dgates, dirs[d].dc_ws = ptr(dho), ptr(dg), ptr(dcs[d])
-            dirs[d].reverse, dirs[d].packed_bf16, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
+            dirs[d].reverse, dirs[d].packed_mode, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
         rows = Tc * N
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 2 finished backward steps [c0-Tc, c0) = frames [T-c0, T-c0+Tc): dgrad into dh1

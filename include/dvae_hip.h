@@ -137,8 +137,10 @@ typedef struct {
   const float* w_packed; /* optional: weights re-packed in MFMA fragment order by dvae_lstm_pack_w (fwd: packed_fwd,
                             bwd: packed_bwd); when given, the faster 1-KiB-burst frame kernels are used */
   int reverse;        /* 0: t = 0..T-1, 1: t = T-1..0 */
-  int packed_bf16;    /* 0: w_packed from dvae_lstm_pack_w (fp32 recurrence); 1: from dvae_lstm_pack_w_bf16 (bf16
-                         operands / fp32 accumulation on v_mfma_f32_16x16x32_bf16; H must be a multiple of 512) */
+  int packed_mode;    /* DVAE_MODE_F32: w_packed from dvae_lstm_pack_w (fp32 MFMA recurrence); DVAE_MODE_BF16: from
+                         dvae_lstm_pack_w_bf16 (bf16 operands / fp32 accumulation on v_mfma_f32_16x16x32_bf16);
+                         DVAE_MODE_F32X3: from dvae_lstm_pack_w_x3 (fp32 results: three bf16 planes of W_hh, h split the
+                         same way, six exact partial products).  The last two need H % 512 == 0 */
   int step_shift;     /* *_range calls: this entry runs its step s in the launch of global step s + step_shift (0 for
                          the plain calls).  Lets two STACKED layers share launches, the upper one a chunk of frames
                          behind the lower one (whose chunk of outputs has meanwhile gone through the upper layer's input
@@ -149,11 +151,14 @@ typedef struct {
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
 /* bf16 compute mode: the same copies rounded to bf16 (each 4H*H bf16 values = 2*4H*H bytes) */
 int dvae_lstm_pack_w_bf16(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream);
+/* fp32x3 mode: three bf16 planes per fragment, w == w1 + w2 + w3 exactly (each copy 3 * 4H*H bf16 values = 6*4H*H bytes) */
+int dvae_lstm_pack_w_x3(const float* w_hh, void* packed_fwd, void* packed_bwd, int H, void* stream);
 /* ---- all weight-derived operand layouts of a model in ONE launch (once per training step, after Adam) ----
  * kind CONV_T    src Wp[5][d0=Cout][d1=Cin]                 -> dst Wpt[5][Cin][Cout]  (operand of dvae_conv5_dgrad_t)
- *      LSTM_PACK src W_hh[4*d0][d0], d0 = H                 -> dst packed_fwd, dst2 packed_bwd (either may be null);
- *                                                              bf16 fragments instead of fp32 ones when lstm_bf16 != 0
- *                                                              and H % 512 == 0 (see dvae_lstm_pack_w[_bf16])
+ *      LSTM_PACK src W_hh[4*d0][d0], d0 = H                 -> dst packed_fwd in mode d1, dst2 packed_bwd in mode d2
+ *                                                              (either pointer may be null; DVAE_MODE_F32 / _BF16 /
+ *                                                              _F32X3, the last two only where H % 512 == 0): see
+ *                                                              dvae_lstm_pack_w / _bf16 / _x3
  *      TRANSPOSE src W[d0][d1]                              -> dst W^T[d1][d0]
  *      ADD2      src, src2 [d0]                             -> dst = src + src2        (b_ih + b_hh)
  * `descs` is a HOST array of n <= 56 entries (copied into the launch); the device buffers are the caller's. */
@@ -168,7 +173,7 @@ typedef struct {
   void* dst;
   void* dst2;
 } dvae_repack_desc_t;
-int dvae_repack_all(const dvae_repack_desc_t* descs, int n, int lstm_bf16, void* stream);
+int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
 
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
