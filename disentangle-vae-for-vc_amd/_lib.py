@@ -31,6 +31,14 @@ class RepackDesc(C.Structure):
                 ("dst2", vp)]
 
 
+class LossDesc(C.Structure):
+    """dvae_loss_desc_t"""
+    _fields_ = [(k, vp) for k in ("x1", "x2", "recon1", "recon2", "recon1_hat", "recon2_hat", "q1_mu", "q1_lv", "q2_mu",
+                                  "q2_lv", "s_mu", "s_lv")] + \
+               [("n", i64), ("nq", i32), ("ns", i32), ("l1_scale", f32), ("kl_scale", f32), ("style_scale", f32),
+                ("mse_cof", f32), ("kl_cof", f32)]
+
+
 REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2 = 0, 1, 2, 3
 
 # DVAE_MODE_* of include/dvae_hip.h
@@ -46,6 +54,8 @@ SIGNATURES = {
     "dvae_last_hip_error": (i32, []),
     "dvae_gemm_f32": (i32, [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_conv5_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv5_fwd_stats": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "dvae_bn_stats_finalize": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "dvae_conv5_wgrad": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_conv_pack_w": (i32, [vp, vp, i32, i32, vp]),
     "dvae_conv_pack_wt": (i32, [vp, vp, i32, i32, vp]),
@@ -70,6 +80,9 @@ SIGNATURES = {
     "dvae_l1_ws_bytes": (i64, [i64]),
     "dvae_l1_sum_fwd": (i32, [vp, vp, vp, vp, i64, f32, vp]),
     "dvae_l1_sum_bwd": (i32, [vp, vp, vp, vp, i64, f32, vp]),
+    "dvae_loss_ws_bytes": (i64, [i64]),
+    "dvae_loss_fwd": (i32, [C.POINTER(LossDesc), vp, vp, vp]),
+    "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
     "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, vp]),

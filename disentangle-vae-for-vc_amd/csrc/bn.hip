@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int ROWS_PER_CHUNK = 64;   // 512 workgroups at R = 16384, C = 512: two per CU (128 rows: one per CU at 2-3 TB/s; 32 rows: no faster, finalize slower)
+constexpr int ROWS_PER_CHUNK = DVAE_BN_ROWS_PER_CHUNK;   // 512 workgroups at R = 16384, C = 512: two per CU (128 rows: one per CU at 2-3 TB/s; 32 rows: no faster, finalize slower)
 
 __host__ __device__ inline int n_chunks(int R) { return (R + ROWS_PER_CHUNK - 1) / ROWS_PER_CHUNK; }
 
@@ -245,6 +245,16 @@ DVAE_API int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* 
                      C, G, 0);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, mean, rstd,
                      running_mean, running_var, num_batches_tracked, ch, R, N, C, G, eps, momentum);
+  return dvae_check_launch();
+}
+
+// the second half of dvae_bn_stats_fwd: the partial sums are already in `ws` (dvae_conv5_fwd_stats)
+DVAE_API int dvae_bn_stats_finalize(float* mean, float* rstd, float* running_mean, float* running_var,
+                                    int64_t* num_batches_tracked, const void* ws, int R, int N, int C, int G, float eps,
+                                    float momentum, void* stream) {
+  if (check(R, N, C, G) || !mean || !rstd || !ws) return DVAE_EINVAL;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double*)ws,
+                     mean, rstd, running_mean, running_var, num_batches_tracked, n_chunks(R), R, N, C, G, eps, momentum);
   return dvae_check_launch();
 }
 

@@ -16,6 +16,8 @@ extern int g_dvae_compute_mode;   // gemm.hip: process default of the contractio
 
 extern int g_dvae_last_hip_error;
 
+#define DVAE_BN_ROWS_PER_CHUNK 64   // rows per BatchNorm partial-sum chunk (bn.hip; the conv epilogue writes the same layout)
+
 static inline int dvae_check_launch() {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

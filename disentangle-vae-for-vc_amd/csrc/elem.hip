@@ -139,6 +139,134 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* __restrict__ x
   }
 }
 
+// ------------------------------------------------------------------ the whole loss_functionGVAE2 in two launches
+// (disentangled_vae.py:310-327): four L1 sums / batch_size, two KL terms, the report-only style KL and the weighted
+// total.  Round 1 spent 19 launches on it forward (4 x (partial + final), 3 KL, ~8 ATen scalar ops) and ~15 backward.
+struct LossArgs {
+  const float* x[2];        // x1, x2                      [n]
+  const float* r[4];        // recon1, recon2, recon1_hat, recon2_hat   [n]
+  const float* qmu[2];      // q_z1_mu, q_z2_mu            [nq]
+  const float* qlv[2];
+  const float* smu;         // z_style_mu, z_style_logvar  [ns]
+  const float* slv;
+  int64_t n;
+  int nq, ns;
+  float l1_scale, kl_scale, style_scale, mse_cof, kl_cof;
+};
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(const LossArgs a, double* __restrict__ part) {
+  const int64_t n4 = a.n >> 2;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x[0] + 4 * i), x2 = *reinterpret_cast<const f32x4*>(a.x[1] + 4 * i);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 r = *reinterpret_cast<const f32x4*>(a.r[k] + 4 * i);
+      const f32x4 x = (k & 1) ? x2 : x1;
+      acc[k] += fabsf(x[0] - r[0]) + fabsf(x[1] - r[1]) + fabsf(x[2] - r[2]) + fabsf(x[3] - r[3]);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < a.n; i += 256)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] += fabsf(a.x[k & 1][i] - a.r[k][i]);
+  __shared__ double red[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double d = wave_sum_d((double)acc[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    part[blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// out[8] = (LOSS, L1_x1, L1_x2, L1_x1hat, L1_x2hat, KL_z1, KL_z2, KL_style)
+__global__ __launch_bounds__(256) void loss_final_kernel(const LossArgs a, const double* __restrict__ part, int nparts,
+                                                         float* __restrict__ out) {
+  __shared__ double red[7][4];
+  double v[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nparts; i += 256)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += part[i * 4 + k];
+  auto kl = [](float m, float l) { return (double)(1.f + l - m * m - expf(l)); };
+  for (int i = threadIdx.x; i < a.nq; i += 256) {
+    v[4] += kl(a.qmu[0][i], a.qlv[0][i]);
+    v[5] += kl(a.qmu[1][i], a.qlv[1][i]);
+  }
+  for (int i = threadIdx.x; i < a.ns; i += 256) v[6] += kl(a.smu[i], a.slv[i]);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const double d = wave_sum_d(v[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = d;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const double tot = red[k][0] + red[k][1] + red[k][2] + red[k][3];
+      t[k] = (float)(tot * (double)(k < 4 ? a.l1_scale : (k < 6 ? a.kl_scale : a.style_scale)));
+      out[1 + k] = t[k];
+    }
+    // the reference's operation order: mse_cof * (((a + b) + c) + d) + kl_cof * (e + f), all in fp32
+    out[0] = a.mse_cof * (((t[0] + t[1]) + t[2]) + t[3]) + a.kl_cof * (t[4] + t[5]);
+  }
+}
+
+// gradients w.r.t. the four reconstructions and the six latent statistics, given g[8] = dL/d(out[8])
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const LossArgs a, const float* __restrict__ g, float* __restrict__ dr0,
+                                                       float* __restrict__ dr1, float* __restrict__ dr2,
+                                                       float* __restrict__ dr3, float* __restrict__ dqmu0,
+                                                       float* __restrict__ dqlv0, float* __restrict__ dqmu1,
+                                                       float* __restrict__ dqlv1, float* __restrict__ dsmu,
+                                                       float* __restrict__ dslv, int l1_blocks) {
+  const float g0 = g[0];
+  if ((int)blockIdx.x < l1_blocks) {
+    float* dr[4] = {dr0, dr1, dr2, dr3};
+    float w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (g0 * a.mse_cof + g[1 + k]) * a.l1_scale;
+    const int64_t n4 = a.n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)l1_blocks * 256) {
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(a.x[0] + 4 * i), x2 = *reinterpret_cast<const f32x4*>(a.x[1] + 4 * i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!dr[k]) continue;
+        const f32x4 r = *reinterpret_cast<const f32x4*>(a.r[k] + 4 * i);
+        const f32x4 x = (k & 1) ? x2 : x1;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = x[e] - r[e];
+          o[e] = d > 0.f ? -w[k] : (d < 0.f ? w[k] : 0.f);
+        }
+        *reinterpret_cast<f32x4*>(dr[k] + 4 * i) = o;
+      }
+    }
+    if (blockIdx.x == 0)
+      for (int64_t i = (n4 << 2) + threadIdx.x; i < a.n; i += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!dr[k]) continue;
+          const float d = a.x[k & 1][i] - a.r[k][i];
+          dr[k][i] = d > 0.f ? -w[k] : (d < 0.f ? w[k] : 0.f);
+        }
+    return;
+  }
+  // latent statistics: one extra workgroup
+  const float w1 = (g0 * a.kl_cof + g[5]) * a.kl_scale, w2 = (g0 * a.kl_cof + g[6]) * a.kl_scale, ws = g[7] * a.style_scale;
+  for (int i = threadIdx.x; i < a.nq; i += 256) {
+    if (dqmu0) { dqmu0[i] = w1 * (-2.f * a.qmu[0][i]); dqlv0[i] = w1 * (1.f - expf(a.qlv[0][i])); }
+    if (dqmu1) { dqmu1[i] = w2 * (-2.f * a.qmu[1][i]); dqlv1[i] = w2 * (1.f - expf(a.qlv[1][i])); }
+  }
+  if (dsmu)
+    for (int i = threadIdx.x; i < a.ns; i += 256) {
+      dsmu[i] = ws * (-2.f * a.smu[i]);
+      dslv[i] = ws * (1.f - expf(a.slv[i]));
+    }
+}
+
 // ------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
@@ -500,6 +628,60 @@ DVAE_API int dvae_l1_sum_bwd(const float* x, const float* y, const float* gout, 
                              void* stream) {
   if (!x || !y || !gout || !dy || n < 1) return DVAE_EINVAL;
   hipLaunchKernelGGL(l1_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, y, gout, dy, n, scale);
+  return dvae_check_launch();
+}
+
+
+namespace {
+int fill_loss_args(LossArgs& a, const dvae_loss_desc_t* d) {
+  if (!d || d->n < 1 || d->nq < 1 || d->ns < 1) return DVAE_EINVAL;
+  const void* ps[] = {d->x1, d->x2, d->recon1, d->recon2, d->recon1_hat, d->recon2_hat, d->q1_mu, d->q1_lv, d->q2_mu, d->q2_lv,
+                      d->s_mu, d->s_lv};
+  for (const void* p : ps)
+    if (!p) return DVAE_EINVAL;
+  for (int i = 0; i < 6; ++i)
+    if (((uintptr_t)ps[i]) & 15) return DVAE_EINVAL;
+  a.x[0] = d->x1; a.x[1] = d->x2;
+  a.r[0] = d->recon1; a.r[1] = d->recon2; a.r[2] = d->recon1_hat; a.r[3] = d->recon2_hat;
+  a.qmu[0] = d->q1_mu; a.qlv[0] = d->q1_lv; a.qmu[1] = d->q2_mu; a.qlv[1] = d->q2_lv;
+  a.smu = d->s_mu; a.slv = d->s_lv;
+  a.n = d->n; a.nq = d->nq; a.ns = d->ns;
+  a.l1_scale = d->l1_scale; a.kl_scale = d->kl_scale; a.style_scale = d->style_scale;
+  a.mse_cof = d->mse_cof; a.kl_cof = d->kl_cof;
+  return DVAE_OK;
+}
+}  // namespace
+
+DVAE_API int64_t dvae_loss_ws_bytes(int64_t n) {
+  (void)n;
+  return (int64_t)L1_BLOCKS * 4 * sizeof(double);
+}
+
+DVAE_API int dvae_loss_fwd(const dvae_loss_desc_t* desc, float* out8, void* ws, void* stream) {
+  LossArgs a;
+  int rc = fill_loss_args(a, desc);
+  if (rc) return rc;
+  if (!out8 || !ws) return DVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = nblk(a.n / 4 + 1, 256, L1_BLOCKS);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, s, a, (double*)ws);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, a, (const double*)ws, blocks, out8);
+  return dvae_check_launch();
+}
+
+DVAE_API int dvae_loss_bwd(const dvae_loss_desc_t* desc, const float* g8, float* d_recon1, float* d_recon2,
+                           float* d_recon1_hat, float* d_recon2_hat, float* d_q1_mu, float* d_q1_lv, float* d_q2_mu,
+                           float* d_q2_lv, float* d_s_mu, float* d_s_lv, void* stream) {
+  LossArgs a;
+  int rc = fill_loss_args(a, desc);
+  if (rc) return rc;
+  if (!g8 || (!d_q1_mu != !d_q1_lv) || (!d_q2_mu != !d_q2_lv) || (!d_s_mu != !d_s_lv)) return DVAE_EINVAL;
+  const float* outs[] = {d_recon1, d_recon2, d_recon1_hat, d_recon2_hat};
+  for (const float* p : outs)
+    if (p && (((uintptr_t)p) & 15)) return DVAE_EINVAL;
+  const int blocks = nblk(a.n / 4 + 1, 256, 1024);
+  hipLaunchKernelGGL(loss_bwd_kernel, dim3(blocks + 1), dim3(256), 0, (hipStream_t)stream, a, g8, d_recon1, d_recon2,
+                     d_recon1_hat, d_recon2_hat, d_q1_mu, d_q1_lv, d_q2_mu, d_q2_lv, d_s_mu, d_s_lv, blocks);
   return dvae_check_launch();
 }
 

@@ -73,6 +73,10 @@ struct GemmParams {
   int act, epi;
   int tiles_m;
   int xcd_map;           // contiguous m-tile ranges per XCD (see the kernel)
+  // conv forward feeding a training-mode BatchNorm: per-column partial sums of the stored outputs, one fp64 pair per
+  // (64-row chunk, group, column) in the layout bn.hip's finalize kernels read — drops bn_partial's pass over Y
+  double* bn_part;
+  int bn_groups, bn_nseg;
 };
 
 // BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
@@ -483,6 +487,51 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
   const int epi = p.epi, act = p.act;
+  if constexpr (WG == 2) {
+    if (p.bn_part) {
+      // BatchNorm partial statistics of this wave's 64 rows x 32*NTW columns (= one 64-row chunk of bn.hip): sum and
+      // sum of squares per group; the two lane halves of a column meet in a shuffle, lane half 0 writes.  fp32 over the
+      // 64 values of a chunk, fp64 from there on (bn_stats_finalize).
+      const int nseg = p.bn_nseg, per = nseg / p.bn_groups;
+      const int rbase = m0 + wm * 64 + 4 * kh;
+      const int chunk = tile_m * 2 + wm, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+      const int bmod = rbase % nseg;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int col = n0 + wn * 32 * NTW + nt * 32 + l31;
+        const float bias_v = (add_bias && col < p.N) ? p.bias[col] : 0.f;
+        float s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f};     // [stat] of group 0 / group 1
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int dr = mt * 32 + (r & 3) + 8 * (r >> 2);
+            int rm = bmod + dr;
+            if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+            const bool ok = (rbase + dr < p.M), g1 = rm >= per;
+            const float v = ok ? acc[mt][nt][r] + bias_v : 0.f;
+            s0[0] += g1 ? 0.f : v;
+            s0[1] += g1 ? 0.f : v * v;
+            s1[0] += g1 ? v : 0.f;
+            s1[1] += g1 ? v * v : 0.f;
+          }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          s0[q] += __shfl_xor(s0[q], 32, 64);
+          s1[q] += __shfl_xor(s1[q], 32, 64);
+        }
+        if (kh == 0 && col < p.N && chunk < nchunks) {
+          double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
+          o[0] = (double)s0[0];
+          o[1] = (double)s0[1];
+          if (p.bn_groups > 1) {
+            o[(int64_t)p.N * 2] = (double)s1[0];
+            o[(int64_t)p.N * 2 + 1] = (double)s1[1];
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -638,6 +687,22 @@ DVAE_API int dvae_gemm_f32(const float* A, const float* B, float* C, const float
   p.taps = 1; p.tap_mode = 0;
   p.split_k = split_k; p.act = act; p.epi = epi;
   return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
+}
+
+// conv forward that also leaves the BatchNorm partial statistics of Y in `bn_ws` (>= dvae_bn_ws_bytes(R, Cout, G) bytes,
+// the layout dvae_bn_stats_finalize reads); G = statistics groups (1 or 2)
+DVAE_API int dvae_conv5_fwd_stats(const float* X, const float* Wp, const float* bias, float* Y, int R, int N, int Cin,
+                                  int Cout, int mode, int G, void* bn_ws, void* stream) {
+  if (!bn_ws || G < 1 || G > 2 || N < 1 || (N % G) || (R % N)) return DVAE_EINVAL;
+  GemmParams p{};
+  p.A = X; p.B = Wp; p.C = Y; p.bias = bias;
+  p.M = R; p.N = Cout; p.K = Cin;
+  p.lda = Cin; p.ldb = Cin; p.ldc = Cout;
+  p.taps = 5; p.tap_mode = 1;
+  p.a_row_shift = N; p.b_tap_stride = (int64_t)Cout * Cin;
+  p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
+  p.bn_part = (double*)bn_ws; p.bn_groups = G; p.bn_nseg = N;
+  return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 
 DVAE_API int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y, int R, int N,

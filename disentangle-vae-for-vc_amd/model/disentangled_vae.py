@@ -438,14 +438,16 @@ class ConvolutionalMulVAE(VariationalBaseModelVAE):
                            q_z2_mu, q_z2_logvar, style_mu1, style_logvar1, train=False):
         """8-tuple (LOSS, L1_x1, L1_x2, L1_x1hat, L1_x2hat, KL_z1, KL_z2, z_kl_style), disentangled_vae.py:310-327.
         The variables are named MSE_* in the reference but are L1 sums divided by the CONFIGURED batch size."""
+        return self.losses_vector(x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar,
+                                  q_z2_mu, q_z2_logvar, style_mu1, style_logvar1).unbind(0)
+
+    def losses_vector(self, x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar, q_z2_mu,
+                      q_z2_logvar, style_mu1, style_logvar1):
+        """The same eight scalars as one device vector [8] (two launches forward, one backward: ops.LossGVAE2Fn)."""
         inv_b = 1.0 / float(self.batch_size)
-        l1 = [L1SumFn.apply(x1, x_recon1, inv_b), L1SumFn.apply(x2, x_recon2, inv_b),
-              L1SumFn.apply(x1, recons_x1_hat, inv_b), L1SumFn.apply(x2, recons_x2_hat, inv_b)]
-        kl1 = KlFn.apply(q_z1_mu, q_z1_logvar, -0.5 / q_z1_mu.shape[0])
-        kl2 = KlFn.apply(q_z2_mu, q_z2_logvar, -0.5 / q_z2_mu.shape[0])
-        kl_style = KlFn.apply(style_mu1, style_logvar1, -inv_b)
-        loss = self.mse_cof * (l1[0] + l1[1] + l1[2] + l1[3]) + self.kl_cof * (kl1 + kl2)
-        return loss, l1[0], l1[1], l1[2], l1[3], kl1, kl2, kl_style
+        return ops.LossGVAE2Fn.apply(x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar,
+                                     q_z2_mu, q_z2_logvar, style_mu1, style_logvar1, inv_b, -0.5 / q_z1_mu.shape[0],
+                                     -inv_b, self.mse_cof, self.kl_cof)
 
     def update_(self):
         self.model.update_c()

@@ -90,7 +90,12 @@ class VariationalBaseModelVAE:
     def _eager_train_step(self, data1, data2):
         self.optimizer.zero_grad()
         outs = self.model(data1, data2)
-        losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
+        if hasattr(self, "losses_vector"):
+            vec = self.losses_vector(data1, data2, *outs)      # the eight scalars as one vector (fused loss kernels)
+            losses = (vec[0],)
+        else:
+            vec = None
+            losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
         if self.reducer is not None:
             self.reducer.begin()
         losses[0].backward()
@@ -99,7 +104,7 @@ class VariationalBaseModelVAE:
             self.reducer.finish()
             scale = 1.0 / self.reducer.world_size
         self.optimizer.step(grad_scale=scale)
-        return torch.stack([l.detach() for l in losses])
+        return vec.detach() if vec is not None else torch.stack([l.detach() for l in losses])
 
     def _step_graph(self, data1, data2):
         m = self.model

@@ -305,16 +305,19 @@ class ConvBnActFn(torch.autograd.Function):
         st = stream()
         mode = current_mode()
         y = torch.empty((R, Cout), device=dev, dtype=torch.float32)
-        check(L.dvae_conv5_fwd(ptr(x), ptr(conv_wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, st),
-              "dvae_conv5_fwd")
         if training:
+            # the conv epilogue leaves the BatchNorm partial sums of y behind: no separate statistics pass over y
             G = groups
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             rstd = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
-            check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt),
-                                      ptr(ws), R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_fwd")
+            check(L.dvae_conv5_fwd_stats(ptr(x), ptr(conv_wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, G, ptr(ws),
+                                         st), "dvae_conv5_fwd_stats")
+            check(L.dvae_bn_stats_finalize(ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(ws),
+                                           R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_finalize")
         else:
+            check(L.dvae_conv5_fwd(ptr(x), ptr(conv_wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, st),
+                  "dvae_conv5_fwd")
             G = 1
             mean = running_mean.detach().reshape(1, Cout).contiguous()
             rstd = torch.rsqrt(running_var.detach() + BN_EPS).reshape(1, Cout).contiguous()
@@ -703,6 +706,59 @@ class L1SumFn(torch.autograd.Function):
         check(lib().dvae_l1_sum_bwd(ptr(x), ptr(y), ptr(g), ptr(dy), x.numel(), ctx.scale, stream()),
               "dvae_l1_sum_bwd")
         return None, dy, None
+
+
+class LossGVAE2Fn(torch.autograd.Function):
+    """The eight scalars of loss_functionGVAE2 (disentangled_vae.py:310-327) as ONE vector
+    (LOSS, L1_x1, L1_x2, L1_x1hat, L1_x2hat, KL_z1, KL_z2, KL_style): two launches forward, one backward."""
+
+    @staticmethod
+    def _desc(x1, x2, r, q, scales):
+        d = _lib.LossDesc()
+        d.x1, d.x2 = ptr(x1), ptr(x2)
+        d.recon1, d.recon2, d.recon1_hat, d.recon2_hat = (ptr(t) for t in r)
+        d.q1_mu, d.q1_lv, d.q2_mu, d.q2_lv, d.s_mu, d.s_lv = (ptr(t) for t in q)
+        d.n, d.nq, d.ns = x1.numel(), q[0].numel(), q[4].numel()
+        d.l1_scale, d.kl_scale, d.style_scale, d.mse_cof, d.kl_cof = scales
+        return d
+
+    @staticmethod
+    def forward(ctx, x1, x2, r1, r2, h1, h2, q1mu, q1lv, q2mu, q2lv, smu, slv, l1_scale, kl_scale, style_scale, mse_cof,
+                kl_cof):
+        ts = [t.contiguous() for t in (x1, x2, r1, r2, h1, h2, q1mu, q1lv, q2mu, q2lv, smu, slv)]
+        _ok(*ts)
+        for t in ts[1:6]:
+            if t.numel() != ts[0].numel():
+                raise ValueError("loss: inputs and reconstructions must have the same number of elements")
+        if not (ts[6].numel() == ts[7].numel() == ts[8].numel() == ts[9].numel() and ts[10].numel() == ts[11].numel()):
+            raise ValueError("loss: mu / logvar shapes do not match")
+        scales = (float(l1_scale), float(kl_scale), float(style_scale), float(mse_cof), float(kl_cof))
+        L = lib()
+        out = torch.empty(8, device=ts[0].device, dtype=torch.float32)
+        ws = torch.empty((L.dvae_loss_ws_bytes(ts[0].numel()),), device=ts[0].device, dtype=torch.uint8)
+        d = LossGVAE2Fn._desc(ts[0], ts[1], ts[2:6], ts[6:12], scales)
+        check(L.dvae_loss_fwd(C.byref(d), ptr(out), ptr(ws), stream()), "dvae_loss_fwd")
+        ctx.save_for_backward(*ts)
+        ctx.scales = scales
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        g = g.contiguous()
+        need = ctx.needs_input_grad
+        grads = [None] * 12
+        for i in range(2, 12):
+            if need[i]:
+                grads[i] = torch.empty_like(ts[i])
+        # mu / logvar gradients come in pairs
+        for a, b in ((6, 7), (8, 9), (10, 11)):
+            if (grads[a] is None) != (grads[b] is None):
+                grads[a] = grads[a] if grads[a] is not None else torch.empty_like(ts[a])
+                grads[b] = grads[b] if grads[b] is not None else torch.empty_like(ts[b])
+        d = LossGVAE2Fn._desc(ts[0], ts[1], ts[2:6], ts[6:12], ctx.scales)
+        check(lib().dvae_loss_bwd(C.byref(d), ptr(g), *[ptr(grads[i]) for i in range(2, 12)], stream()), "dvae_loss_bwd")
+        return (None, None, *[grads[i] if need[i] else None for i in range(2, 12)], None, None, None, None, None)
 
 
 def prof_enable(family: int):

@@ -87,6 +87,11 @@ int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
  */
 int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y,
                    int R, int N, int Cin, int Cout, int mode, void* stream);
+/* conv forward that also leaves the per-column partial sums of Y that a training-mode BatchNorm over G statistics groups
+ * needs in bn_ws (>= dvae_bn_ws_bytes(R, Cout, G) bytes): follow with dvae_bn_stats_finalize instead of
+ * dvae_bn_stats_fwd — one pass over Y less per block (disentangled_vae.py:151-162: conv -> BatchNorm -> ReLU) */
+int dvae_conv5_fwd_stats(const float* X, const float* Wp, const float* bias, float* Y,
+                         int R, int N, int Cin, int Cout, int mode, int G, void* bn_ws, void* stream);
 int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp,
                      int R, int N, int Cin, int Cout, int split_k, int mode, void* stream);
 /* W[Cout][Cin][5] (torch layout, state_dict contract) -> Wp[5][Cout][Cin] */
@@ -112,6 +117,10 @@ int64_t dvae_bn_ws_bytes(int R, int C, int G);
 int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* running_mean, float* running_var,
                       int64_t* num_batches_tracked, void* ws, int R, int N, int C, int G,
                       float eps, float momentum, void* stream);
+/* finalize only: the partial sums are already in ws (left there by dvae_conv5_fwd_stats) */
+int dvae_bn_stats_finalize(float* mean, float* rstd, float* running_mean, float* running_var,
+                           int64_t* num_batches_tracked, const void* ws, int R, int N, int C, int G,
+                           float eps, float momentum, void* stream);
 int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
                       const float* beta, const float* residual, float* Z,
                       int R, int N, int C, int G, int act, void* stream);
@@ -209,6 +218,27 @@ int dvae_l1_sum_fwd(const float* x, const float* y, float* out, void* ws, int64_
 /* dy = -sign(x-y) * g * scale */
 int dvae_l1_sum_bwd(const float* x, const float* y, const float* gout, float* dy, int64_t n, float scale,
                     void* stream);
+
+/* ---- the whole loss_functionGVAE2 (disentangled_vae.py:310-327) in two launches forward, one backward ----
+ * out8 = (LOSS, L1(x1,recon1), L1(x2,recon2), L1(x1,recon1_hat), L1(x2,recon2_hat), KL_z1, KL_z2, KL_style) with
+ *   L1(x, r) = l1_scale * sum|x - r|                      (l1_scale = 1 / batch_size: F.l1_loss(sum).div(batch_size))
+ *   KL_zk    = kl_scale * sum(1 + lv - mu^2 - exp(lv))   (kl_scale = -0.5 / rows of q_zk_mu: torch.mean over the batch)
+ *   KL_style = style_scale * sum(...)                     (report only)
+ *   LOSS     = mse_cof * (((L1_1 + L1_2) + L1_3) + L1_4) + kl_cof * (KL_z1 + KL_z2)
+ * bwd: g8 = gradient w.r.t. out8 (a device vector: no host round trip); any output pointer may be null (not needed). */
+typedef struct {
+  const float *x1, *x2, *recon1, *recon2, *recon1_hat, *recon2_hat;   /* [n] each, 16-byte aligned */
+  const float *q1_mu, *q1_lv, *q2_mu, *q2_lv;                          /* [nq] each */
+  const float *s_mu, *s_lv;                                            /* [ns] each */
+  int64_t n;
+  int nq, ns;
+  float l1_scale, kl_scale, style_scale, mse_cof, kl_cof;
+} dvae_loss_desc_t;
+int64_t dvae_loss_ws_bytes(int64_t n);
+int dvae_loss_fwd(const dvae_loss_desc_t* desc, float* out8, void* ws, void* stream);
+int dvae_loss_bwd(const dvae_loss_desc_t* desc, const float* g8, float* d_recon1, float* d_recon2, float* d_recon1_hat,
+                  float* d_recon2_hat, float* d_q1_mu, float* d_q1_lv, float* d_q2_mu, float* d_q2_lv, float* d_s_mu,
+                  float* d_s_lv, void* stream);
 
 /* ---- Adam over one flat parameter buffer (torch.optim.Adam at disentangled_vae.py:304) ----
  * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). `step` is 1-based. */

@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import torch
 
 from oracle import mel_ref
 
@@ -83,6 +84,25 @@ def test_hip_frontend_matches_restatement(n):
     assert got.shape == ref.shape == (80, fe.num_frames(n))
     # normalised units: 1e-4 = 0.01 dB.  fp32 DFT round-off only matters in bins ~100 dB below the frame's peak.
     assert np.abs(got - ref).max() <= 2e-4, np.abs(got - ref).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_hip_frontend_does_not_follow_the_training_compute_mode(mode):
+    """Features must be those of the fp32 corpus whatever arithmetic the TRAINING contractions run in: the front-end
+    pins its two contractions to exact fp32 products (bf16 operands would put a leakage floor ~50 dB under each frame's
+    peak against a 100 dB normalisation range)."""
+    from dvae_amd import ops
+    from dvae_amd.frontend import MelFrontend
+    fe = MelFrontend()
+    wav = _signal(16001, 3)
+    base = fe.melspectrogram(wav)
+    with ops.compute_dtype(mode):
+        other = fe.melspectrogram(wav)
+        assert ops.get_compute_dtype() == mode
+    assert torch.equal(base, other)
+    ref = mel_ref.melspectrogram(wav.astype(np.float64))
+    assert np.abs(other.cpu().numpy() - ref).max() <= 2e-4
 
 
 @pytest.mark.gpu

@@ -322,3 +322,63 @@ def test_model_bf16_full_size_steps(ops):
     ops.set_compute_dtype("bf16")
     d = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(first["bf16"], first["fp32"]))
     assert 1e-7 < d < 2e-2, d
+
+
+@pytest.mark.parametrize("B,T,name", [(128, 256, "configs[2]"), (64, 512, "configs[4] per-GPU shape")])
+def test_model_bf16_baseline_config_shapes(ops, B, T, name):
+    """BASELINE configs[2] (bf16, B=128, T=256, 162 M parameters) and the per-GPU shape of configs[4] (bf16, B=64, T=512,
+    296 M parameters) at FULL size through the replayed graph.  No CPU oracle finishes at these sizes in test time, so
+    the checks are the size-independent properties of the path: finite losses that decrease over Adam steps on a fixed
+    batch; the eight scalars consistent with each other (LOSS = 10 * (4 L1 terms) + 10 * (2 KL terms)); pair symmetry
+    (swapping the utterances and their noise swaps the per-utterance terms) in eval mode; agreement with the fp32x3 path
+    on the same batch and noise within bf16 distance."""
+    from oracle.fill import synthetic_eps, synthetic_pair
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 9))
+    eps = synthetic_eps(B, seed=10)
+    w = _make(B, T)
+    w.model.eps_override = eps
+    with torch.no_grad():
+        w.model.eval()
+        la = [float(v) for v in w.loss_functionGVAE2(x1, x2, *w.model(x1, x2))]
+        w.model.eps_override = (eps[1], eps[0], eps[2])
+        lb = [float(v) for v in w.loss_functionGVAE2(x2, x1, *w.model(x2, x1))]
+        w.model.train()
+    rel = lambda a, b: abs(a - b) / max(1e-12, abs(b))
+    assert rel(la[1], lb[2]) < 1e-4 and rel(la[2], lb[1]) < 1e-4 and rel(la[3], lb[4]) < 1e-4 and rel(la[5], lb[6]) < 1e-4
+    w.model.eps_override = eps
+    w.enable_graph(True)
+    hist = [w.step(x1, x2, None, train=True) for _ in range(4)]
+    assert all(np.isfinite(h).all() for h in hist), name
+    assert hist[-1][0] < hist[0][0], (name, [h[0] for h in hist])
+    for h in hist:
+        assert rel(h[0], 10.0 * (h[1] + h[2] + h[3] + h[4]) + 10.0 * (h[5] + h[6])) < 1e-5, h
+    first_bf16 = hist[0]
+    del w
+    torch.cuda.empty_cache()
+    with ops.compute_dtype("fp32x3"):
+        w32 = _make(B, T)
+        w32.model.eps_override = eps
+        first_f32 = w32.step(x1, x2, None, train=True)
+    d = max(abs(a - b) / max(1.0, abs(b)) for a, b in zip(first_bf16, first_f32))
+    assert 1e-7 < d < 2e-2, (name, d)
+
+
+def test_model_bf16_t512_losses_against_bf16_oracle(ops):
+    """configs[4]'s frame count (T = 512) at B = 1 against the bf16 oracle: the eight loss scalars to 2e-3 (the end-to-end
+    bound of this mode, see test_model_bf16_losses_and_gradients)."""
+    from oracle.bf16_ref import RefDVAEBf16
+    from oracle.dvae_ref import loss_gvae2
+    from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+    B, T = 1, 512
+    x1, x2 = synthetic_pair(B, T, 41)
+    eps = synthetic_eps(B, seed=42)
+    m = RefDVAEBf16(4, 32, T)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    m.train()
+    with torch.no_grad():
+        ref = [float(l) for l in loss_gvae2(x1, x2, m(x1, x2, eps), B)]
+    w = _make(B, T)
+    w.model.eps_override = eps
+    got = w.step(x1.cuda(), x2.cuda(), None, train=True)
+    for i in range(8):
+        assert abs(got[i] - ref[i]) <= 2e-3 * max(1.0, abs(ref[i])), (i, got[i], ref[i])

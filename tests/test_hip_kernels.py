@@ -433,3 +433,79 @@ def test_bn_one_group_equals_two_separate_calls(ops):
     close(rm2, rm1, rel=1e-5, name="running_mean order")
     close(rv2, rv1, rel=1e-5, name="running_var order")
     assert int(nb2) == int(nb1) == 2
+
+
+@pytest.mark.parametrize("N,T,Cin,Cout,G", [(5, 7, 80, 80, 1), (6, 21, 80, 512, 2), (128, 9, 512, 512, 2), (2, 100, 512, 80, 2),
+                                            (66, 3, 80, 512, 2)])
+def test_conv_epilogue_bn_statistics_equal_the_standalone_pass(ops, N, T, Cin, Cout, G):
+    """dvae_conv5_fwd_stats (BatchNorm partial sums written by the conv epilogue, one fp64 pair per 64-row chunk, group
+    and column) + dvae_bn_stats_finalize against dvae_conv5_fwd + dvae_bn_stats_fwd (the separate statistics pass), on
+    ragged row counts (partial chunks, chunks straddling a frame, fewer segments than rows per chunk)."""
+    from dvae_amd._lib import check, lib, ptr, stream
+    L = lib()
+    R = N * T
+    x = dev(rnd(R, Cin, seed=1))
+    wp = dev(rnd(5, Cout, Cin, seed=2) * 0.1)
+    b = dev(rnd(Cout, seed=3) + 1.0)
+    mode = ops.current_mode()
+    out = {}
+    for fused in (False, True):
+        y = torch.empty(R, Cout, device="cuda")
+        mean, rstd = torch.empty(G, Cout, device="cuda"), torch.empty(G, Cout, device="cuda")
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        nbt = torch.zeros((), dtype=torch.long, device="cuda")
+        ws = torch.full((L.dvae_bn_ws_bytes(R, Cout, G),), 0xFF, device="cuda", dtype=torch.uint8)   # poison: every slot must be written
+        if fused:
+            check(L.dvae_conv5_fwd_stats(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, Cin, Cout, mode, G, ptr(ws), stream()), "fwd_stats")
+            check(L.dvae_bn_stats_finalize(ptr(mean), ptr(rstd), ptr(rm), ptr(rv), ptr(nbt), ptr(ws), R, N, Cout, G, 1e-5, 0.1,
+                                           stream()), "finalize")
+        else:
+            check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, Cin, Cout, mode, stream()), "fwd")
+            check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(rm), ptr(rv), ptr(nbt), ptr(ws), R, N, Cout, G, 1e-5, 0.1,
+                                      stream()), "stats")
+        out[fused] = (y, mean, rstd, rm, rv, int(nbt))
+    assert torch.equal(out[True][0], out[False][0])                    # same conv output
+    for k, name in ((1, "mean"), (2, "rstd"), (3, "running_mean"), (4, "running_var")):
+        close(out[True][k], out[False][k], rel=2e-5, name=name)
+    assert out[True][5] == out[False][5] == G
+    # and against torch on the CPU
+    yc = out[False][0].cpu().double().reshape(T, N, Cout)
+    per = N // G
+    for g in range(G):
+        seg = yc[:, g * per:(g + 1) * per].reshape(-1, Cout)
+        close(out[True][1][g], seg.mean(0), rel=2e-5, name="mean vs torch")
+        close(out[True][2][g], 1.0 / torch.sqrt(seg.var(0, unbiased=False) + 1e-5), rel=1e-4, name="rstd vs torch")
+
+
+@pytest.mark.parametrize("B,T", [(3, 17), (4, 64)])
+def test_fused_loss_gvae2(ops, B, T):
+    """ops.LossGVAE2Fn (the eight scalars of loss_functionGVAE2 in two launches, one backward launch) against the
+    reference's formulas in torch on the CPU (disentangled_vae.py:310-327), with an upstream gradient on EVERY output."""
+    n = 80 * T
+    x = [rnd(B, 80, T, seed=s, lo=0.0) for s in (1, 2)]
+    r = [rnd(B, 80, T, seed=s).requires_grad_() for s in (3, 4, 5, 6)]
+    q = [rnd(B, 32, seed=s).requires_grad_() for s in (7, 8, 9, 10)]
+    st = [rnd(B, 4, seed=s).requires_grad_() for s in (11, 12)]
+    bs, mse_cof, kl_cof = 7.0, 10.0, 3.0
+    l1 = [F.l1_loss(r[k], x[k & 1], reduction="sum") / bs for k in range(4)]
+    kl = lambda mu, lv: (-0.5) * torch.mean(torch.sum(1 + lv - mu.pow(2) - lv.exp(), dim=-1))
+    k1, k2 = kl(q[0], q[1]), kl(q[2], q[3])
+    ks = (-1.0) * torch.sum(1 + st[1] - st[0].pow(2) - st[1].exp()) / bs
+    loss = mse_cof * (l1[0] + l1[1] + l1[2] + l1[3]) + kl_cof * (k1 + k2)
+    ref = torch.stack([loss, *l1, k1, k2, ks])
+    gv = rnd(8, seed=13) + 1.5
+    (ref * gv).sum().backward()
+
+    d = lambda t: dev(t.detach()).requires_grad_(t.requires_grad)
+    xd, rd, qd, sd = [d(t) for t in x], [d(t) for t in r], [d(t) for t in q], [d(t) for t in st]
+    out = ops.LossGVAE2Fn.apply(xd[0], xd[1], *rd, *qd, *sd, 1.0 / bs, -0.5 / B, -1.0 / bs, mse_cof, kl_cof)
+    close(out, ref, rel=2e-6, name="loss vector")
+    (out * dev(gv)).sum().backward()
+    for a, b_, nm in zip(rd + qd + sd, r + q + st, ["r1", "r2", "h1", "h2", "q1mu", "q1lv", "q2mu", "q2lv", "smu", "slv"]):
+        close(a.grad, b_.grad, rel=1e-5, name="d" + nm)
+    # only the total (what the training step differentiates)
+    rd2 = [d(t) for t in r]
+    out2 = ops.LossGVAE2Fn.apply(xd[0], xd[1], *rd2, *[t.detach() for t in qd], *[t.detach() for t in sd], 1.0 / bs,
+                                 -0.5 / B, -1.0 / bs, mse_cof, kl_cof)
+    out2[0].backward()
+    assert rd2[2].grad is not None and float(rd2[2].grad.abs().max()) == pytest.approx(mse_cof / bs, rel=1e-6)
