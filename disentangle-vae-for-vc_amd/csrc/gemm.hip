@@ -96,7 +96,7 @@ struct GemmParams {
 // three bf16 images per operand and the fragment reads are those of the bf16 mode, three per tile.  Splitting in
 // registers after the fragment read (fp32 images) measured 160 TFLOP/s: every element is then split by both waves
 // that read it and the VALU stream sits in front of each MFMA burst.
-template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0>
+template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0, bool BNS = false>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
   constexpr bool BF = (MODE == 1), X3 = (MODE == 2);
   static_assert(!BF || (BK == 32 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
@@ -487,50 +487,18 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
   const int epi = p.epi, act = p.act;
-  if constexpr (WG == 2) {
-    if (p.bn_part) {
-      // BatchNorm partial statistics of this wave's 64 rows x 32*NTW columns (= one 64-row chunk of bn.hip): sum and
-      // sum of squares per group; the two lane halves of a column meet in a shuffle, lane half 0 writes.  fp32 over the
-      // 64 values of a chunk, fp64 from there on (bn_stats_finalize).
-      const int nseg = p.bn_nseg, per = nseg / p.bn_groups;
-      const int rbase = m0 + wm * 64 + 4 * kh;
-      const int chunk = tile_m * 2 + wm, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
-      const int bmod = rbase % nseg;
+  // BNS: BatchNorm partial statistics of this wave's 64 rows x 32*NTW columns (= one 64-row chunk of bn.hip), gathered
+  // in the SAME pass that stores the tile (each accumulator is read once): sum and sum of squares per statistics group,
+  // fp32 over the 64 values of a chunk, fp64 from there on (bn_stats_finalize).  A separate instantiation: in the
+  // common one this code cost 120 VGPRs (occupancy 1 instead of 2-3).
+  float bst[NTW][4];    // [column tile][group 0: sum, sumsq; group 1: sum, sumsq]
+  int bmod = 0;
+  if constexpr (BNS) {
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int col = n0 + wn * 32 * NTW + nt * 32 + l31;
-        const float bias_v = (add_bias && col < p.N) ? p.bias[col] : 0.f;
-        float s0[2] = {0.f, 0.f}, s1[2] = {0.f, 0.f};     // [stat] of group 0 / group 1
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dr = mt * 32 + (r & 3) + 8 * (r >> 2);
-            int rm = bmod + dr;
-            if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
-            const bool ok = (rbase + dr < p.M), g1 = rm >= per;
-            const float v = ok ? acc[mt][nt][r] + bias_v : 0.f;
-            s0[0] += g1 ? 0.f : v;
-            s0[1] += g1 ? 0.f : v * v;
-            s1[0] += g1 ? v : 0.f;
-            s1[1] += g1 ? v * v : 0.f;
-          }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          s0[q] += __shfl_xor(s0[q], 32, 64);
-          s1[q] += __shfl_xor(s1[q], 32, 64);
-        }
-        if (kh == 0 && col < p.N && chunk < nchunks) {
-          double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
-          o[0] = (double)s0[0];
-          o[1] = (double)s0[1];
-          if (p.bn_groups > 1) {
-            o[(int64_t)p.N * 2] = (double)s1[0];
-            o[(int64_t)p.N * 2 + 1] = (double)s1[1];
-          }
-        }
-      }
-    }
+      for (int q = 0; q < 4; ++q) bst[nt][q] = 0.f;
+    bmod = (m0 + wm * 64 + 4 * kh) % p.bn_nseg;
   }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -546,7 +514,20 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int dr = (r & 3) + 8 * (r >> 2);
-            if (row0 + dr < p.M) cbase[(int64_t)dr * p.ldc] = acc[mt][nt][r] + bias_v;
+            const float v = acc[mt][nt][r] + bias_v;
+            const bool ok = row0 + dr < p.M;
+            if (ok) cbase[(int64_t)dr * p.ldc] = v;
+            if constexpr (BNS) {
+              const int nseg = p.bn_nseg;
+              int rm = bmod + mt * 32 + dr;
+              if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+              const float u = ok ? v : 0.f;
+              const bool g1 = rm >= nseg / p.bn_groups;
+              bst[nt][0] += g1 ? 0.f : u;
+              bst[nt][1] += g1 ? 0.f : u * u;
+              bst[nt][2] += g1 ? u : 0.f;
+              bst[nt][3] += g1 ? u * u : 0.f;
+            }
           }
         } else {
 #pragma unroll
@@ -570,6 +551,34 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       }
     }
   }
+  if constexpr (BNS) {
+    const int chunk = tile_m * 2 + wm, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = n0 + wn * 32 * NTW + nt * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);     // the two lane halves of a column
+      if (kh == 0 && col < p.N && chunk < nchunks) {
+        double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
+        o[0] = (double)bst[nt][0];
+        o[1] = (double)bst[nt][1];
+        if (p.bn_groups > 1) {
+          o[(int64_t)p.N * 2] = (double)bst[nt][2];
+          o[(int64_t)p.N * 2 + 1] = (double)bst[nt][3];
+        }
+      }
+    }
+  }
+}
+
+// conv forward with BatchNorm statistics (k-contiguous operands, 128-row tiles, unsplit, plain store)
+void launch_bns(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, int mode) {
+#define BNS_LAUNCH(NTW_, BK_, MODE_) hipLaunchKernelGGL((gemm_f32_kernel<true, true, NTW_, BK_, 2, MODE_, true>), grid, dim3(256), 0, s, p)
+  if (mode == DVAE_MODE_BF16) { if (narrow) BNS_LAUNCH(1, 32, 1); else BNS_LAUNCH(2, 32, 1); }
+  else if (mode == DVAE_MODE_F32X3) { if (narrow) BNS_LAUNCH(1, 16, 2); else BNS_LAUNCH(2, 16, 2); }
+  else if (bk == 32) { if (narrow) BNS_LAUNCH(1, 32, 0); else BNS_LAUNCH(2, 32, 0); }
+  else { if (narrow) BNS_LAUNCH(1, 16, 0); else BNS_LAUNCH(2, 16, 0); }
+#undef BNS_LAUNCH
 }
 
 template <bool AK, bool BKC>
@@ -650,7 +659,10 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   const double alg_bytes = 4.0 * ((double)p.M * p.K + (double)p.K * p.N * (p.tap_mode == 1 ? ntap : 1.0) +
                                   (double)p.M * p.N * (p.tap_mode == 2 ? ntap : 1.0));
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap, tag, alg_bytes);
-  if (a_kc && b_kc)
+  if (p.bn_part) {
+    if (!a_kc || !b_kc || big || p.split_k != 1 || p.epi != DVAE_EPI_STORE || p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
+    launch_bns(p, grid, s, narrow, bk, mode);
+  } else if (a_kc && b_kc)
     launch_variant<true, true>(p, grid, s, narrow, bk, big, mode);
   else if (a_kc && !b_kc)
     launch_variant<true, false>(p, grid, s, narrow, bk, big, mode);

@@ -100,7 +100,8 @@ def test_hip_frontend_does_not_follow_the_training_compute_mode(mode):
     with ops.compute_dtype(mode):
         other = fe.melspectrogram(wav)
         assert ops.get_compute_dtype() == mode
-    assert torch.equal(base, other)
+    # not bit-equal run to run (split-K partial sums meet in atomics), but far inside what bf16 operands would do (~1e-2)
+    assert float((base - other).abs().max()) <= 2e-6
     ref = mel_ref.melspectrogram(wav.astype(np.float64))
     assert np.abs(other.cpu().numpy() - ref).max() <= 2e-4
 
