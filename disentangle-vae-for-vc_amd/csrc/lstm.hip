@@ -541,7 +541,11 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
 
 // PM as in the forward kernel.  KR = k depth of a round (64; 32 in fp32x3 mode, where the wave-private staging holds three
 // planes per buffer: 8 waves x 2 buffers x 3 planes x 32 rows x 40 bf16 = 123 KB).
-template <int MT, int KR, int PM = 0>
+// NU = 16-unit column tiles per workgroup.  NU = 2 (32 hidden units x 16*MT segments) halves the dG[t+1] stream (4H wide,
+// the dominant traffic of this kernel) and turns two stacked H = 1024 layers into ONE resident round of 256 workgroups
+// instead of two — and measured 24.8 us per layer-frame against 18.1 (each wave's serial chain doubles; nothing overlaps
+// it at one workgroup per CU).  Kept as a parameter, dispatched with NU = 1.
+template <int MT, int KR, int PM = 0, int NU = 1>
 __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
   constexpr int NW = 8;
   constexpr bool B16 = (PM != 0);
@@ -552,6 +556,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
   constexpr int KRW = KR >= 64 ? 64 : KR;                 // floats of a row one load instruction covers
   constexpr int LPR = KRW / 4, RPI = 64 / LPR;            // lanes per row, rows per instruction
   constexpr int NRI = 16 * MT / RPI, NQ = KR / KRW;       // row groups, instructions per row
+  constexpr int UW = 16 * NU;                             // hidden units per workgroup
   using lds_t = typename std::conditional<B16, __bf16, float>::type;
   const StepDir& d = a.d[blockIdx.z];
   const int step = gstep - d.shift;
@@ -563,35 +568,53 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
   const int tp = d.reverse ? t + 1 : t - 1;
   int jb, mb;
   decode_block(blockIdx.x, n_j, n_m, jb, mb);
-  const int j0 = jb * 16, m0 = mb * 16 * MT;
+  const int j0 = jb * UW, m0 = mb * 16 * MT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quarter = wave >> 1, part = wave & 1;      // k range: [quarter*H + part*H/2, +H/2)
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) lds_t Ast[NW][2 * NP * PL];   // per wave, two buffers of NP planes
-  __shared__ float sm[NW][MT * 16][17];
+  // per wave: two staging buffers of NP planes; once a wave has left its k loop the same bytes hold its partial tiles
+  // (sm) for the cross-wave reduction (wave-private until the workgroup barrier)
+  constexpr int ST_BYTES = 2 * NP * PL * (int)sizeof(lds_t), SM_BYTES = MT * 16 * (UW + 1) * 4;
+  constexpr int WAVE_BYTES = ((ST_BYTES > SM_BYTES ? ST_BYTES : SM_BYTES) + 15) / 16 * 16;
+  __shared__ __attribute__((aligned(16))) char lds_raw[NW * WAVE_BYTES];
+  lds_t* __restrict__ stg = reinterpret_cast<lds_t*>(lds_raw + wave * WAVE_BYTES);
+  auto sm = [&](int w, int row, int col) -> float& {
+    return reinterpret_cast<float*>(lds_raw + w * WAVE_BYTES)[row * (UW + 1) + col];
+  };
 
+  // epilogue operands: MT*16 x UW (segment, unit) elements over 512 threads
+  constexpr int NEL = MT * 16 * UW, NE = (NEL + 511) / 512;
   const float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
-  const int en = m0 + (tid >> 4), ej = j0 + (tid & 15);
-  const bool eok = (tid < MT * 256) && (en < N);
-  float gt[4], cc, cp, dho, dcar;
+  int en[NE], ej[NE];
+  bool eok[NE];
+  float gt[NE][4], cc[NE], cp[NE], dho[NE], dcar[NE];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) gt[g] = eok ? G[(int64_t)en * 4 * H + g * H + ej] : 0.f;
-  cc = eok ? d.c_all[((int64_t)t * N + en) * H + ej] : 0.f;
-  cp = (eok && fstep > 0) ? d.c_all[((int64_t)tp * N + en) * H + ej] : 0.f;
-  dho = eok ? d.dh_out[((int64_t)t * N + en) * a.ldh + ej] : 0.f;
-  dcar = (eok && step > 0) ? d.dc[(int64_t)en * H + ej] : 0.f;
+  for (int e = 0; e < NE; ++e) {
+    const int idx = tid + 512 * e;
+    en[e] = m0 + idx / UW;
+    ej[e] = j0 + idx % UW;
+    eok[e] = (idx < NEL) && (en[e] < N);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) gt[e][g] = eok[e] ? G[(int64_t)en[e] * 4 * H + g * H + ej[e]] : 0.f;
+    cc[e] = eok[e] ? d.c_all[((int64_t)t * N + en[e]) * H + ej[e]] : 0.f;
+    cp[e] = (eok[e] && fstep > 0) ? d.c_all[((int64_t)tp * N + en[e]) * H + ej[e]] : 0.f;
+    dho[e] = eok[e] ? d.dh_out[((int64_t)t * N + en[e]) * a.ldh + ej[e]] : 0.f;
+    dcar[e] = (eok[e] && step > 0) ? d.dc[(int64_t)en[e] * H + ej[e]] : 0.f;
+  }
 
-  f32x4 acc[MT];
+  f32x4 acc[NU][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < NU; ++u)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[u][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (step > 0) {
     const int H4 = 4 * H;
     const int koff = quarter * H + part * (H / 2);
-    // packed W^T: [(jb*4 + quarter)][k-chunk inside the quarter][plane][lane][4 dwords]
-    const float* __restrict__ bpk = d.wp + (((int64_t)jb * 4 + quarter) * (H / KC) + (int64_t)part * (H / KC / 2)) * (256 * NP) + lane * 4;
-    lds_t* __restrict__ stg = &Ast[wave][0];
+    // packed W^T: [(jb16*4 + quarter)][k-chunk inside the quarter][plane][lane][4 dwords], jb16 = 16-unit column block
+    const float* __restrict__ bpk = d.wp + (((int64_t)jb * NU * 4 + quarter) * (H / KC) + (int64_t)part * (H / KC / 2)) * (256 * NP) + lane * 4;
+    const int64_t bpk_u = (int64_t)4 * (H / KC) * (256 * NP);      // from one 16-unit block to the next
     const int lrow = lane / LPR, lc4 = lane % LPR;
     const float* arow[NRI];
 #pragma unroll
@@ -624,11 +647,14 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
           }
         }
     };
-    auto loadB = [&](f32x4 (&b)[NS * NP], int rd) {
+    auto loadB = [&](f32x4 (&b)[NU][NS * NP], int rd) {
 #pragma unroll
-      for (int s = 0; s < NS * NP; ++s) b[s] = *reinterpret_cast<const f32x4*>(bpk + (int64_t)(rd * NS * NP + s) * 256);
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int s = 0; s < NS * NP; ++s)
+          b[u][s] = *reinterpret_cast<const f32x4*>(bpk + u * bpk_u + (int64_t)(rd * NS * NP + s) * 256);
     };
-    auto compute = [&](int buf, f32x4 (&b)[NS * NP]) {
+    auto compute = [&](int buf, f32x4 (&b)[NU][NS * NP]) {
       if constexpr (B16) {
         const lds_t* __restrict__ al = stg + buf * (NP * PL) + r * LDA + 8 * kq;
         constexpr int NT6 = (PM == 2) ? 6 : 1;
@@ -642,8 +668,10 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
             for (int p = 0; p < NP; ++p) av[p] = *reinterpret_cast<const bf16x8*>(al + p * PL + mt * 16 * LDA + 32 * s);
 #pragma unroll
             for (int term = 0; term < NT6; ++term)
-              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], __builtin_bit_cast(bf16x8, b[s * NP + ib[term]]),
-                                                                acc[mt], 0, 0, 0);
+#pragma unroll
+              for (int u = 0; u < NU; ++u)
+                acc[u][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], __builtin_bit_cast(bf16x8, b[u][s * NP + ib[term]]),
+                                                                     acc[u][mt], 0, 0, 0);
           }
       } else {
       const lds_t* __restrict__ al = stg + buf * (NP * PL) + r * LDA + 4 * kq;
@@ -656,7 +684,9 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], b[s][e], acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+              acc[u][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][e], b[u][s][e], acc[u][mt], 0, 0, 0);
       }
       }
     };
@@ -664,7 +694,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
     // Measured at H = 1024: PF = 4 is SLOWER than 2 (20.4 vs 18.0 us per frame: more loads in flight only deepen the
     // queues), so the frame kernels are throughput-, not latency-bound; see DESIGN.md.
     constexpr int PF = DVAE_LSTM_PF;
-    f32x4 bS[PF][NS * NP], sS[PF][NRI][NQ];
+    f32x4 bS[PF][NU][NS * NP], sS[PF][NRI][NQ];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       loadA(sS[u], min(u, last));
@@ -685,27 +715,33 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
       }
     }
   }
+  __builtin_amdgcn_wave_barrier();     // this wave's staging reads are done: its bytes become its partial tiles
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int u = 0; u < NU; ++u)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sm[wave][mt * 16 + kq * 4 + e][r] = acc[mt][e];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sm(wave, mt * 16 + kq * 4 + e, u * 16 + r) = acc[u][mt][e];
   __syncthreads();
 
-  if (eok) {
-    const int row = tid >> 4, col = tid & 15;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    if (!eok[e]) continue;
+    const int idx = tid + 512 * e;
+    const int row = idx / UW, col = idx % UW;
     float rec = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) rec += sm[w][row][col];
-    const float dh = dho + rec;
-    const float gi = gt[0], gf = gt[1], gg = gt[2], go = gt[3];
-    const float tc = gate_tanh(cc);
-    const float dc = dcar + dh * go * (1.f - tc * tc);
-    float* o = d.dgates + ((int64_t)t * N + en) * 4 * H + ej;
+    for (int w = 0; w < NW; ++w) rec += sm(w, row, col);
+    const float dh = dho[e] + rec;
+    const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
+    const float tc = gate_tanh(cc[e]);
+    const float dc = dcar[e] + dh * go * (1.f - tc * tc);
+    float* o = d.dgates + ((int64_t)t * N + en[e]) * 4 * H + ej[e];
     o[0] = dc * gg * gi * (1.f - gi);
-    o[H] = dc * cp * gf * (1.f - gf);
+    o[H] = dc * cp[e] * gf * (1.f - gf);
     o[2 * H] = dc * gi * (1.f - gg * gg);
     o[3 * H] = dh * tc * go * (1.f - go);
-    d.dc[(int64_t)en * H + ej] = dc * gf;
+    d.dc[(int64_t)en[e] * H + ej[e]] = dc * gf;
   }
 }
 
