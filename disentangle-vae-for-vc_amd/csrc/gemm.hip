@@ -56,10 +56,11 @@ __device__ __forceinline__ void split3(const f32x4& x, bf16x4 (&p)[3]) {
 // The large tile halves the global-load instructions per MFMA (measured: loads cost ~15 % of the small tile's time).
 
 struct GemmParams {
-  const float* A;
-  const float* B;
-  float* C;
+  const void* A;         // fp32, or bf16 when a16 (bf16 mode only)
+  const void* B;
+  void* C;               // fp32, or bf16 when c16 (plain store only)
   const float* bias;
+  int a16, b16, c16;
   int M, N, K;
   int64_t lda, ldb, ldc;
   int taps;              // 1 or 5
@@ -96,9 +97,14 @@ struct GemmParams {
 // three bf16 images per operand and the fragment reads are those of the bf16 mode, three per tile.  Splitting in
 // registers after the fragment read (fp32 images) measured 160 TFLOP/s: every element is then split by both waves
 // that read it and the VALU stream sits in front of each MFMA burst.
-template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0, bool BNS = false>
+// A16 / B16M (bf16 mode only): the operand is ALREADY bf16 in memory (activations written as bf16 by their producers,
+// bf16 weight copies from the repack launch): half the bytes per element and no conversion on the way into LDS.
+template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0, bool BNS = false, bool A16 = false, bool B16M = false>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
   constexpr bool BF = (MODE == 1), X3 = (MODE == 2);
+  static_assert(!(A16 || B16M) || MODE == 1, "bf16 operands in memory: bf16 mode only");
+  constexpr int EA = A16 ? 8 : 4, EB = B16M ? 8 : 4;      // elements per 16-byte load
+  constexpr int ESA = A16 ? 2 : 4, ESB = B16M ? 2 : 4;    // bytes per element in memory
   static_assert(!BF || (BK == 32 && WG == 2), "bf16 mode: 128 x 64*NTW x 32 tile only");
   static_assert(!X3 || (BK == 16 && WG == 2), "split mode: 128 x 64*NTW x 16 tile only (3 images x 2 buffers in LDS)");
   constexpr bool B16 = BF || X3;         // bf16 images in LDS
@@ -111,9 +117,9 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   constexpr int A_SZ = A_KC ? BM * LD_KC : BK * LDA;
   constexpr int B_SZ = B_KC ? BN * LD_KC : BK * LDB;
   using lds_t = typename std::conditional<B16, __bf16, float>::type;
-  constexpr int NLA = BM * BK / 4 / NTHR;   // float4 per thread per k-tile (A)
-  constexpr int NLB = BN * BK / 4 / NTHR;   // (B)
-  constexpr int KQ = BK / 4;                // float4 per row of a k-contiguous tile
+  constexpr int NLA = BM * BK / EA / NTHR;  // 16-byte loads per thread per k-tile (A)
+  constexpr int NLB = BN * BK / EB / NTHR;  // (B)
+  constexpr int KQA = BK / EA, KQB = BK / EB;   // 16-byte pieces per row of a k-contiguous tile
   constexpr int NC = BK / 8;                // 8-deep k groups per tile
   __shared__ __attribute__((aligned(16))) lds_t As[2][NP * A_SZ];
   __shared__ __attribute__((aligned(16))) lds_t Bs[2][NP * B_SZ];
@@ -151,20 +157,20 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   const int kiters = (klen + BK - 1) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
 
-  float* __restrict__ C = p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+  float* __restrict__ C = (float*)p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
-  // ---- per-thread source descriptors, computed once
-  const float* a_src[NLA];
+  // ---- per-thread source descriptors (byte pointers), computed once
+  const char* a_src[NLA];
   unsigned a_ok[NLA];   // bit `tap` set: the (shifted) source row exists
   int a_k[NLA];         // this load's k offset inside the tile (bound check against klen)
 #pragma unroll
   for (int j = 0; j < NLA; ++j) {
     const int idx = t + NTHR * j;
     if (A_KC) {
-      const int row = idx / KQ, kq = idx % KQ;
+      const int row = idx / KQA, kq = idx % KQA;
       const int64_t m = m0 + row;
-      a_k[j] = 4 * kq;
-      a_src[j] = p.A + m * p.lda + k_begin + 4 * kq;
+      a_k[j] = EA * kq;
+      a_src[j] = (const char*)p.A + (m * p.lda + k_begin + EA * kq) * ESA;
       unsigned ok = 0;
       if (m < p.M) {
         if (p.tap_mode == 1) {
@@ -179,29 +185,29 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       }
       a_ok[j] = ok;
     } else {
-      const int kr = idx / (BM / 4), m4 = idx % (BM / 4);
+      const int kr = idx / (BM / EA), m4 = idx % (BM / EA);
       a_k[j] = kr;
-      a_src[j] = p.A + (int64_t)(k_begin + kr) * p.lda + m0 + 4 * m4;
-      a_ok[j] = (m0 + 4 * m4 < p.M) ? 1u : 0u;
+      a_src[j] = (const char*)p.A + ((int64_t)(k_begin + kr) * p.lda + m0 + EA * m4) * ESA;
+      a_ok[j] = (m0 + EA * m4 < p.M) ? 1u : 0u;
     }
   }
-  const float* b_src[NLB];
+  const char* b_src[NLB];
   unsigned b_ok[NLB];
   int b_k[NLB];
 #pragma unroll
   for (int j = 0; j < NLB; ++j) {
     const int idx = t + NTHR * j;
     if (B_KC) {
-      const int row = idx / KQ, kq = idx % KQ;
-      b_k[j] = 4 * kq;
-      b_src[j] = p.B + (int64_t)(n0 + row) * p.ldb + k_begin + 4 * kq;
+      const int row = idx / KQB, kq = idx % KQB;
+      b_k[j] = EB * kq;
+      b_src[j] = (const char*)p.B + ((int64_t)(n0 + row) * p.ldb + k_begin + EB * kq) * ESB;
       b_ok[j] = (n0 + row < p.N) ? 1u : 0u;
     } else {
-      const int kr = idx / (BN / 4), n4 = idx % (BN / 4);
+      const int kr = idx / (BN / EB), n4 = idx % (BN / EB);
       b_k[j] = kr;
       const int64_t shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
-      b_src[j] = p.B + ((int64_t)(k_begin + kr) + shift) * p.ldb + n0 + 4 * n4;
-      b_ok[j] = (n0 + 4 * n4 < p.N) ? 1u : 0u;
+      b_src[j] = (const char*)p.B + (((int64_t)(k_begin + kr) + shift) * p.ldb + n0 + EB * n4) * ESB;
+      b_ok[j] = (n0 + EB * n4 < p.N) ? 1u : 0u;
     }
   }
   const int64_t b_shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   // Branch-free loads: a lane whose element does not exist (ragged edge, conv padding, k tail) reads 16 bytes of zeros
   // (g_gemm_zero) instead.  With `if (ok) load` hipcc gives every load its own basic block (s_and_saveexec + branch)
   // and a vmcnt(0) at the loop head, and nothing in the load phase can be scheduled next to an MFMA.
-  const float* __restrict__ zsrc = g_gemm_zero;
+  const char* __restrict__ zsrc = (const char*)g_gemm_zero;
   auto load_tiles = [&](f32x4 (&ra)[NLA], f32x4 (&rb)[NLB], int tap, int kit) {
     const int kofs = kit * BK;
     const int64_t a_tap = (p.tap_mode == 1) ? (int64_t)(tap - 2) * p.a_row_shift * p.lda : 0;
@@ -225,30 +231,30 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
       bool ok;
-      const float* src;
+      const char* src;
       if (A_KC) {
         ok = ((a_ok[j] >> tap) & 1u) && (kofs + a_k[j] < klen);
-        src = a_src[j] + a_tap + kofs;
+        src = a_src[j] + (a_tap + kofs) * ESA;
       } else {
         ok = a_ok[j] && (kofs + a_k[j] < klen);
-        src = a_src[j] + (int64_t)kofs * p.lda;
+        src = a_src[j] + (int64_t)kofs * p.lda * ESA;
       }
       ra[j] = *reinterpret_cast<const f32x4*>(ok ? src : zsrc);
     }
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       bool ok;
-      const float* src;
+      const char* src;
       if (B_KC) {
         ok = b_ok[j] && (kofs + b_k[j] < klen);
-        src = b_src[j] + b_tap + kofs;
+        src = b_src[j] + (b_tap + kofs) * ESB;
       } else {
         ok = b_ok[j] && (kofs + b_k[j] < klen);
         if (p.tap_mode == 2) {
           const int64_t kk = (int64_t)k_begin + kofs + b_k[j] + b_shift;
           ok = ok && (kk >= 0) && (kk < p.K);
         }
-        src = b_src[j] + b_tap + (int64_t)kofs * p.ldb;
+        src = b_src[j] + (b_tap + (int64_t)kofs * p.ldb) * ESB;
       }
       rb[j] = *reinterpret_cast<const f32x4*>(ok ? src : zsrc);
     }
@@ -258,8 +264,11 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLA; ++j) {
       const int idx = t + NTHR * j;
-      if constexpr (B16) {
-        const int off = A_KC ? (idx / KQ) * LDA + 4 * (idx % KQ) : (idx / (BM / 4)) * LDA + 4 * (idx % (BM / 4));
+      if constexpr (A16) {      // already bf16: 8 elements, one 16-byte LDS store
+        const int off = A_KC ? (idx / KQA) * LDA + EA * (idx % KQA) : (idx / (BM / EA)) * LDA + EA * (idx % (BM / EA));
+        *reinterpret_cast<f32x4*>(&As[buf][off]) = ra[j];
+      } else if constexpr (B16) {
+        const int off = A_KC ? (idx / KQA) * LDA + 4 * (idx % KQA) : (idx / (BM / 4)) * LDA + 4 * (idx % (BM / 4));
         if constexpr (X3) {
           bf16x4 pl[3];
           split3(ra[j], pl);
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
           *reinterpret_cast<bf16x4*>(&As[buf][off]) = __builtin_convertvector(ra[j], bf16x4);
         }
       } else if (A_KC) {
-        const int row = idx / KQ, kq = idx % KQ;
+        const int row = idx / KQA, kq = idx % KQA;
         *reinterpret_cast<f32x4*>(&As[buf][row * LDA + 4 * kq]) = ra[j];
       } else {
         const int kr = idx / (BM / 4), m4 = idx % (BM / 4);
@@ -279,8 +288,11 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
     for (int j = 0; j < NLB; ++j) {
       const int idx = t + NTHR * j;
-      if constexpr (B16) {
-        const int off = B_KC ? (idx / KQ) * LDB + 4 * (idx % KQ) : (idx / (BN / 4)) * LDB + 4 * (idx % (BN / 4));
+      if constexpr (B16M) {
+        const int off = B_KC ? (idx / KQB) * LDB + EB * (idx % KQB) : (idx / (BN / EB)) * LDB + EB * (idx % (BN / EB));
+        *reinterpret_cast<f32x4*>(&Bs[buf][off]) = rb[j];
+      } else if constexpr (B16) {
+        const int off = B_KC ? (idx / KQB) * LDB + 4 * (idx % KQB) : (idx / (BN / 4)) * LDB + 4 * (idx % (BN / 4));
         if constexpr (X3) {
           bf16x4 pl[3];
           split3(rb[j], pl);
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
           *reinterpret_cast<bf16x4*>(&Bs[buf][off]) = __builtin_convertvector(rb[j], bf16x4);
         }
       } else if (B_KC) {
-        const int row = idx / KQ, kq = idx % KQ;
+        const int row = idx / KQB, kq = idx % KQB;
         *reinterpret_cast<f32x4*>(&Bs[buf][row * LDB + 4 * kq]) = rb[j];
       } else {
         const int kr = idx / (BN / 4), n4 = idx % (BN / 4);
@@ -509,7 +521,14 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       const float bias_v = add_bias ? p.bias[col] : 0.f;
       const int row0 = m0 + wm * 64 + mt * 32 + 4 * kh;
       float* cbase = C + (int64_t)row0 * p.ldc + col;
-      if (epi == DVAE_EPI_STORE) {
+      if (epi == DVAE_EPI_STORE && p.c16) {       // bf16 output (bf16 mode: the consumer is another contraction)
+        __bf16* cb = (__bf16*)p.C + (int64_t)row0 * p.ldc + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          if (row0 + dr < p.M) cb[(int64_t)dr * p.ldc] = (__bf16)act_apply(acc[mt][nt][r] + bias_v, act);
+        }
+      } else if (epi == DVAE_EPI_STORE) {
         if (act == DVAE_ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -574,7 +593,14 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 // conv forward with BatchNorm statistics (k-contiguous operands, 128-row tiles, unsplit, plain store)
 void launch_bns(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, int mode) {
 #define BNS_LAUNCH(NTW_, BK_, MODE_) hipLaunchKernelGGL((gemm_f32_kernel<true, true, NTW_, BK_, 2, MODE_, true>), grid, dim3(256), 0, s, p)
-  if (mode == DVAE_MODE_BF16) { if (narrow) BNS_LAUNCH(1, 32, 1); else BNS_LAUNCH(2, 32, 1); }
+  if (mode == DVAE_MODE_BF16) {
+#define BNS16(NTW_, A16_, B16_) hipLaunchKernelGGL((gemm_f32_kernel<true, true, NTW_, 32, 2, 1, true, A16_, B16_>), grid, dim3(256), 0, s, p)
+#define BNS16_N(A16_, B16_) do { if (narrow) BNS16(1, A16_, B16_); else BNS16(2, A16_, B16_); } while (0)
+    if (p.a16 && p.b16) BNS16_N(true, true); else if (p.a16) BNS16_N(true, false); else if (p.b16) BNS16_N(false, true);
+    else BNS16_N(false, false);
+#undef BNS16_N
+#undef BNS16
+  }
   else if (mode == DVAE_MODE_F32X3) { if (narrow) BNS_LAUNCH(1, 16, 2); else BNS_LAUNCH(2, 16, 2); }
   else if (bk == 32) { if (narrow) BNS_LAUNCH(1, 32, 0); else BNS_LAUNCH(2, 32, 0); }
   else { if (narrow) BNS_LAUNCH(1, 16, 0); else BNS_LAUNCH(2, 16, 0); }
@@ -583,9 +609,13 @@ void launch_bns(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int 
 
 template <bool AK, bool BKC>
 void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, bool big, int mode) {
-  if (mode == DVAE_MODE_BF16) {   // bf16 operands, fp32 accumulation
-    if (narrow) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 1, 32, 2, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, 2, 32, 2, 1>), grid, dim3(256), 0, s, p);
+  if (mode == DVAE_MODE_BF16) {   // bf16 operands (rounded while staged, or already bf16 in memory), fp32 accumulation
+#define BF16K(NTW_, A16_, B16_) hipLaunchKernelGGL((gemm_f32_kernel<AK, BKC, NTW_, 32, 2, 1, false, A16_, B16_>), grid, dim3(256), 0, s, p)
+#define BF16K_N(A16_, B16_) do { if (narrow) BF16K(1, A16_, B16_); else BF16K(2, A16_, B16_); } while (0)
+    if (p.a16 && p.b16) BF16K_N(true, true); else if (p.a16) BF16K_N(true, false); else if (p.b16) BF16K_N(false, true);
+    else BF16K_N(false, false);
+#undef BF16K_N
+#undef BF16K
     return;
   }
   if (mode == DVAE_MODE_F32X3) {  // fp32 operands split into 3 bf16 terms, 6 bf16 MFMAs per product
@@ -608,7 +638,18 @@ void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, 
 }
 
 int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
+  // operand storage flags ride in the upper bits of `mode`
+  p.a16 = (mode >= 0 && (mode & DVAE_MODE_A_BF16)) ? 1 : 0;
+  p.b16 = (mode >= 0 && (mode & DVAE_MODE_B_BF16)) ? 1 : 0;
+  p.c16 = (mode >= 0 && (mode & DVAE_MODE_C_BF16)) ? 1 : 0;
+  if (mode >= 0) mode &= 0xff;
   if (mode == DVAE_MODE_DEFAULT) mode = g_dvae_compute_mode;
+  if ((p.a16 || p.b16 || p.c16) && mode != DVAE_MODE_BF16) return DVAE_EINVAL;
+  if (p.c16 && (p.epi != DVAE_EPI_STORE || p.split_k > 1)) return DVAE_EINVAL;
+  // a bf16 operand moves 8 elements per 16-byte load
+  if (p.a16 && ((p.lda & 7) || (a_kc ? (p.K & 7) : (p.M & 7)))) return DVAE_EINVAL;
+  if (p.b16 && ((p.ldb & 7) || (b_kc ? (p.K & 7) : (p.N & 7)))) return DVAE_EINVAL;
+  if (p.b16 && p.tap_mode == 1 && (p.b_tap_stride & 7)) return DVAE_EINVAL;
   if (mode != DVAE_MODE_F32 && mode != DVAE_MODE_BF16 && mode != DVAE_MODE_F32X3) return DVAE_EINVAL;
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return DVAE_EINVAL;
   if (!p.A || !p.B || !p.C) return DVAE_EINVAL;
@@ -689,7 +730,7 @@ DVAE_API int dvae_set_compute_mode(int mode) {
 }
 DVAE_API int dvae_get_compute_mode(void) { return g_dvae_compute_mode; }
 
-DVAE_API int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+DVAE_API int dvae_gemm_f32(const void* A, const void* B, void* C, const float* bias, int M, int N, int K,
                            int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int act,
                            int epi, int split_k, int mode, void* stream) {
   GemmParams p{};
@@ -703,7 +744,7 @@ DVAE_API int dvae_gemm_f32(const float* A, const float* B, float* C, const float
 
 // conv forward that also leaves the BatchNorm partial statistics of Y in `bn_ws` (>= dvae_bn_ws_bytes(R, Cout, G) bytes,
 // the layout dvae_bn_stats_finalize reads); G = statistics groups (1 or 2)
-DVAE_API int dvae_conv5_fwd_stats(const float* X, const float* Wp, const float* bias, float* Y, int R, int N, int Cin,
+DVAE_API int dvae_conv5_fwd_stats(const void* X, const void* Wp, const float* bias, float* Y, int R, int N, int Cin,
                                   int Cout, int mode, int G, void* bn_ws, void* stream) {
   if (!bn_ws || G < 1 || G > 2 || N < 1 || (N % G) || (R % N)) return DVAE_EINVAL;
   GemmParams p{};
@@ -717,7 +758,7 @@ DVAE_API int dvae_conv5_fwd_stats(const float* X, const float* Wp, const float* 
   return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 
-DVAE_API int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y, int R, int N,
+DVAE_API int dvae_conv5_fwd(const void* X, const void* Wp, const float* bias, float* Y, int R, int N,
                             int Cin, int Cout, int mode, void* stream) {
   GemmParams p{};
   p.A = X; p.B = Wp; p.C = Y; p.bias = bias;
@@ -730,7 +771,7 @@ DVAE_API int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, 
 }
 
 // data gradient: the weights packed as Wpt[5][Cin][Cout] (dvae_conv_pack_wt): both operands k-contiguous
-DVAE_API int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout,
+DVAE_API int dvae_conv5_dgrad_t(const void* dY, const void* Wpt, float* dX, int R, int N, int Cin, int Cout,
                                 int mode, void* stream) {
   GemmParams p{};
   p.A = dY; p.B = Wpt; p.C = dX; p.bias = nullptr;
@@ -742,7 +783,7 @@ DVAE_API int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, in
   return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 
-DVAE_API int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp, int R, int N, int Cin, int Cout,
+DVAE_API int dvae_conv5_wgrad(const void* dY, const void* X, float* dWp, int R, int N, int Cin, int Cout,
                               int split_k, int mode, void* stream) {
   GemmParams p{};
   p.A = dY; p.B = X; p.C = dWp; p.bias = nullptr;

@@ -135,6 +135,7 @@ def _tiles(m, n):
 
 # ----------------------------------------------------------------------------- compute mode
 MODE_F32, MODE_BF16, MODE_F32X3 = _lib.MODE_F32, _lib.MODE_BF16, _lib.MODE_F32X3
+A_BF16, B_BF16, C_BF16 = 0x100, 0x200, 0x400    # DVAE_MODE_A/B/C_BF16: operand / result stored as bf16 (bf16 mode)
 DEFAULT_COMPUTE_DTYPE = _lib.DEFAULT_COMPUTE_DTYPE      # "fp32x3" (DVAE_COMPUTE_DTYPE in the environment overrides)
 _MODE_NAMES = {MODE_F32: "fp32", MODE_BF16: "bf16", MODE_F32X3: "fp32x3"}
 

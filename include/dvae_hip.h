@@ -56,6 +56,13 @@ int dvae_version(void);
  *                  v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 — BASELINE configs[2], [4] ("bf16 compute");
  * DVAE_MODE_DEFAULT  whatever dvae_set_compute_mode() last set (process-wide default, initially DVAE_MODE_F32).
  * Everything that is not a contraction (BatchNorm, gates, losses, Adam, master weights) is fp32 in every mode. */
+/* bf16 mode only, OR-ed into `mode`: the operand / the result is bf16 IN MEMORY (written so by its producer), not fp32
+ * rounded on the way into the matrix cores.  A = first operand (activations), B = second (weights), C = result (plain
+ * store epilogue only).  Leading dimensions stay in elements; a bf16 operand needs them (and its contiguous extent)
+ * to be multiples of 8. */
+#define DVAE_MODE_A_BF16 0x100
+#define DVAE_MODE_B_BF16 0x200
+#define DVAE_MODE_C_BF16 0x400
 #define DVAE_MODE_DEFAULT (-1)
 #define DVAE_MODE_F32 0
 #define DVAE_MODE_BF16 1
@@ -70,11 +77,11 @@ int dvae_last_hip_error(void);
  *   a_kcontig = 1: A stored [M][K] (lda = row stride)   0: stored [K][M]
  *   b_kcontig = 1: B stored [N][K] (torch Linear/LSTM weight layout)   0: stored [K][N]
  * lda, ldb must be multiples of 4 and A, B 16-byte aligned; K % 4 == 0 if an operand is k-contiguous,
- * M % 4 == 0 (N % 4 == 0) if A (B) is not.
+ * M % 4 == 0 (N % 4 == 0) if A (B) is not.  A, B, C are fp32 unless `mode` carries DVAE_MODE_A/B/C_BF16 (bf16 mode).
  * Replaces: nn.Linear forward/backward (disentangled_vae.py:165-171,194,211-213,232-233,247),
  * LSTM input projections and weight gradients (:163,172,193).
  */
-int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
+int dvae_gemm_f32(const void* A, const void* B, void* C, const float* bias,
                   int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                   int a_kcontig, int b_kcontig, int act, int epi, int split_k, int mode, void* stream);
 
@@ -85,21 +92,21 @@ int dvae_gemm_f32(const float* A, const float* B, float* C, const float* bias,
  * wgrad: dWp[tap][Cout][Cin] += sum_r dY[r, co] * X[r+(tap-2)*N, ci]     (atomic accumulation)
  * R = T*N rows, N = segments per frame.
  */
-int dvae_conv5_fwd(const float* X, const float* Wp, const float* bias, float* Y,
+int dvae_conv5_fwd(const void* X, const void* Wp, const float* bias, float* Y,
                    int R, int N, int Cin, int Cout, int mode, void* stream);
 /* conv forward that also leaves the per-column partial sums of Y that a training-mode BatchNorm over G statistics groups
  * needs in bn_ws (>= dvae_bn_ws_bytes(R, Cout, G) bytes): follow with dvae_bn_stats_finalize instead of
  * dvae_bn_stats_fwd — one pass over Y less per block (disentangled_vae.py:151-162: conv -> BatchNorm -> ReLU) */
-int dvae_conv5_fwd_stats(const float* X, const float* Wp, const float* bias, float* Y,
+int dvae_conv5_fwd_stats(const void* X, const void* Wp, const float* bias, float* Y,
                          int R, int N, int Cin, int Cout, int mode, int G, void* bn_ws, void* stream);
-int dvae_conv5_wgrad(const float* dY, const float* X, float* dWp,
+int dvae_conv5_wgrad(const void* dY, const void* X, float* dWp,
                      int R, int N, int Cin, int Cout, int split_k, int mode, void* stream);
 /* W[Cout][Cin][5] (torch layout, state_dict contract) -> Wp[5][Cout][Cin] */
 int dvae_conv_pack_w(const float* W, float* Wp, int Cout, int Cin, void* stream);
 /* Wpt[5][Cin][Cout]: the transposed pack; with it the data gradient reads BOTH operands k-contiguously (the faster
  * ds_read_b128 fragment path of the contraction kernel). */
 int dvae_conv_pack_wt(const float* W, float* Wpt, int Cout, int Cin, void* stream);
-int dvae_conv5_dgrad_t(const float* dY, const float* Wpt, float* dX, int R, int N, int Cin, int Cout, int mode,
+int dvae_conv5_dgrad_t(const void* dY, const void* Wpt, float* dX, int R, int N, int Cin, int Cout, int mode,
                        void* stream);
 /* dW[Cout][Cin][5] += dWp[5][Cout][Cin] */
 int dvae_conv_unpack_add_w(const float* dWp, float* dW, int Cout, int Cin, void* stream);

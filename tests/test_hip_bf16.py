@@ -382,3 +382,29 @@ def test_model_bf16_t512_losses_against_bf16_oracle(ops):
     got = w.step(x1.cuda(), x2.cuda(), None, train=True)
     for i in range(8):
         assert abs(got[i] - ref[i]) <= 2e-3 * max(1.0, abs(ref[i])), (i, got[i], ref[i])
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 80), (1024, 512, 520)])
+def test_gemm_bf16_operands_in_memory(ops, a_kc, b_kc, M, N, K):
+    """DVAE_MODE_A/B/C_BF16: operands that are ALREADY bf16 in memory (activations written as bf16 by their producers,
+    bf16 weight copies) give bit-identical results to fp32 operands holding the same (bf16-exact) values — only the
+    staging differs — and a bf16 result is the rounded fp32 result."""
+    a, b = r16(rnd(M, K, seed=1)), r16(rnd(K, N, seed=2))
+    A = a if a_kc else a.t().contiguous()
+    B = b.t().contiguous() if b_kc else b
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+
+    def run(A_, B_, flags, cdt=torch.float32):
+        C_ = torch.empty(M, N, device="cuda", dtype=cdt)
+        ops.gemm(A_.cuda().contiguous(), B_.cuda().contiguous(), C_, None, M, N, K, lda, ldb, N, a_kc, b_kc, 0, ops.EPI_STORE, 1,
+                 ops.MODE_BF16 | flags)
+        return C_
+
+    base = run(A, B, 0)
+    close(base, a.double() @ b.double(), name="fp32-stored operands")
+    for flags, A_, B_ in ((ops.A_BF16, A.bfloat16(), B), (ops.B_BF16, A, B.bfloat16()),
+                          (ops.A_BF16 | ops.B_BF16, A.bfloat16(), B.bfloat16())):
+        assert torch.equal(run(A_, B_, flags), base), hex(flags)
+    c16 = run(A.bfloat16(), B.bfloat16(), ops.A_BF16 | ops.B_BF16 | ops.C_BF16, torch.bfloat16)
+    assert torch.equal(c16, base.bfloat16())
