@@ -39,7 +39,7 @@ class LossDesc(C.Structure):
                 ("mse_cof", f32), ("kl_cof", f32)]
 
 
-REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2 = 0, 1, 2, 3
+REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2, REPACK_CAST_BF16 = 0, 1, 2, 3, 4
 
 # DVAE_MODE_* of include/dvae_hip.h
 MODE_F32, MODE_BF16, MODE_F32X3 = 0, 1, 2

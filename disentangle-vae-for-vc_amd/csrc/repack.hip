@@ -10,13 +10,15 @@
 //              planes for v_mfma_f32_16x16x32_bf16, per pack as the descriptor says);
 //   TRANSPOSE  W[R][C] -> W^T[C][R]   (W_ih^T for the input-projection data gradients, W_hh^T for the H = 64 and
 //              generic backward recurrences);
-//   ADD2       b_ih + b_hh (nn.LSTM keeps two bias vectors; the kernels add one).
+//   ADD2       b_ih + b_hh (nn.LSTM keeps two bias vectors; the kernels add one);
+//   CAST_BF16  bf16 copies of weights (bf16 compute mode: the B operands of the forward / data-gradient contractions);
+//              CONV_T and TRANSPOSE can write bf16 as well.
 // All of it is HBM-bound byte shuffling: 32x32 tiles through LDS so both sides move whole 128-B lines.
 #include "common.h"
 
 namespace {
 
-constexpr int MAX_DESC = 56;   // the table travels as a kernel argument (<= 4 KB)
+constexpr int MAX_DESC = 72;   // the table travels as a kernel argument (3 756 bytes <= 4 KB)
 
 struct Desc {
   int kind, d0, d1, d2;
@@ -31,9 +33,9 @@ struct Table {
   Desc d[MAX_DESC];
 };
 
-// [R][C] -> [C][R], tiles lb, lb + nb, ...
+// [R][C] -> [C][R], tiles lb, lb + nb, ...; out16: the destination is bf16
 __device__ __forceinline__ void transpose_tiles(const float* __restrict__ in, float* __restrict__ out, int R, int C,
-                                                int lb, int nb, float (*tile)[33]) {
+                                                int lb, int nb, float (*tile)[33], bool out16 = false) {
   const int tc = (C + 31) / 32, tr = (R + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int t = lb; t < tc * tr; t += nb) {
@@ -46,7 +48,10 @@ __device__ __forceinline__ void transpose_tiles(const float* __restrict__ in, fl
     __syncthreads();
     for (int k = ty; k < 32; k += 8) {
       const int c = c0 + k, r = r0 + tx;
-      if (c < C && r < R) out[(int64_t)c * R + r] = tile[tx][k];
+      if (c < C && r < R) {
+        if (out16) reinterpret_cast<__bf16*>(out)[(int64_t)c * R + r] = (__bf16)tile[tx][k];
+        else out[(int64_t)c * R + r] = tile[tx][k];
+      }
     }
   }
 }
@@ -176,7 +181,10 @@ __global__ __launch_bounds__(256) void repack_all_kernel(const Table t) {
   switch (d.kind) {
     case DVAE_REPACK_CONV_T: {   // d0 = Cout, d1 = Cin: five [Cout][Cin] -> [Cin][Cout] transposes
       const int64_t cc = (int64_t)d.d0 * d.d1;
-      for (int tap = 0; tap < 5; ++tap) transpose_tiles(d.src + tap * cc, d.dst + tap * cc, d.d0, d.d1, lb, nb, tile);
+      for (int tap = 0; tap < 5; ++tap) {
+        float* dst = d.d2 ? (float*)((__bf16*)d.dst + tap * cc) : d.dst + tap * cc;
+        transpose_tiles(d.src + tap * cc, dst, d.d0, d.d1, lb, nb, tile, d.d2 != 0);
+      }
       break;
     }
     case DVAE_REPACK_LSTM_PACK: {   // d0 = H, d1 / d2 = DVAE_MODE_* of the forward / backward pack
@@ -193,9 +201,15 @@ __global__ __launch_bounds__(256) void repack_all_kernel(const Table t) {
       }
       break;
     }
-    case DVAE_REPACK_TRANSPOSE:   // d0 = R, d1 = C
-      transpose_tiles(d.src, d.dst, d.d0, d.d1, lb, nb, tile);
+    case DVAE_REPACK_TRANSPOSE:   // d0 = R, d1 = C, d2: bf16 destination
+      transpose_tiles(d.src, d.dst, d.d0, d.d1, lb, nb, tile, d.d2 != 0);
       break;
+    case DVAE_REPACK_CAST_BF16: { // n = d0 * d1 elements (d1 >= 1), a multiple of 4
+      const int64_t n4 = ((int64_t)d.d0 * d.d1) >> 2;
+      for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256)
+        reinterpret_cast<bf16x4*>(d.dst)[i] = __builtin_convertvector(reinterpret_cast<const f32x4*>(d.src)[i], bf16x4);
+      break;
+    }
     case DVAE_REPACK_ADD2:        // d0 = n
       for (int i = lb * 256 + threadIdx.x; i < d.d0; i += nb * 256) d.dst[i] = d.src[i] + d.src2[i];
       break;
@@ -262,6 +276,10 @@ DVAE_API int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* strea
       case DVAE_REPACK_ADD2:
         if (!s.src || !s.src2 || !s.dst || s.d0 < 1) return DVAE_EINVAL;
         elems = s.d0;
+        break;
+      case DVAE_REPACK_CAST_BF16:
+        if (!s.src || !s.dst || s.d0 < 1 || s.d1 < 1 || (((int64_t)s.d0 * s.d1) & 3)) return DVAE_EINVAL;
+        elems = (int64_t)s.d0 * s.d1;
         break;
       default:
         return DVAE_EINVAL;

@@ -15,14 +15,15 @@ parameter has moved (FlatAdam re-homes parameters into its flat buffer after the
 from __future__ import annotations
 
 from collections import namedtuple
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional  # noqa: F401
 
 import torch
 
 from . import _lib
 from ._lib import check, lib, stream
 
-LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b")
+# w_ih_t: W_ih^T (fp32, or bf16 in the bf16 compute mode); w_ih16: bf16 copy of W_ih (bf16 mode only, else None)
+LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b w_ih16", defaults=(None,))
 
 
 def lstm_pack_modes(mode: int, H: int):
@@ -78,10 +79,13 @@ def lstm_local(w_ih, w_hh, b_ih, b_hh, mode: int) -> LstmDerived:
 
 
 class DerivedWeights:
-    def __init__(self, convs: Dict[str, torch.nn.Parameter], lstms: Dict[str, tuple]):
+    def __init__(self, convs: Dict[str, torch.nn.Parameter], lstms: Dict[str, tuple],
+                 casts: Optional[Dict[str, torch.nn.Parameter]] = None):
         """convs: name -> packed conv weight parameter that needs a data gradient; lstms: name -> (w_ih, w_hh, b_ih,
-        b_hh) of one (layer, direction)."""
-        self._convs, self._lstms = convs, lstms
+        b_hh) of one (layer, direction); casts: name -> weight (conv packs, Linear weights) whose bf16 copy is the B
+        operand of a contraction in the bf16 compute mode."""
+        self._convs, self._lstms, self._casts = convs, lstms, dict(casts or {})
+        self.w16: Dict[str, torch.Tensor] = {}
         self._sig = None
         self._descs = None
         self.wpt: Dict[str, torch.Tensor] = {}
@@ -90,27 +94,38 @@ class DerivedWeights:
 
     def _signature(self):
         return tuple(p.data_ptr() for p in self._convs.values()) + \
-            tuple(p.data_ptr() for ps in self._lstms.values() for p in ps)
+            tuple(p.data_ptr() for ps in self._lstms.values() for p in ps) + \
+            tuple(p.data_ptr() for p in self._casts.values())
 
     def _build(self, mode):
+        """(Re)build buffers and the descriptor table for compute mode `mode`.  In the bf16 mode the weight operands of
+        the forward / data-gradient contractions are bf16 COPIES (half the bytes, no conversion in the kernels)."""
         descs = []
+        b16 = mode == _lib.MODE_BF16
+        wdt = torch.bfloat16 if b16 else torch.float32
+        self.wpt, self.lstm, self.w16 = {}, {}, {}
         for name, wp in self._convs.items():
             _, cout, cin = wp.shape
-            if name not in self.wpt:
-                self.wpt[name] = torch.empty((5, cin, cout), device=wp.device, dtype=torch.float32)
-            descs.append(_desc(_lib.REPACK_CONV_T, wp, self.wpt[name], cout, cin))
+            self.wpt[name] = torch.empty((5, cin, cout), device=wp.device, dtype=wdt)
+            descs.append(_desc(_lib.REPACK_CONV_T, wp, self.wpt[name], cout, cin, d2=int(b16)))
+        if b16:
+            for name, w in self._casts.items():
+                self.w16[name] = torch.empty(w.shape, device=w.device, dtype=torch.bfloat16)
+                descs.append(_desc(_lib.REPACK_CAST_BF16, w, self.w16[name], w.numel(), 1))
         for name, (w_ih, w_hh, b_ih, b_hh) in self._lstms.items():
             H, In = w_hh.shape[1], w_ih.shape[1]
-            if name not in self.lstm:
-                f = dict(device=w_hh.device, dtype=torch.float32)
-                big = H % 512 == 0
-                self.lstm[name] = LstmDerived(torch.empty(4 * H, **f), torch.empty((In, 4 * H), **f),
-                                              torch.empty((H, 4 * H), **f),
-                                              torch.empty(6 * H * H, **f) if big else None,     # up to 3 bf16 planes
-                                              torch.empty(6 * H * H, **f) if big else None)
-            d = self.lstm[name]
+            f = dict(device=w_hh.device, dtype=torch.float32)
+            big = H % 512 == 0
+            d = LstmDerived(torch.empty(4 * H, **f), torch.empty((In, 4 * H), device=w_hh.device, dtype=wdt),
+                            torch.empty((H, 4 * H), **f),
+                            torch.empty(6 * H * H, **f) if big else None,     # up to 3 bf16 planes
+                            torch.empty(6 * H * H, **f) if big else None,
+                            torch.empty((4 * H, In), device=w_hh.device, dtype=torch.bfloat16) if b16 else None)
+            self.lstm[name] = d
             descs.append(_desc(_lib.REPACK_ADD2, b_ih, d.bias, 4 * H, src2=b_hh))
-            descs.append(_desc(_lib.REPACK_TRANSPOSE, w_ih, d.w_ih_t, 4 * H, In))
+            descs.append(_desc(_lib.REPACK_TRANSPOSE, w_ih, d.w_ih_t, 4 * H, In, d2=int(b16)))
+            if b16:
+                descs.append(_desc(_lib.REPACK_CAST_BF16, w_ih, d.w_ih16, 4 * H * In, 1))
             descs.append(_desc(_lib.REPACK_TRANSPOSE, w_hh, d.w_hh_t, 4 * H, H))
             if d.pack_f is not None:
                 mf, mb = lstm_pack_modes(mode, H)

@@ -163,7 +163,7 @@ class Postnet(nn.Module):
         ch = [N_MEL, 512, 512, 512, 512, N_MEL]
         self.convolutions = nn.ModuleList(_conv_bn(ch[i], ch[i + 1], keyed=True) for i in range(5))
 
-    def forward_frames(self, y, n_seg, groups, residual=None, wpt=None):
+    def forward_frames(self, y, n_seg, groups, residual=None, wpt=None, w16=None):
         """y [T*N, 80] frame-major -> postnet(y) (+ residual fused into the last BatchNorm apply).
         `wpt`: the five transposed conv packs from the owning model's DerivedWeights (None: made in backward)."""
         last = len(self.convolutions) - 1
@@ -172,7 +172,7 @@ class Postnet(nn.Module):
             y = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
                                   ACT_TANH if i < last else ACT_NONE, self.training,
-                                  None if wpt is None else wpt[i])
+                                  None if wpt is None else wpt[i], None if w16 is None else w16[i])
         return y
 
     def forward(self, x):
@@ -278,12 +278,22 @@ class DisentangledVAE(nn.Module):
                 convs[f"dec_modules.{i}"] = _conv_of(self.dec_modules[i]).weight
             for i in range(5):
                 convs[f"postnet.{i}"] = _conv_of(self.postnet.convolutions[i]).weight
-            self._derived = DerivedWeights(convs, dict(self._lstm_names()))
+            casts = {f"enc_modules.{i}": _conv_of(self.enc_modules[i]).weight for i in range(3)}
+            casts.update({f"dec_modules.{i}": _conv_of(self.dec_modules[i]).weight for i in range(3)})
+            casts.update({f"postnet.{i}": _conv_of(self.postnet.convolutions[i]).weight for i in range(5)})
+            for n in ("enc_linear", "style", "content", "dec_linear2"):
+                casts[n] = getattr(self, n).linear_layer.weight
+            casts["dec_pre_linear1"], casts["dec_pre_linear2"] = self.dec_pre_linear1.weight, self.dec_pre_linear2.weight
+            self._derived = DerivedWeights(convs, dict(self._lstm_names()), casts)
         self._derived.refresh(ops.current_mode())
         return self._derived
 
     def _wpt(self, name):
         return self._derived.wpt.get(name) if self._derived is not None else None
+
+    def _w16(self, name):
+        """bf16 copy of a weight (bf16 compute mode; None otherwise)."""
+        return self._derived.w16.get(name) if self._derived is not None else None
 
     def _lstm_der(self, mname, l, bidirectional):
         d = self._derived.lstm
@@ -312,19 +322,20 @@ class DisentangledVAE(nn.Module):
             c, bn = _conv_of(blk), blk[1]
             x = ConvBnActFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
-                                  self._wpt(f"enc_modules.{i}"))
+                                  self._wpt(f"enc_modules.{i}"), self._w16(f"enc_modules.{i}"))
         h = self._lstm("enc_lstm", x, T, n_seg)                          # [T*N, 128]
         d2 = 2 * self.dim_neck
         flat = Permute102Fn.apply(h, T, n_seg, d2, (n_seg, T * d2))     # index t*128+d as in :209
         lin = self.enc_linear.linear_layer
-        feat = LinearFn.apply(flat, lin.weight, lin.bias, ACT_RELU)
+        feat = LinearFn.apply(flat, lin.weight, lin.bias, ACT_RELU, self._w16("enc_linear"))
         st, ct = self.style.linear_layer, self.content.linear_layer
-        return LinearFn.apply(feat, st.weight, st.bias, ACT_NONE), LinearFn.apply(feat, ct.weight, ct.bias, ACT_NONE)
+        return (LinearFn.apply(feat, st.weight, st.bias, ACT_NONE, self._w16("style")),
+                LinearFn.apply(feat, ct.weight, ct.bias, ACT_NONE, self._w16("content")))
 
     def _decode_frames(self, z, T, n_seg, groups):
         p1, p2 = self.dec_pre_linear1, self.dec_pre_linear2
-        h = LinearFn.apply(z, p1.weight, p1.bias, ACT_NONE)
-        h = LinearFn.apply(h, p2.weight, p2.bias, ACT_NONE)              # [N, T*128]  (no activation, :232-233)
+        h = LinearFn.apply(z, p1.weight, p1.bias, ACT_NONE, self._w16("dec_pre_linear1"))
+        h = LinearFn.apply(h, p2.weight, p2.bias, ACT_NONE, self._w16("dec_pre_linear2"))   # [N, T*128]  (no activation, :232-233)
         d2 = 2 * self.dim_neck
         h = Permute102Fn.apply(h, n_seg, T, d2, (T * n_seg, d2))
         h = self._lstm("dec_lstm1", h, T, n_seg)
@@ -332,10 +343,10 @@ class DisentangledVAE(nn.Module):
             c, bn = blk[0], blk[1]
             h = ConvBnActFn.apply(h, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
-                                  self._wpt(f"dec_modules.{i}"))
+                                  self._wpt(f"dec_modules.{i}"), self._w16(f"dec_modules.{i}"))
         h = self._lstm("dec_lstm2", h, T, n_seg)
         lin = self.dec_linear2.linear_layer
-        return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE)        # [T*N, 80]
+        return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE, self._w16("dec_linear2"))   # [T*N, 80]
 
     # ---- reference API
     def encode(self, x):
@@ -395,7 +406,8 @@ class DisentangledVAE(nn.Module):
         z, q_mu, q_lv, s_mu, s_lv = LatentFn.apply(style, content, eps_c, eps_s, Bh, S, Cn)
         y = self._decode_frames(z, T, N, 2)                              # [T*N, 80]
         y_hat = self.postnet.forward_frames(y, N, 2, residual=y,         # y + postnet(y)
-                                            wpt=[self._wpt(f"postnet.{i}") for i in range(5)])
+                                            wpt=[self._wpt(f"postnet.{i}") for i in range(5)],
+                                            w16=[self._w16(f"postnet.{i}") for i in range(5)])
         rec = FramesToMelFn.apply(y, N, N_MEL, T)
         rec_hat = FramesToMelFn.apply(y_hat, N, N_MEL, T)
         return (rec[:Bh], rec[Bh:], rec_hat[:Bh], rec_hat[Bh:], q_mu[:Bh], q_lv[:Bh], q_mu[Bh:], q_lv[Bh:],

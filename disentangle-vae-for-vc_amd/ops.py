@@ -162,6 +162,17 @@ def get_compute_dtype() -> str:
     return _MODE_NAMES[current_mode()]
 
 
+def _mflags(mode, A=None, B=None, Cout=None):
+    """`mode` plus the storage flags of bf16 tensors (bf16 compute mode only; anything else must be fp32)."""
+    m = int(mode)
+    bf = lambda t: t is not None and not isinstance(t, int) and t.dtype == torch.bfloat16
+    if bf(A) or bf(B) or bf(Cout):
+        if (m & 0xff) != MODE_BF16:
+            raise ValueError("bf16 tensors are operands of the bf16 compute mode only")
+        m |= (A_BF16 if bf(A) else 0) | (B_BF16 if bf(B) else 0) | (C_BF16 if bf(Cout) else 0)
+    return m
+
+
 def _mode(mode):
     if mode is None:
         return current_mode()
@@ -187,12 +198,13 @@ def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi
     """A, B, Cout, bias: tensors or raw device addresses (ints)."""
     a = lambda t: t if (t is None or isinstance(t, int)) else t.data_ptr()
     check(lib().dvae_gemm_f32(a(A), a(B), a(Cout), a(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),
-                              act, epi, split_k, _mode(mode), stream()), "dvae_gemm_f32")
+                              act, epi, split_k, _mflags(_mode(mode), A, B, Cout), stream()), "dvae_gemm_f32")
 
 
-def linear_fwd(x, w, b, act=ACT_NONE, mode=None):
-    """y[M,Nout] = act(x[M,K] @ w[Nout,K]^T + b)"""
+def linear_fwd(x, w, b, act=ACT_NONE, mode=None, w16=None):
+    """y[M,Nout] = act(x[M,K] @ w[Nout,K]^T + b).  w16: bf16 copy of w (bf16 compute mode), used as the operand."""
     M, K = x.shape
+    w = w if w16 is None else w16
     Nout = w.shape[0]
     y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
     sk = _split_k(_tiles(M, Nout), K)
@@ -206,8 +218,9 @@ def linear_fwd(x, w, b, act=ACT_NONE, mode=None):
     return y
 
 
-def linear_dgrad(dy, w, mode=None):
+def linear_dgrad(dy, w, mode=None, w16=None):
     """dx[M,K] = dy[M,Nout] @ w[Nout,K]"""
+    w = w if w16 is None else w16
     M, Nout = dy.shape
     K = w.shape[1]
     sk = _split_k(_tiles(M, K), Nout)
@@ -261,10 +274,11 @@ class LinearFn(torch.autograd.Function):
     """nn.Linear (+ optional ReLU): disentangled_vae.py:165-171,194 used at :211-213,232-233,247."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act):
+    def forward(ctx, x, weight, bias, act, w16=None):
         _ok(x, weight, bias)
         ctx.mode = current_mode()
-        y = linear_fwd(x, weight, bias, act, ctx.mode)
+        ctx.w16 = w16 if ctx.mode == MODE_BF16 else None      # bf16 copy of the weight (derived.DerivedWeights)
+        y = linear_fwd(x, weight, bias, act, ctx.mode, ctx.w16)
         ctx.save_for_backward(x, weight, bias, y if act != ACT_NONE else None)
         ctx.act = act
         return y
@@ -277,12 +291,12 @@ class LinearFn(torch.autograd.Function):
             du = torch.empty_like(dy)
             check(lib().dvae_act_bwd(ptr(dy), ptr(y), ptr(du), dy.numel(), ctx.act, stream()), "dvae_act_bwd")
             dy = du
-        dx = linear_dgrad(dy, weight, ctx.mode) if ctx.needs_input_grad[0] else None
+        dx = linear_dgrad(dy, weight, ctx.mode, ctx.w16) if ctx.needs_input_grad[0] else None
         with side_work(dy, x):
             linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode)
             colsum_add(dy, _grad_buf(bias))
         _ready(weight, bias)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- Conv1d(k5) + BatchNorm + act
@@ -295,7 +309,7 @@ class ConvBnActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, conv_wp, conv_b, bn_w, bn_b, running_mean, running_var, nbt, residual,
-                n_seg, groups, act, training, wpt=None):
+                n_seg, groups, act, training, wpt=None, w16=None):
         _ok(x, conv_wp, conv_b, bn_w, bn_b, residual)
         L = lib()
         R, Cin = x.shape
@@ -305,6 +319,8 @@ class ConvBnActFn(torch.autograd.Function):
         dev = x.device
         st = stream()
         mode = current_mode()
+        wop = w16 if (w16 is not None and mode == MODE_BF16) else conv_wp     # bf16 copy of the pack in the bf16 mode
+        fmode = _mflags(mode, None, wop)
         y = torch.empty((R, Cout), device=dev, dtype=torch.float32)
         if training:
             # the conv epilogue leaves the BatchNorm partial sums of y behind: no separate statistics pass over y
@@ -312,12 +328,12 @@ class ConvBnActFn(torch.autograd.Function):
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             rstd = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
-            check(L.dvae_conv5_fwd_stats(ptr(x), ptr(conv_wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, G, ptr(ws),
+            check(L.dvae_conv5_fwd_stats(ptr(x), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, G, ptr(ws),
                                          st), "dvae_conv5_fwd_stats")
             check(L.dvae_bn_stats_finalize(ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(ws),
                                            R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_finalize")
         else:
-            check(L.dvae_conv5_fwd(ptr(x), ptr(conv_wp), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, mode, st),
+            check(L.dvae_conv5_fwd(ptr(x), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, st),
                   "dvae_conv5_fwd")
             G = 1
             mean = running_mean.detach().reshape(1, Cout).contiguous()
@@ -356,7 +372,7 @@ class ConvBnActFn(torch.autograd.Function):
             if wpt is None:
                 from .derived import conv_wpt_local
                 wpt = conv_wpt_local(conv_wp)
-            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, mode, st),
+            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, _mflags(mode, None, wpt), st),
                   "dvae_conv5_dgrad_t")
         with side_work(dy, x):
             # the weight gradient goes straight into the (packed) gradient view: atomic split-K epilogue
@@ -366,7 +382,7 @@ class ConvBnActFn(torch.autograd.Function):
             colsum_add(dy, _grad_buf(conv_b))
         _ready(conv_wp, conv_b, bn_w, bn_b)
         dres = dz if has_res else None
-        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None, None)
+        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------- LSTM layer
@@ -407,7 +423,8 @@ class LstmLayerFn(torch.autograd.Function):
         gates, cells = [], []
         for d, (wi, wh, bi, bh) in enumerate(params):
             g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
-            gemm(x, wi, g, der[d].bias, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
+            gemm(x, wi if der[d].w_ih16 is None else der[d].w_ih16, g, der[d].bias, R, 4 * H, In, In, In, 4 * H, True, True,
+                 mode=mode)
             c = torch.empty((R, H), device=dev, dtype=torch.float32)
             gates.append(g)
             cells.append(c)
@@ -524,7 +541,8 @@ class LstmStack2Fn(torch.autograd.Function):
         g1, g2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
         c1, c2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
         h1, h2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
-        gemm(x, w_ih1, g1, der[0].bias, R, 4 * H, In, In, In, 4 * H, True, True, mode=mode)
+        gemm(x, w_ih1 if der[0].w_ih16 is None else der[0].w_ih16, g1, der[0].bias, R, 4 * H, In, In, In, 4 * H, True, True,
+             mode=mode)
         dirs = (_lib.LstmDir * 2)()
         for d, (g, wh, h, c) in enumerate(((g1, w_hh1, h1, c1), (g2, w_hh2, h2, c2))):
             dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed = ptr(g), ptr(wh), ptr(der[d].pack_f)
@@ -534,8 +552,8 @@ class LstmStack2Fn(torch.autograd.Function):
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
                 r0 = (c0 - Tc) * N
-                gemm(h1.data_ptr() + 4 * r0 * H, w_ih2, g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias,
-                     rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode)
+                gemm(h1.data_ptr() + 4 * r0 * H, w_ih2 if der[1].w_ih16 is None else der[1].w_ih16,
+                     g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias, rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode)
             check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
         ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
         ctx.der = der

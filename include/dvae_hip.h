@@ -175,13 +175,16 @@ int dvae_lstm_pack_w_x3(const float* w_hh, void* packed_fwd, void* packed_bwd, i
  *                                                              (either pointer may be null; DVAE_MODE_F32 / _BF16 /
  *                                                              _F32X3, the last two only where H % 512 == 0): see
  *                                                              dvae_lstm_pack_w / _bf16 / _x3
- *      TRANSPOSE src W[d0][d1]                              -> dst W^T[d1][d0]
+ *      TRANSPOSE src W[d0][d1]                              -> dst W^T[d1][d0]         (bf16 destination when d2 != 0;
+ *                                                                                       CONV_T likewise)
  *      ADD2      src, src2 [d0]                             -> dst = src + src2        (b_ih + b_hh)
- * `descs` is a HOST array of n <= 56 entries (copied into the launch); the device buffers are the caller's. */
+ *      CAST_BF16 src [d0*d1] fp32                           -> dst bf16, same layout   (bf16 mode: weight operands)
+ * `descs` is a HOST array of n <= 72 entries (copied into the launch); the device buffers are the caller's. */
 #define DVAE_REPACK_CONV_T 0
 #define DVAE_REPACK_LSTM_PACK 1
 #define DVAE_REPACK_TRANSPOSE 2
 #define DVAE_REPACK_ADD2 3
+#define DVAE_REPACK_CAST_BF16 4
 typedef struct {
   int kind, d0, d1, d2;
   const void* src;
