@@ -63,8 +63,8 @@ SIGNATURES = {
     "dvae_conv_unpack_add_w": (i32, [vp, vp, i32, i32, vp]),
     "dvae_bn_ws_bytes": (i64, [i32, i32, i32]),
     "dvae_bn_stats_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
-    "dvae_bn_apply_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
-    "dvae_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "dvae_bn_apply_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dvae_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_lstm_pack_w": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_x3": (i32, [vp, vp, vp, i32, vp]),
@@ -85,10 +85,10 @@ SIGNATURES = {
     "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
-    "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_frames_to_mel": (i32, [vp, vp, i32, i32, i32, vp]),
     "dvae_permute_102": (i32, [vp, vp, i32, i32, i32, vp]),
-    "dvae_colsum_add": (i32, [vp, vp, vp, i32, i32, i64, vp]),
+    "dvae_colsum_add": (i32, [vp, vp, vp, i32, i32, i64, i32, vp]),
     "dvae_transpose": (i32, [vp, vp, i32, i32, vp]),
     "dvae_act_fwd": (i32, [vp, i64, i32, vp]),
     "dvae_act_bwd": (i32, [vp, vp, vp, i64, i32, vp]),

@@ -17,9 +17,10 @@ __host__ __device__ inline int n_chunks(int R) { return (R + ROWS_PER_CHUNK - 1)
 
 // partial[chunk][g][c][2] (fp64): sum and sum of squares (MODE 0), or sum(dU) and sum(dU*yhat) (MODE 1)
 // 64 channel-quads x 4 row lanes per workgroup, 16-byte loads; fp64 accumulation per thread.
-template <int MODE>
+// ZB16: Z (the block's output, needed for the activation derivative) is stored as bf16 (bf16 compute mode)
+template <int MODE, bool ZB16 = false>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ Y, const float* __restrict__ dZ,
-                                                         const float* __restrict__ Z, const float* __restrict__ mean,
+                                                         const void* __restrict__ Z, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, double* __restrict__ part,
                                                          int R, int N, int C, int G, int act) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
       f32x4 dz = y, z = y;
       if (MODE == 1) {
         dz = *reinterpret_cast<const f32x4*>(dZ + (int64_t)r * C + c);
-        z = *reinterpret_cast<const f32x4*>(Z + (int64_t)r * C + c);
+        z = ld4<ZB16>(Z, ((int64_t)r * C + c) >> 2);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -141,10 +142,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
   if (rvar) rvar[c] = rv;
 }
 
+template <bool ZB16>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ Y, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ res,
-                                                       float* __restrict__ Z, int64_t total4, int N, int C, int G,
+                                                       void* __restrict__ Z, int64_t total4, int N, int C, int G,
                                                        int act) {
   const int c4n = C >> 2;
   const int per = N / G;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
       for (int k = 0; k < 4; ++k) z[k] += rr[k];
     }
-    *reinterpret_cast<f32x4*>(Z + i * 4) = z;
+    st4<ZB16>(Z, i, z);
   }
 }
 
@@ -189,11 +191,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   if (dbeta) dbeta[c] += (float)tb;
 }
 
+template <bool ZB16, bool DYB16>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dZ, const float* __restrict__ Y,
-                                                           const float* __restrict__ Z, const float* __restrict__ mean,
+                                                           const void* __restrict__ Z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ s12, float* dY,
+                                                           const float* __restrict__ s12, void* dY,
                                                            int64_t total4, int R, int N, int C, int G, int act) {
   const int c4n = C >> 2;
   const int per = N / G;
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dZ, cons
     const int g = (int)(r % N) / per;
     const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(Y + i * 4);
-    const f32x4 z = *reinterpret_cast<const f32x4*>(Z + i * 4);
+    const f32x4 z = ld4<ZB16>(Z, i);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + c);
     const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + g * C + c);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dZ, cons
       const float s1 = s12[(g * C + c + k) * 2], s2 = s12[(g * C + c + k) * 2 + 1];
       o[k] = ga[k] * rs[k] * (du - s1 * inv_cnt - yh * s2 * inv_cnt);
     }
-    *reinterpret_cast<f32x4*>(dY + i * 4) = o;
+    st4<DYB16>(dY, i, o);
   }
 }
 
@@ -241,7 +244,7 @@ DVAE_API int dvae_bn_stats_fwd(const float* Y, float* mean, float* rstd, float* 
   const int ch = n_chunks(R);
   double* part = (double*)ws;
   dim3 grid((C + 255) / 256, ch);
-  hipLaunchKernelGGL((bn_partial_kernel<0>), grid, dim3(256), 0, s, Y, nullptr, nullptr, nullptr, nullptr, part, R, N,
+  hipLaunchKernelGGL((bn_partial_kernel<0, false>), grid, dim3(256), 0, s, Y, nullptr, nullptr, nullptr, nullptr, part, R, N,
                      C, G, 0);
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, mean, rstd,
                      running_mean, running_var, num_batches_tracked, ch, R, N, C, G, eps, momentum);
@@ -259,31 +262,38 @@ DVAE_API int dvae_bn_stats_finalize(float* mean, float* rstd, float* running_mea
 }
 
 DVAE_API int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, const float* residual, float* Z, int R, int N, int C, int G, int act,
-                               void* stream) {
+                               const float* beta, const float* residual, void* Z, int R, int N, int C, int G, int act,
+                               int z_bf16, void* stream) {
   if (check(R, N, C, G) || !Y || !mean || !rstd || !gamma || !beta || !Z) return DVAE_EINVAL;
   const int64_t total4 = (int64_t)R * C / 4;
   const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, mean, rstd, gamma, beta,
-                     residual, Z, total4, N, C, G, act);
+  if (z_bf16)
+    hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, mean, rstd, gamma, beta,
+                       residual, Z, total4, N, C, G, act);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, mean, rstd, gamma, beta,
+                       residual, Z, total4, N, C, G, act);
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const float* mean, const float* rstd,
-                         const float* gamma, float* dY, float* dgamma, float* dbeta, void* ws, int R, int N, int C,
-                         int G, int act, void* stream) {
+DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const void* Z, const float* mean, const float* rstd,
+                         const float* gamma, void* dY, float* dgamma, float* dbeta, void* ws, int R, int N, int C,
+                         int G, int act, int dtypes, void* stream) {
+  const bool zb = dtypes & 1, dyb = dtypes & 2;
   if (check(R, N, C, G) || !dZ || !Y || !Z || !mean || !rstd || !gamma || !dY || !ws) return DVAE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ch = n_chunks(R);
   double* part = (double*)ws;
   float* s12 = (float*)((char*)ws + (int64_t)ch * G * C * 2 * sizeof(double));
   dim3 grid((C + 255) / 256, ch);
-  hipLaunchKernelGGL((bn_partial_kernel<1>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
+  if (zb) hipLaunchKernelGGL((bn_partial_kernel<1, true>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
+  else hipLaunchKernelGGL((bn_partial_kernel<1, false>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, s12, dgamma, dbeta, ch, C,
                      G);
   const int64_t total4 = (int64_t)R * C / 4;
   const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, dZ, Y, Z, mean, rstd, gamma, s12, dY, total4,
-                     R, N, C, G, act);
+#define BWDA(ZB_, DYB_) hipLaunchKernelGGL((bn_bwd_apply_kernel<ZB_, DYB_>), dim3(blocks), dim3(256), 0, s, dZ, Y, Z, mean, rstd, gamma, s12, dY, total4, R, N, C, G, act)
+  if (zb && dyb) BWDA(true, true); else if (zb) BWDA(true, false); else if (dyb) BWDA(false, true); else BWDA(false, false);
+#undef BWDA
   return dvae_check_launch();
 }

@@ -45,6 +45,18 @@ struct ProfScope {
   }
 };
 
+// four consecutive elements of an fp32 or bf16 tensor as f32x4 (element index 4*i4)
+template <bool B16>
+__device__ __forceinline__ f32x4 ld4(const void* p, int64_t i4) {
+  if constexpr (B16) return __builtin_convertvector(reinterpret_cast<const bf16x4*>(p)[i4], f32x4);
+  else return reinterpret_cast<const f32x4*>(p)[i4];
+}
+template <bool B16>
+__device__ __forceinline__ void st4(void* p, int64_t i4, const f32x4& v) {
+  if constexpr (B16) reinterpret_cast<bf16x4*>(p)[i4] = __builtin_convertvector(v, bf16x4);
+  else reinterpret_cast<f32x4*>(p)[i4] = v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

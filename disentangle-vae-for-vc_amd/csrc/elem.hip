@@ -1,5 +1,6 @@
 // The HBM-bound and tiny kernels of the step: reparameterise + latent assembly, KL and L1 reductions
 // (wavefront shuffle reductions, fp64 only for the final cross-workgroup sums), flat Adam, layout changes.
+#include <type_traits>
 #include "common.h"
 
 int g_dvae_last_hip_error = 0;
@@ -341,9 +342,12 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 
 // ------------------------------------------------------------------ layout
 // X[t][g*Bh+b][c] = x_g[b][c][t] ; tile-transpose through LDS over (c,t) per segment
+template <bool OB16>
 __global__ __launch_bounds__(256) void mel_to_frames_kernel(const float* __restrict__ x1,
-                                                            const float* __restrict__ x2, float* __restrict__ X,
+                                                            const float* __restrict__ x2, void* __restrict__ Xv,
                                                             int Bh, int C, int T, int N) {
+  using out_t = typename std::conditional<OB16, __bf16, float>::type;
+  out_t* __restrict__ X = reinterpret_cast<out_t*>(Xv);
   __shared__ float tile[32][33];
   const int n = blockIdx.z;
   const float* __restrict__ src = (n < Bh ? x1 + (int64_t)n * C * T : x2 + (int64_t)(n - Bh) * C * T);
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256) void mel_to_frames_kernel(const float* __restr
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
     const int t = t0 + k, c = c0 + tx;
-    if (t < T && c < C) X[((int64_t)t * N + n) * C + c] = tile[tx][k];
+    if (t < T && c < C) X[((int64_t)t * N + n) * C + c] = (out_t)tile[tx][k];
   }
 }
 
@@ -393,8 +397,11 @@ __global__ __launch_bounds__(256) void permute_102_kernel(const float* __restric
 
 constexpr int CS_ROWS = 128;
 // out[c] += sum_r X[r][c]: 64 column-quads x 4 row lanes per workgroup, 16-byte loads (1 KiB per wave per row)
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, float* __restrict__ o1,
+template <bool XB16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ Xv, float* __restrict__ o1,
                                                      float* __restrict__ o2, int R, int C, int64_t ld, int rows_pb) {
+  using elem_t = typename std::conditional<XB16, __bf16, float>::type;
+  const elem_t* __restrict__ X = reinterpret_cast<const elem_t*>(Xv);
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cl) * 4;
   const int r0 = blockIdx.y * rows_pb, r1 = min(R, r0 + rows_pb);
@@ -402,20 +409,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   if (c + 3 < C) {
     // eight independent 16-byte loads in flight per thread (one dependent load per iteration left the kernel at
     // ~2 TB/s: too little memory-level parallelism for HBM latency)
-    const float* __restrict__ px = X + (int64_t)(r0 + rl) * ld + c;
+    const elem_t* __restrict__ px = X + (int64_t)(r0 + rl) * ld + c;
     const int n = (r1 - r0 - rl + 3) >> 2;          // rows of this thread
     int i = 0;
     for (; i + 8 <= n; i += 8) {
       f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(px + (int64_t)(i + u) * 4 * ld);
+      for (int u = 0; u < 8; ++u) v[u] = ld4<XB16>(px + (int64_t)(i + u) * 4 * ld, 0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; i < n; ++i) s += *reinterpret_cast<const f32x4*>(px + (int64_t)i * 4 * ld);
+    for (; i < n; ++i) s += ld4<XB16>(px + (int64_t)i * 4 * ld, 0);
   } else if (c < C) {
     for (int r = r0 + rl; r < r1; r += 4)
-      for (int k = 0; k < 4 && c + k < C; ++k) s[k] += X[(int64_t)r * ld + c + k];
+      for (int k = 0; k < 4 && c + k < C; ++k) s[k] += (float)X[(int64_t)r * ld + c + k];
   }
   __shared__ f32x4 red[4][64];
   red[rl][cl] = s;
@@ -743,11 +750,13 @@ DVAE_API int dvae_mul_div(const float* a, const float* b, const float* c, float*
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_mel_to_frames(const float* x1, const float* x2, float* X, int Bh, int C, int T, void* stream) {
+DVAE_API int dvae_mel_to_frames(const float* x1, const float* x2, void* X, int Bh, int C, int T, int out_bf16,
+                                void* stream) {
   if (!x1 || !X || Bh < 1 || C < 1 || T < 1) return DVAE_EINVAL;
   const int N = x2 ? 2 * Bh : Bh;
   dim3 grid((T + 31) / 32, (C + 31) / 32, N);
-  hipLaunchKernelGGL(mel_to_frames_kernel, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, X, Bh, C, T, N);
+  if (out_bf16) hipLaunchKernelGGL(mel_to_frames_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, X, Bh, C, T, N);
+  else hipLaunchKernelGGL(mel_to_frames_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x1, x2, X, Bh, C, T, N);
   return dvae_check_launch();
 }
 
@@ -765,15 +774,16 @@ DVAE_API int dvae_permute_102(const float* in, float* out, int A, int B, int C, 
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_colsum_add(const float* X, float* out1, float* out2, int R, int C, int64_t ld, void* stream) {
+DVAE_API int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int C, int64_t ld, int x_bf16, void* stream) {
   if (!X || !out1 || R < 1 || C < 1) return DVAE_EINVAL;
-  if ((ld & 3) || (((uintptr_t)X) & 15)) return DVAE_EINVAL;
+  if ((ld & 3) || (((uintptr_t)X) & (x_bf16 ? 7 : 15))) return DVAE_EINVAL;
   // (fewer rows per workgroup for narrow matrices -- more workgroups -- was tried: the extra same-address atomics
   // cost more than the parallelism gains, 0.43 -> 1.0 ms per step)
   const int cb = (C + 255) / 256;
   const int rows_pb = CS_ROWS;
   dim3 grid(cb, (R + rows_pb - 1) / rows_pb);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
+  if (x_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
   return dvae_check_launch();
 }
 

@@ -167,12 +167,13 @@ class Postnet(nn.Module):
         """y [T*N, 80] frame-major -> postnet(y) (+ residual fused into the last BatchNorm apply).
         `wpt`: the five transposed conv packs from the owning model's DerivedWeights (None: made in backward)."""
         last = len(self.convolutions) - 1
+        y16 = None            # bf16 compute mode: the data of y when y is a placeholder (ops.ConvBnActFn)
         for i, blk in enumerate(self.convolutions):
             c, bn = _conv_of(blk), blk[1]
-            y = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
-                                  ACT_TANH if i < last else ACT_NONE, self.training,
-                                  None if wpt is None else wpt[i], None if w16 is None else w16[i])
+            y, y16 = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
+                                       ACT_TANH if i < last else ACT_NONE, self.training,
+                                       None if wpt is None else wpt[i], None if w16 is None else w16[i], y16, True)
         return y
 
     def forward(self, x):
@@ -307,23 +308,26 @@ class DisentangledVAE(nn.Module):
         if x.shape[1] != N_MEL or x.shape[2] != self.n_frames:
             raise ValueError(f"expected [B, {N_MEL}, {self.n_frames}] mel segments, got {tuple(x.shape)}")
 
-    def _lstm(self, mname, x, T, n_seg):
+    def _lstm(self, mname, x, T, n_seg, x16=None):
+        """x16: bf16 data of x when x is a placeholder (output of a conv block in the bf16 compute mode)."""
         mod = getattr(self, mname)
         if LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
             # two stacked layers of equal width share their frame launches (ops.LstmStack2Fn)
             der = self._lstm_der(mname, 0, False) + self._lstm_der(mname, 1, False)
-            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4], der)
+            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4], der, x16)
         for l in range(mod.num_layers):
-            x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l), self._lstm_der(mname, l, mod.bidirectional))
+            x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l), self._lstm_der(mname, l, mod.bidirectional),
+                                  x16 if l == 0 else None)
         return x
 
     def _encode_frames(self, x, T, n_seg, groups):
+        x16 = None
         for i, blk in enumerate(self.enc_modules):
             c, bn = _conv_of(blk), blk[1]
-            x = ConvBnActFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
-                                  self._wpt(f"enc_modules.{i}"), self._w16(f"enc_modules.{i}"))
-        h = self._lstm("enc_lstm", x, T, n_seg)                          # [T*N, 128]
+            x, x16 = ConvBnActFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
+                                       self._wpt(f"enc_modules.{i}"), self._w16(f"enc_modules.{i}"), x16, True)
+        h = self._lstm("enc_lstm", x, T, n_seg, x16)                     # [T*N, 128]
         d2 = 2 * self.dim_neck
         flat = Permute102Fn.apply(h, T, n_seg, d2, (n_seg, T * d2))     # index t*128+d as in :209
         lin = self.enc_linear.linear_layer
@@ -339,12 +343,13 @@ class DisentangledVAE(nn.Module):
         d2 = 2 * self.dim_neck
         h = Permute102Fn.apply(h, n_seg, T, d2, (T * n_seg, d2))
         h = self._lstm("dec_lstm1", h, T, n_seg)
+        h16 = None
         for i, blk in enumerate(self.dec_modules):
             c, bn = blk[0], blk[1]
-            h = ConvBnActFn.apply(h, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
-                                  self._wpt(f"dec_modules.{i}"), self._w16(f"dec_modules.{i}"))
-        h = self._lstm("dec_lstm2", h, T, n_seg)
+            h, h16 = ConvBnActFn.apply(h, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
+                                       self._wpt(f"dec_modules.{i}"), self._w16(f"dec_modules.{i}"), h16, True)
+        h = self._lstm("dec_lstm2", h, T, n_seg, h16)
         lin = self.dec_linear2.linear_layer
         return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE, self._w16("dec_linear2"))   # [T*N, 80]
 
@@ -400,7 +405,8 @@ class DisentangledVAE(nn.Module):
         Bh, _, T = x1.shape
         N = 2 * Bh
         S, Cn = self.speaker_size, self.latent_dim - self.speaker_size
-        x = mel_to_frames(x1.contiguous(), x2.contiguous())              # [T*N, 80]
+        # [T*N, 80]; bf16 in the bf16 compute mode (it only feeds the first conv)
+        x = mel_to_frames(x1.contiguous(), x2.contiguous(), dtype=ops.act_storage(ops.current_mode()))
         style, content = self._encode_frames(x, T, N, 2)
         eps_c, eps_s = self._eps(Bh, x1.device, train)
         z, q_mu, q_lv, s_mu, s_lv = LatentFn.apply(style, content, eps_c, eps_s, Bh, S, Cn)

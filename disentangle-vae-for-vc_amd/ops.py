@@ -89,13 +89,26 @@ def join_side():
         _side_dirty = False
 
 
-def _ok(*ts):
+def _ok(*ts, act16=()):
+    """Every tensor fp32, contiguous, on the GPU; the tensors listed in `act16` (activations that are contraction
+    operands) may also be bf16 — the storage their producers use in the bf16 compute mode."""
     for t in ts:
         if t is None:
             continue
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        dts = (torch.float32, torch.bfloat16) if any(t is a for a in act16) else (torch.float32,)
+        if not (t.is_cuda and t.dtype in dts and t.is_contiguous()):
             raise ValueError(f"HIP op needs contiguous fp32 GPU tensors, got {t.device} {t.dtype} "
                              f"contiguous={t.is_contiguous()}")
+
+
+def _b16(t) -> int:
+    return int(t is not None and t.dtype == torch.bfloat16)
+
+
+def act_storage(mode) -> torch.dtype:
+    """Storage of the activations that only feed contractions (conv-block outputs, BatchNorm data gradients): bf16 in
+    the bf16 compute mode — written so by their producers — fp32 otherwise."""
+    return torch.bfloat16 if int(mode) == MODE_BF16 else torch.float32
 
 
 def _grad_buf(p: torch.Tensor) -> torch.Tensor:
@@ -249,16 +262,16 @@ def colsum_add(x, out1, out2=None, rows=None, cols=None, ld=None):
     rows = x.shape[0] if rows is None else rows
     cols = x.shape[1] if cols is None else cols
     ld = x.shape[1] if ld is None else ld
-    check(lib().dvae_colsum_add(ptr(x), ptr(out1), ptr(out2), rows, cols, ld, stream()), "dvae_colsum_add")
+    check(lib().dvae_colsum_add(ptr(x), ptr(out1), ptr(out2), rows, cols, ld, _b16(x), stream()), "dvae_colsum_add")
 
 
-def mel_to_frames(x1, x2=None):
-    """[Bh,C,T] (x2 optional) -> frame-major [T*N, C]"""
+def mel_to_frames(x1, x2=None, dtype=torch.float32):
+    """[Bh,C,T] (x2 optional) -> frame-major [T*N, C] (fp32, or bf16 when it only feeds a contraction in the bf16 mode)"""
     _ok(x1, x2)
     Bh, Cc, T = x1.shape
     N = Bh * (2 if x2 is not None else 1)
-    X = torch.empty((T * N, Cc), device=x1.device, dtype=torch.float32)
-    check(lib().dvae_mel_to_frames(ptr(x1), ptr(x2), ptr(X), Bh, Cc, T, stream()), "dvae_mel_to_frames")
+    X = torch.empty((T * N, Cc), device=x1.device, dtype=dtype)
+    check(lib().dvae_mel_to_frames(ptr(x1), ptr(x2), ptr(X), Bh, Cc, T, _b16(X), stream()), "dvae_mel_to_frames")
     return X
 
 
@@ -300,17 +313,28 @@ class LinearFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- Conv1d(k5) + BatchNorm + act
+def _placeholder(R, C, dev):
+    """fp32 [R, C] tensor with one element of storage: what autograd sees of an activation whose DATA lives in a bf16
+    tensor travelling beside it (bf16 compute mode).  Gradients flow through the placeholder in fp32 — autograd would
+    otherwise cast every gradient of a bf16 tensor to bf16 — nobody reads its values."""
+    return torch.empty_strided((R, C), (0, 0), device=dev, dtype=torch.float32)
+
+
 class ConvBnActFn(torch.autograd.Function):
     """act(BatchNorm1d_train(Conv1d_k5_p2(x))) [+ residual] on frame-major rows.
     Reference blocks: encoder :151-162/:201-202, decoder :175-191/:242-243, Postnet :43-87.
     `conv_wp` is the conv weight in the PACKED layout [5][Cout][Cin] (the layout the parameter lives in, see
     model/disentangled_vae._Conv1dParams); its gradient is accumulated in the same layout.  `wpt` is the transposed
-    pack [5][Cin][Cout] for the data gradient (derived.DerivedWeights) or None (computed in backward if needed)."""
+    pack [5][Cin][Cout] for the data gradient (derived.DerivedWeights) or None (computed in backward if needed).
+    bf16 compute mode: `w16` / a bf16 `wpt` are bf16 copies of the weights; `x16` is the bf16 DATA of the input when `x`
+    is a placeholder (see _placeholder); with `emit16` the op returns (z, z16): z16 the bf16 output written by the
+    BatchNorm-apply kernel (the storage its consumers — contractions — read), z its fp32 placeholder for autograd; in the
+    other modes, with a residual, or in eval mode z is a real fp32 tensor and z16 is None."""
 
     @staticmethod
     def forward(ctx, x, conv_wp, conv_b, bn_w, bn_b, running_mean, running_var, nbt, residual,
-                n_seg, groups, act, training, wpt=None, w16=None):
-        _ok(x, conv_wp, conv_b, bn_w, bn_b, residual)
+                n_seg, groups, act, training, wpt=None, w16=None, x16=None, emit16=False):
+        _ok(x, conv_wp, conv_b, bn_w, bn_b, residual, act16=(x,))
         L = lib()
         R, Cin = x.shape
         if conv_wp.dim() != 3 or conv_wp.shape[0] != 5 or conv_wp.shape[2] != Cin:
@@ -319,8 +343,9 @@ class ConvBnActFn(torch.autograd.Function):
         dev = x.device
         st = stream()
         mode = current_mode()
+        xa = x if x16 is None else x16                                        # what the kernels read
         wop = w16 if (w16 is not None and mode == MODE_BF16) else conv_wp     # bf16 copy of the pack in the bf16 mode
-        fmode = _mflags(mode, None, wop)
+        fmode = _mflags(mode, xa, wop)
         y = torch.empty((R, Cout), device=dev, dtype=torch.float32)
         if training:
             # the conv epilogue leaves the BatchNorm partial sums of y behind: no separate statistics pass over y
@@ -328,42 +353,49 @@ class ConvBnActFn(torch.autograd.Function):
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             rstd = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
-            check(L.dvae_conv5_fwd_stats(ptr(x), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, G, ptr(ws),
+            check(L.dvae_conv5_fwd_stats(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, G, ptr(ws),
                                          st), "dvae_conv5_fwd_stats")
             check(L.dvae_bn_stats_finalize(ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(ws),
                                            R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_finalize")
         else:
-            check(L.dvae_conv5_fwd(ptr(x), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, st),
+            check(L.dvae_conv5_fwd(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, st),
                   "dvae_conv5_fwd")
             G = 1
             mean = running_mean.detach().reshape(1, Cout).contiguous()
             rstd = torch.rsqrt(running_var.detach() + BN_EPS).reshape(1, Cout).contiguous()
-        z = torch.empty((R, Cout), device=dev, dtype=torch.float32)
-        check(L.dvae_bn_apply_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(bn_w), ptr(bn_b), ptr(residual), ptr(z),
-                                  R, n_seg, Cout, G, act, st), "dvae_bn_apply_fwd")
-        ctx.save_for_backward(x, y, z, mean, rstd, conv_wp, conv_b, bn_w, bn_b, wpt)
-        ctx.cfg = (n_seg, G, act, training, residual is not None, mode)
-        return z
+        as16 = bool(emit16) and mode == MODE_BF16 and training and residual is None
+        zd = torch.empty((R, Cout), device=dev, dtype=torch.bfloat16 if as16 else torch.float32)   # the data
+        check(L.dvae_bn_apply_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(bn_w), ptr(bn_b), ptr(residual), ptr(zd),
+                                  R, n_seg, Cout, G, act, _b16(zd), st), "dvae_bn_apply_fwd")
+        z = _placeholder(R, Cout, dev) if as16 else zd
+        ctx.save_for_backward(xa, y, zd, mean, rstd, conv_wp, conv_b, bn_w, bn_b, wpt)
+        ctx.cfg = (n_seg, G, act, training, residual is not None, mode, Cin)
+        ctx.n_out = 2 if emit16 else 1
+        if not emit16:
+            return z
+        if as16:
+            ctx.mark_non_differentiable(zd)
+        return z, (zd if as16 else None)
 
     @staticmethod
-    def backward(ctx, dz):
-        x, y, z, mean, rstd, conv_wp, conv_b, bn_w, bn_b, wpt = ctx.saved_tensors
-        n_seg, G, act, training, has_res, mode = ctx.cfg
+    def backward(ctx, dz, *_):
+        xa, y, z, mean, rstd, conv_wp, conv_b, bn_w, bn_b, wpt = ctx.saved_tensors
+        n_seg, G, act, training, has_res, mode, Cin = ctx.cfg
         if not training:
             raise RuntimeError("backward through eval-mode BatchNorm is not part of the training path")
         L = lib()
         st = stream()
         dz = dz.contiguous()
-        R, Cin = x.shape
+        R = y.shape[0]
         Cout = y.shape[1]
-        dev = x.device
+        dev = y.device
         if has_res and act != ACT_NONE:
             raise RuntimeError("residual is only supported with ACT_NONE")
         ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
-        dy = torch.empty_like(y)
+        dy = torch.empty((R, Cout), device=dev, dtype=act_storage(mode))     # operand of the data / weight gradient
         check(L.dvae_bn_bwd(ptr(dz), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(bn_w), ptr(dy),
-                            ptr(_grad_buf(bn_w)), ptr(_grad_buf(bn_b)), ptr(ws), R, n_seg, Cout, G, act, st),
-              "dvae_bn_bwd")
+                            ptr(_grad_buf(bn_w)), ptr(_grad_buf(bn_b)), ptr(ws), R, n_seg, Cout, G, act,
+                            _b16(z) | (_b16(dy) << 1), st), "dvae_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)
@@ -372,17 +404,17 @@ class ConvBnActFn(torch.autograd.Function):
             if wpt is None:
                 from .derived import conv_wpt_local
                 wpt = conv_wpt_local(conv_wp)
-            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, _mflags(mode, None, wpt), st),
+            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, _mflags(mode, dy, wpt), st),
                   "dvae_conv5_dgrad_t")
-        with side_work(dy, x):
+        with side_work(dy, xa):
             # the weight gradient goes straight into the (packed) gradient view: atomic split-K epilogue
             sk = _split_k(5 * _tiles(Cout, Cin), R)
-            check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(_grad_buf(conv_wp)), R, n_seg, Cin, Cout, sk, mode, stream()),
-                  "dvae_conv5_wgrad")
+            check(L.dvae_conv5_wgrad(ptr(dy), ptr(xa), ptr(_grad_buf(conv_wp)), R, n_seg, Cin, Cout, sk,
+                                     _mflags(mode, dy, xa), stream()), "dvae_conv5_wgrad")
             colsum_add(dy, _grad_buf(conv_b))
         _ready(conv_wp, conv_b, bn_w, bn_b)
         dres = dz if has_res else None
-        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None, None, None)
+        return (dx, None, None, None, None, None, None, None, dres, None, None, None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------- LSTM layer
@@ -401,8 +433,9 @@ class LstmLayerFn(torch.autograd.Function):
     `derived`: list of derived.LstmDerived, one per direction (or None)."""
 
     @staticmethod
-    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, derived=None):
-        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
+    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, derived=None, x16=None):
+        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, act16=(x,))
+        x = x if x16 is None else x16                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
         L = lib()
         st = stream()
         dev = x.device
@@ -500,7 +533,7 @@ class LstmLayerFn(torch.autograd.Function):
         for (wi, wh, bi, bh) in params:
             _ready(wi, wh, bi, bh)
         del keep
-        return (dx,) + (None,) * 11
+        return (dx,) + (None,) * 12
 
 
 class LstmStack2Fn(torch.autograd.Function):
@@ -527,8 +560,9 @@ class LstmStack2Fn(torch.autograd.Function):
         return layers == 2 and not bidirectional and H % 512 == 0 and Tc > 0 and T % Tc == 0 and T // Tc >= 2
 
     @staticmethod
-    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, derived=None):
-        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
+    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, derived=None, x16=None):
+        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, act16=(x,))
+        x = x if x16 is None else x16                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
         L, st, dev = lib(), stream(), x.device
         R, In = x.shape
         H = w_hh1.shape[1]
@@ -603,7 +637,7 @@ class LstmStack2Fn(torch.autograd.Function):
         _ready(w_ih2, w_hh2, b_ih2, b_hh2)
         _ready(w_ih1, w_hh1, b_ih1, b_hh1)
         del dcs
-        return (dx,) + (None,) * 11
+        return (dx,) + (None,) * 12
 
 
 # ----------------------------------------------------------------------------- layout

@@ -129,11 +129,13 @@ int dvae_bn_stats_finalize(float* mean, float* rstd, float* running_mean, float*
                            int64_t* num_batches_tracked, const void* ws, int R, int N, int C, int G,
                            float eps, float momentum, void* stream);
 int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* rstd, const float* gamma,
-                      const float* beta, const float* residual, float* Z,
-                      int R, int N, int C, int G, int act, void* stream);
-int dvae_bn_bwd(const float* dZ, const float* Y, const float* Z, const float* mean, const float* rstd,
-                const float* gamma, float* dY, float* dgamma, float* dbeta, void* ws,
-                int R, int N, int C, int G, int act, void* stream);
+                      const float* beta, const float* residual, void* Z,
+                      int R, int N, int C, int G, int act, int z_bf16, void* stream);
+/* dtypes: bit 0 = Z is bf16, bit 1 = dY is written as bf16 (bf16 compute mode: Z and dY are contraction operands, their
+ * producers write them in the storage the consumers read; z_bf16 of dvae_bn_apply_fwd likewise) */
+int dvae_bn_bwd(const float* dZ, const float* Y, const void* Z, const float* mean, const float* rstd,
+                const float* gamma, void* dY, float* dgamma, float* dbeta, void* ws,
+                int R, int N, int C, int G, int act, int dtypes, void* stream);
 
 /* ---- LSTM recurrence, frame-major, one launch per frame (nn.LSTM at disentangled_vae.py:163,172,193) ----
  * One dvae_lstm_dir_t per direction (1 or 2).  Gate order i,f,g,o (torch).
@@ -264,13 +266,13 @@ int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, 
  * dvae_mel_to_frames: x1,x2 [Bh,C,T] (torch layout, variational_base_vae.py:81-82) -> X[T, 2*Bh, C]; x2 may be
  *   null (then N = Bh).  dvae_frames_to_mel is the inverse ([T,N,C] -> out[N,C,T]).
  * dvae_permute_102: in[A,B,C] -> out[B,A,C]
- * dvae_colsum_add: out1[c] += sum_r X[r,c] (and out2 if non-null); X row stride ld.
+ * dvae_colsum_add: out1[c] += sum_r X[r,c] (and out2 if non-null); X row stride ld; X fp32 or (x_bf16) bf16.
  * dvae_transpose: in[R,C] -> out[C,R]
  */
-int dvae_mel_to_frames(const float* x1, const float* x2, float* X, int Bh, int C, int T, void* stream);
+int dvae_mel_to_frames(const float* x1, const float* x2, void* X, int Bh, int C, int T, int out_bf16, void* stream);
 int dvae_frames_to_mel(const float* X, float* out, int N, int C, int T, void* stream);
 int dvae_permute_102(const float* in, float* out, int A, int B, int C, void* stream);
-int dvae_colsum_add(const float* X, float* out1, float* out2, int R, int C, int64_t ld, void* stream);
+int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int C, int64_t ld, int x_bf16, void* stream);
 int dvae_transpose(const float* in, float* out, int R, int C, void* stream);
 /* dU = dZ * act'(Z), Z = activation OUTPUT (ReLU after enc_linear, disentangled_vae.py:211); dU may alias dZ */
 /* Y = act(Y) in place (used after a split-K Linear) */

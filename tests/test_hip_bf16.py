@@ -408,3 +408,39 @@ def test_gemm_bf16_operands_in_memory(ops, a_kc, b_kc, M, N, K):
         assert torch.equal(run(A_, B_, flags), base), hex(flags)
     c16 = run(A.bfloat16(), B.bfloat16(), ops.A_BF16 | ops.B_BF16 | ops.C_BF16, torch.bfloat16)
     assert torch.equal(c16, base.bfloat16())
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_conv_block_bf16_storage(ops, act):
+    """ConvBnActFn with `emit16` (bf16 compute mode): the block's output is WRITTEN as bf16 by the BatchNorm-apply kernel
+    and travels beside an fp32 placeholder that carries the gradient; the data gradient it hands back, its weight and
+    BatchNorm gradients equal those of the fp32-storage path (whose operands the contraction kernels round to the same
+    bf16 values while staging them) — exactly for ReLU, to bf16 resolution of z for tanh (1 - z^2 uses the stored z)."""
+    from dvae_amd.ops import ConvBnActFn
+    N, T, Cin, Cout = 8, 32, 80, 512
+    R = N * T
+    x = dev(rnd(R, Cin, seed=1))
+    gz = dev(rnd(R, Cout, seed=7))
+    res = {}
+    for emit in (False, True):
+        P = lambda t: torch.nn.Parameter(dev(t))
+        cw, cb = P(rnd(5, Cout, Cin, seed=2) * 0.1), P(rnd(Cout, seed=3))
+        bw, bb = P(rnd(Cout, seed=4, lo=0.5, hi=1.5)), P(rnd(Cout, seed=5) * 0.1)
+        for p in (cw, cb, bw, bb):
+            p.grad = torch.zeros_like(p)
+        xin = x.clone().requires_grad_()
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        nbt = torch.zeros((), dtype=torch.long, device="cuda")
+        out = ConvBnActFn.apply(xin, cw, cb, bw, bb, rm, rv, nbt, None, N, 2, act, True, None, None, None, emit)
+        if emit:
+            z, z16 = out
+            assert z16.dtype == torch.bfloat16 and z.dtype == torch.float32 and z.stride() == (0, 0) and not z16.requires_grad
+        else:
+            z, z16 = out, None
+        z.backward(gz)
+        res[emit] = (z if z16 is None else z16, xin.grad.clone(), cw.grad.clone(), bw.grad.clone(), bb.grad.clone())
+    assert torch.equal(res[True][0], res[False][0].bfloat16())
+    tol = 0.0 if act == 1 else 2e-3
+    for k, name in ((1, "dx"), (2, "dW"), (3, "dgamma"), (4, "dbeta")):
+        a, b = res[True][k].double(), res[False][k].double()
+        assert float((a - b).abs().max()) <= max(tol, 2e-6) * float(b.abs().max()), name

@@ -408,7 +408,7 @@ def test_abi_rejects_bad_arguments_without_crashing():
     assert L.dvae_lstm_seq_fwd(None, 1, 4, 8, 64, 64, st) == -1
     assert L.dvae_adam_flat(p, p, p, p, 64, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0, st) == -1                  # step < 1
     assert L.dvae_l1_sum_fwd(p, p + 4, p, p, 64, 1.0, st) == -1                                        # misaligned
-    assert L.dvae_mel_to_frames(None, None, p, 4, 80, 64, st) == -1
+    assert L.dvae_mel_to_frames(None, None, p, 4, 80, 64, 0, st) == -1
     torch.cuda.synchronize()
     assert float(a.abs().sum()) == 0.0
 
