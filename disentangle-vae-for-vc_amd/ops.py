@@ -334,7 +334,7 @@ class ConvBnActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, conv_wp, conv_b, bn_w, bn_b, running_mean, running_var, nbt, residual,
                 n_seg, groups, act, training, wpt=None, w16=None, x16=None, emit16=False):
-        _ok(x, conv_wp, conv_b, bn_w, bn_b, residual, act16=(x,))
+        _ok(x if x16 is None else x16, conv_wp, conv_b, bn_w, bn_b, residual, act16=(x, x16))
         L = lib()
         R, Cin = x.shape
         if conv_wp.dim() != 3 or conv_wp.shape[0] != 5 or conv_wp.shape[2] != Cin:
@@ -434,8 +434,8 @@ class LstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, derived=None, x16=None):
-        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, act16=(x,))
-        x = x if x16 is None else x16                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
+        x = x if x16 is None else x16
+        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, act16=(x,))                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
         L = lib()
         st = stream()
         dev = x.device
@@ -561,8 +561,8 @@ class LstmStack2Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, derived=None, x16=None):
-        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, act16=(x,))
-        x = x if x16 is None else x16                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
+        x = x if x16 is None else x16
+        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, act16=(x,))                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
         L, st, dev = lib(), stream(), x.device
         R, In = x.shape
         H = w_hh1.shape[1]
