@@ -170,10 +170,12 @@ class Postnet(nn.Module):
         y16 = None            # bf16 compute mode: the data of y when y is a placeholder (ops.ConvBnActFn)
         for i, blk in enumerate(self.convolutions):
             c, bn = _conv_of(blk), blk[1]
-            y, y16 = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                       bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
-                                       ACT_TANH if i < last else ACT_NONE, self.training,
-                                       None if wpt is None else wpt[i], None if w16 is None else w16[i], y16, True)
+            out = ConvBnActFn.apply(y, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                    bn.num_batches_tracked, residual if i == last else None, n_seg, groups,
+                                    ACT_TANH if i < last else ACT_NONE, self.training,
+                                    None if wpt is None else wpt[i], None if w16 is None else w16[i], y16,
+                                    i < last)          # the last block's output leaves the conv stack: real fp32
+            y, y16 = out if i < last else (out, None)
         return y
 
     def forward(self, x):
