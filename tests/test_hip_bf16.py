@@ -440,7 +440,7 @@ def test_conv_block_bf16_storage(ops, act):
         z.backward(gz)
         res[emit] = (z if z16 is None else z16, xin.grad.clone(), cw.grad.clone(), bw.grad.clone(), bb.grad.clone())
     assert torch.equal(res[True][0], res[False][0].bfloat16())
-    tol = 0.0 if act == 1 else 2e-3
+    tol = 0.0 if act == 1 else 1e-2      # tanh: |d(1 - z^2)| <= 2 z^2 * 2^-9 for a bf16-stored z
     for k, name in ((1, "dx"), (2, "dW"), (3, "dgamma"), (4, "dbeta")):
         a, b = res[True][k].double(), res[False][k].double()
         assert float((a - b).abs().max()) <= max(tol, 2e-6) * float(b.abs().max()), name
