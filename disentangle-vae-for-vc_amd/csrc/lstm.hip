@@ -1084,14 +1084,7 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
         if (p.mt5 == 2) BWD5(2, 64, 1); else BWD5(1, 64, 1);
       } else if (a.pm == DVAE_MODE_F32X3) {
         if (p.mt5 == 2) BWD5(2, 32, 2); else BWD5(1, 64, 2);
-      }
-#ifdef DVAE_LSTM_BWD_MT1
-      else if (true) {
-        dim3 grid1(p.n_j * ((N + 15) / 16), 1, ndir);
-        hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, 0>), grid1, block5, 0, s, a, step, p.n_j, (N + 15) / 16);
-      }
-#endif
-      else if (p.mt5 == 2) BWD5(2, 64, 0);
+      } else if (p.mt5 == 2) BWD5(2, 64, 0);
       else BWD5(1, 64, 0);
 #undef BWD5
     }

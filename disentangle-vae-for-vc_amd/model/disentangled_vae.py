@@ -30,8 +30,8 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import (ACT_NONE, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, KlFn, L1SumFn, LatentFn, LinearFn,
-                   LstmLayerFn, LstmStack2Fn, Permute102Fn, mel_to_frames)
+from ..ops import (ACT_NONE, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, LatentFn, LinearFn, LstmLayerFn,
+                   LstmStack2Fn, Permute102Fn, mel_to_frames)
 from ..derived import DerivedWeights
 from ..optim import FlatAdam
 from .variational_base_vae import VariationalBaseModelVAE
