@@ -22,7 +22,7 @@ class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
                 ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_mode", i32),
-                ("step_shift", i32), ("pad_", i32)]
+                ("step_shift", i32), ("state_bf16", i32)]
 
 
 class RepackDesc(C.Structure):

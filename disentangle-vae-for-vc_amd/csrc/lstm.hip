@@ -71,6 +71,7 @@ struct StepArgs {
   StepDir d[2];
   int T, N, H;
   int64_t ldh;
+  int st16;  // bf16 mode: h_out (forward) / dgates (backward) are stored as bf16
   int pm;    // precision mode of the packed weights: 0 fp32 fragments, 1 bf16 (dvae_lstm_pack_w_bf16), 2 three bf16 planes (.._x3)
 };
 
@@ -365,8 +366,13 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const StepArgs a, in
 //      dvae_lstm_pack_w_x3), the h tile split the same way while it is staged (three LDS planes), six exact partial
 //      products per (tile, chunk).  The fp32 MFMA is 16x slower than the bf16 one: at 70 % efficiency it was 9.7 us of a
 //      14.5 us H = 1024 frame; the price is 1.5x the W_hh bytes.
-template <int MT, int KR, int PM = 0, int PF = 2>
+// S16 (bf16 mode only): the state h is STORED as bf16 — the epilogue writes it so, the next frame stages it without a
+// conversion, and the contractions that consume it (next layer's input projection, dW_hh) read 2 bytes per element.
+template <int MT, int KR, int PM = 0, int PF = 2, bool S16 = false>
 __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_fwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
+  static_assert(!S16 || PM == 1, "bf16 state storage: bf16 mode only");
+  using st_t = typename std::conditional<S16, bf16x4, f32x4>::type;     // four staged h values
+  using h_t = typename std::conditional<S16, __bf16, float>::type;
   constexpr int NW = 8;
   constexpr bool B16 = (PM != 0);
   constexpr int NP = (PM == 2) ? 3 : 1;            // bf16 planes per operand
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
   for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (step > 0) {
-    const float* __restrict__ hp = d.h_out + (int64_t)tp * N * a.ldh;
+    const h_t* __restrict__ hp = reinterpret_cast<const h_t*>(d.h_out) + (int64_t)tp * N * a.ldh;
     const int nr = H / KR / 2, last = nr - 1;           // rounds per k-half
     // packed W: [(gate*n_j + jb)][k-chunk][plane][lane][4 dwords]; this wave's chunks start at kh*(H/KC/2)
     const float* __restrict__ wpk = d.wp + (((int64_t)gate * n_j + jb) * (H / KC) + (int64_t)kh * (H / KC / 2)) * (256 * NP) + lane * 4;
@@ -427,23 +433,25 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
 #pragma unroll
       for (int s = 0; s < NS * NP; ++s) w[s] = *reinterpret_cast<const f32x4*>(wpk + (int64_t)(rd * NS * NP + s) * 256);
     };
-    auto loadA = [&](f32x4 (&st)[NST], int rd) {
+    auto loadA = [&](st_t (&st)[NST], int rd) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int n = min(m0 + srow + 16 * i, N - 1);
 #pragma unroll
         for (int q = 0; q < KR / 64; ++q)
-          st[i * (KR / 64) + q] = *reinterpret_cast<const f32x4*>(hp + (int64_t)n * a.ldh + (skh * nr + rd) * KR + 64 * q + 4 * sc4);
+          st[i * (KR / 64) + q] = *reinterpret_cast<const st_t*>(hp + (int64_t)n * a.ldh + (skh * nr + rd) * KR + 64 * q + 4 * sc4);
       }
     };
-    auto storeA = [&](int buf, f32x4 (&st)[NST]) {
+    auto storeA = [&](int buf, st_t (&st)[NST]) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int q = 0; q < KR / 64; ++q) {
           const int off = (srow + 16 * i) * LDA + 64 * q + 4 * sc4;
-          const f32x4 v = st[i * (KR / 64) + q];
-          if constexpr (PM == 2) {
+          const st_t v = st[i * (KR / 64) + q];
+          if constexpr (S16) {
+            *reinterpret_cast<bf16x4*>(&As[buf][skh][off]) = v;
+          } else if constexpr (PM == 2) {
             bf16x4 pl[3];
             split3_bf16(v, pl);
 #pragma unroll
@@ -489,7 +497,8 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
       }
     };
     // PF register sets (W fragments + h rows of PF rounds) in flight, see the backward kernel; PF divides nr
-    f32x4 wS[PF][NS * NP], sS[PF][NST];
+    f32x4 wS[PF][NS * NP];
+    st_t sS[PF][NST];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       loadA(sS[u], min(u, last));
@@ -532,7 +541,7 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
     ST_S(&g[2 * H], gg);
     ST_S(&g[3 * H], go);
     ST_S(&d.c_all[((int64_t)t * N + en[e]) * H + ej[e]], c);
-    d.h_out[((int64_t)t * N + en[e]) * a.ldh + ej[e]] = go * gate_tanh(c);
+    reinterpret_cast<h_t*>(d.h_out)[((int64_t)t * N + en[e]) * a.ldh + ej[e]] = (h_t)(go * gate_tanh(c));
   }
 }
 
@@ -545,8 +554,13 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
 // the dominant traffic of this kernel) and turns two stacked H = 1024 layers into ONE resident round of 256 workgroups
 // instead of two — and measured 24.8 us per layer-frame against 18.1 (each wave's serial chain doubles; nothing overlaps
 // it at one workgroup per CU).  Kept as a parameter, dispatched with NU = 1.
-template <int MT, int KR, int PM = 0, int NU = 1>
+// S16 (bf16 mode only): the gate gradients dG are STORED as bf16 (written so by the epilogue, staged without conversion,
+// read as bf16 by the dx / dW contractions and the bias column sums)
+template <int MT, int KR, int PM = 0, int NU = 1, bool S16 = false>
 __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gstep, int n_j, int n_m) {
+  static_assert(!S16 || PM == 1, "bf16 gate-gradient storage: bf16 mode only");
+  using st_t = typename std::conditional<S16, bf16x4, f32x4>::type;
+  using g_t = typename std::conditional<S16, __bf16, float>::type;
   constexpr int NW = 8;
   constexpr bool B16 = (PM != 0);
   constexpr int NP = (PM == 2) ? 3 : 1;
@@ -616,26 +630,28 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
     const float* __restrict__ bpk = d.wp + (((int64_t)jb * NU * 4 + quarter) * (H / KC) + (int64_t)part * (H / KC / 2)) * (256 * NP) + lane * 4;
     const int64_t bpk_u = (int64_t)4 * (H / KC) * (256 * NP);      // from one 16-unit block to the next
     const int lrow = lane / LPR, lc4 = lane % LPR;
-    const float* arow[NRI];
+    const g_t* arow[NRI];
 #pragma unroll
     for (int i = 0; i < NRI; ++i) {
       const int n = min(m0 + lrow + RPI * i, N - 1);
-      arow[i] = d.dgates + ((int64_t)tn * N + n) * H4 + koff + 4 * lc4;
+      arow[i] = reinterpret_cast<const g_t*>(d.dgates) + ((int64_t)tn * N + n) * H4 + koff + 4 * lc4;
     }
     const int nr = H / 2 / KR, last = nr - 1;
-    auto loadA = [&](f32x4 (&st)[NRI][NQ], int rd) {
+    auto loadA = [&](st_t (&st)[NRI][NQ], int rd) {
 #pragma unroll
       for (int i = 0; i < NRI; ++i)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) st[i][q] = *reinterpret_cast<const f32x4*>(arow[i] + rd * KR + KRW * q);
+        for (int q = 0; q < NQ; ++q) st[i][q] = *reinterpret_cast<const st_t*>(arow[i] + rd * KR + KRW * q);
     };
-    auto storeA = [&](int buf, f32x4 (&st)[NRI][NQ]) {
+    auto storeA = [&](int buf, st_t (&st)[NRI][NQ]) {
 #pragma unroll
       for (int i = 0; i < NRI; ++i)
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
           lds_t* dst = stg + buf * (NP * PL) + (lrow + RPI * i) * LDA + KRW * q + 4 * lc4;
-          if constexpr (PM == 2) {
+          if constexpr (S16) {
+            *reinterpret_cast<bf16x4*>(dst) = st[i][q];
+          } else if constexpr (PM == 2) {
             bf16x4 pl[3];
             split3_bf16(st[i][q], pl);
 #pragma unroll
@@ -694,7 +710,8 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
     // Measured at H = 1024: PF = 4 is SLOWER than 2 (20.4 vs 18.0 us per frame: more loads in flight only deepen the
     // queues), so the frame kernels are throughput-, not latency-bound; see DESIGN.md.
     constexpr int PF = DVAE_LSTM_PF;
-    f32x4 bS[PF][NU][NS * NP], sS[PF][NRI][NQ];
+    f32x4 bS[PF][NU][NS * NP];
+    st_t sS[PF][NRI][NQ];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       loadA(sS[u], min(u, last));
@@ -736,11 +753,11 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
     const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
     const float tc = gate_tanh(cc[e]);
     const float dc = dcar[e] + dh * go * (1.f - tc * tc);
-    float* o = d.dgates + ((int64_t)t * N + en[e]) * 4 * H + ej[e];
-    o[0] = dc * gg * gi * (1.f - gi);
-    o[H] = dc * cp[e] * gf * (1.f - gf);
-    o[2 * H] = dc * gi * (1.f - gg * gg);
-    o[3 * H] = dh * tc * go * (1.f - go);
+    g_t* o = reinterpret_cast<g_t*>(d.dgates) + ((int64_t)t * N + en[e]) * 4 * H + ej[e];
+    o[0] = (g_t)(dc * gg * gi * (1.f - gi));
+    o[H] = (g_t)(dc * cp[e] * gf * (1.f - gf));
+    o[2 * H] = (g_t)(dc * gi * (1.f - gg * gg));
+    o[3 * H] = (g_t)(dh * tc * go * (1.f - go));
     d.dc[(int64_t)en[e] * H + ej[e]] = dc * gf;
   }
 }
@@ -979,6 +996,10 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
   for (int i = 0; i < ndir; ++i)
     if (dirs[i].packed_mode != a.pm || (a.pm && !dirs[i].w_packed)) return DVAE_EINVAL;
   if (a.pm && (H % 512)) return DVAE_EINVAL;          // bf16 / fp32x3 frame kernels exist for H = 512, 1024, ...
+  a.st16 = dirs[0].state_bf16 ? 1 : 0;
+  for (int i = 0; i < ndir; ++i)
+    if ((dirs[i].state_bf16 ? 1 : 0) != a.st16) return DVAE_EINVAL;
+  if (a.st16 && a.pm != DVAE_MODE_BF16) return DVAE_EINVAL;
   a.T = T; a.N = N; a.H = H; a.ldh = ldh;
   return DVAE_OK;
 }
@@ -1031,7 +1052,10 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
     // really overlap (one's load latency under the other's MFMAs) instead of alternating
     for (int step = g0; step < g1; ++step) {
 #define FWD5(MT_, KR_, PM_) hipLaunchKernelGGL((lstm_step_fwd_v5<MT_, KR_, PM_, 2>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5)
-      if (a.pm == DVAE_MODE_BF16) {
+      if (a.pm == DVAE_MODE_BF16 && a.st16) {
+        if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_fwd_v5<2, 128, 1, 2, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+        else hipLaunchKernelGGL((lstm_step_fwd_v5<1, 128, 1, 2, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      } else if (a.pm == DVAE_MODE_BF16) {
         if (p.mt5 == 2) FWD5(2, 128, 1); else FWD5(1, 128, 1);
       } else if (a.pm == DVAE_MODE_F32X3) {
         // (64-row tiles, which read W_hh twice per frame instead of 4x, measured SLOWER: 15.3 vs 12.5 us per layer-frame
@@ -1080,7 +1104,10 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
     dim3 grid5(p.n_j * p.n_m5, 1, ndir), block5(512);
     for (int step = g0; step < g1; ++step) {
 #define BWD5(MT_, KR_, PM_) hipLaunchKernelGGL((lstm_step_bwd_v5<MT_, KR_, PM_>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5)
-      if (a.pm == DVAE_MODE_BF16) {
+      if (a.pm == DVAE_MODE_BF16 && a.st16) {
+        if (p.mt5 == 2) hipLaunchKernelGGL((lstm_step_bwd_v5<2, 64, 1, 1, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+        else hipLaunchKernelGGL((lstm_step_bwd_v5<1, 64, 1, 1, true>), grid5, block5, 0, s, a, step, p.n_j, p.n_m5);
+      } else if (a.pm == DVAE_MODE_BF16) {
         if (p.mt5 == 2) BWD5(2, 64, 1); else BWD5(1, 64, 1);
       } else if (a.pm == DVAE_MODE_F32X3) {
         if (p.mt5 == 2) BWD5(2, 32, 2); else BWD5(1, 64, 2);

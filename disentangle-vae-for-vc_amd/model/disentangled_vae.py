@@ -311,16 +311,16 @@ class DisentangledVAE(nn.Module):
             raise ValueError(f"expected [B, {N_MEL}, {self.n_frames}] mel segments, got {tuple(x.shape)}")
 
     def _lstm(self, mname, x, T, n_seg, x16=None):
-        """x16: bf16 data of x when x is a placeholder (output of a conv block in the bf16 compute mode)."""
+        """x16: bf16 data of x when x is a placeholder (output of a conv block in the bf16 compute mode).
+        Returns (h, h16) the same way: h16 is None unless the layer keeps its state in bf16 (then h is the placeholder)."""
         mod = getattr(self, mname)
         if LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
             # two stacked layers of equal width share their frame launches (ops.LstmStack2Fn)
             der = self._lstm_der(mname, 0, False) + self._lstm_der(mname, 1, False)
-            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4], der, x16)
+            return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4], der, x16, True)
         for l in range(mod.num_layers):
-            x = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l), self._lstm_der(mname, l, mod.bidirectional),
-                                  x16 if l == 0 else None)
-        return x
+            x, x16 = LstmLayerFn.apply(x, T, n_seg, *mod.layer(l), self._lstm_der(mname, l, mod.bidirectional), x16, True)
+        return x, x16
 
     def _encode_frames(self, x, T, n_seg, groups):
         x16 = None
@@ -329,7 +329,7 @@ class DisentangledVAE(nn.Module):
             x, x16 = ConvBnActFn.apply(x, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
                                        self._wpt(f"enc_modules.{i}"), self._w16(f"enc_modules.{i}"), x16, True)
-        h = self._lstm("enc_lstm", x, T, n_seg, x16)                     # [T*N, 128]
+        h, _ = self._lstm("enc_lstm", x, T, n_seg, x16)                  # [T*N, 128]  (H = 64: fp32 state)
         d2 = 2 * self.dim_neck
         flat = Permute102Fn.apply(h, T, n_seg, d2, (n_seg, T * d2))     # index t*128+d as in :209
         lin = self.enc_linear.linear_layer
@@ -344,16 +344,15 @@ class DisentangledVAE(nn.Module):
         h = LinearFn.apply(h, p2.weight, p2.bias, ACT_NONE, self._w16("dec_pre_linear2"))   # [N, T*128]  (no activation, :232-233)
         d2 = 2 * self.dim_neck
         h = Permute102Fn.apply(h, n_seg, T, d2, (T * n_seg, d2))
-        h = self._lstm("dec_lstm1", h, T, n_seg)
-        h16 = None
+        h, h16 = self._lstm("dec_lstm1", h, T, n_seg)
         for i, blk in enumerate(self.dec_modules):
             c, bn = blk[0], blk[1]
             h, h16 = ConvBnActFn.apply(h, c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        bn.num_batches_tracked, None, n_seg, groups, ACT_RELU, self.training,
                                        self._wpt(f"dec_modules.{i}"), self._w16(f"dec_modules.{i}"), h16, True)
-        h = self._lstm("dec_lstm2", h, T, n_seg, h16)
+        h, h16 = self._lstm("dec_lstm2", h, T, n_seg, h16)
         lin = self.dec_linear2.linear_layer
-        return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE, self._w16("dec_linear2"))   # [T*N, 80]
+        return LinearFn.apply(h, lin.weight, lin.bias, ACT_NONE, self._w16("dec_linear2"), h16)   # [T*N, 80]
 
     # ---- reference API
     def encode(self, x):

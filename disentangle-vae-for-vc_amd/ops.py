@@ -207,11 +207,13 @@ class compute_dtype:
 
 
 # ----------------------------------------------------------------------------- raw launches
-def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi=EPI_STORE, split_k=1, mode=None):
-    """A, B, Cout, bias: tensors or raw device addresses (ints)."""
+def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi=EPI_STORE, split_k=1, mode=None,
+         flags=0):
+    """A, B, Cout, bias: tensors or raw device addresses (ints).  Storage flags (A_BF16 ...) are taken from the dtypes of
+    tensor arguments; for raw addresses pass them in `flags`."""
     a = lambda t: t if (t is None or isinstance(t, int)) else t.data_ptr()
     check(lib().dvae_gemm_f32(a(A), a(B), a(Cout), a(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),
-                              act, epi, split_k, _mflags(_mode(mode), A, B, Cout), stream()), "dvae_gemm_f32")
+                              act, epi, split_k, _mflags(_mode(mode), A, B, Cout) | flags, stream()), "dvae_gemm_f32")
 
 
 def linear_fwd(x, w, b, act=ACT_NONE, mode=None, w16=None):
@@ -287,8 +289,10 @@ class LinearFn(torch.autograd.Function):
     """nn.Linear (+ optional ReLU): disentangled_vae.py:165-171,194 used at :211-213,232-233,247."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, act, w16=None):
-        _ok(x, weight, bias)
+    def forward(ctx, x, weight, bias, act, w16=None, x16=None):
+        """x16: bf16 data of x when x is a placeholder (output of an LSTM layer in the bf16 compute mode)."""
+        x = x if x16 is None else x16
+        _ok(x, weight, bias, act16=(x,))
         ctx.mode = current_mode()
         ctx.w16 = w16 if ctx.mode == MODE_BF16 else None      # bf16 copy of the weight (derived.DerivedWeights)
         y = linear_fwd(x, weight, bias, act, ctx.mode, ctx.w16)
@@ -309,7 +313,7 @@ class LinearFn(torch.autograd.Function):
             linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode)
             colsum_add(dy, _grad_buf(bias))
         _ready(weight, bias)
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- Conv1d(k5) + BatchNorm + act
@@ -433,9 +437,11 @@ class LstmLayerFn(torch.autograd.Function):
     `derived`: list of derived.LstmDerived, one per direction (or None)."""
 
     @staticmethod
-    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, derived=None, x16=None):
-        x = x if x16 is None else x16
-        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, act16=(x,))                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
+    def forward(ctx, x, T, N, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, derived=None, x16=None, emit16=False):
+        """emit16 (bf16 compute mode, H a multiple of 512): returns (h, h16) — h16 the state as the frame kernels WROTE it
+        (bf16), h its fp32 placeholder for autograd (see ConvBnActFn); otherwise h is a real fp32 tensor and h16 None."""
+        x = x if x16 is None else x16                     # bf16 mode: the DATA of a placeholder input
+        _ok(x, w_ih, w_hh, b_ih, b_hh, w_ih_r, w_hh_r, b_ih_r, b_hh_r, act16=(x,))
         L = lib()
         st = stream()
         dev = x.device
@@ -443,7 +449,10 @@ class LstmLayerFn(torch.autograd.Function):
         H = w_hh.shape[1]
         ndir = 2 if w_ih_r is not None else 1
         ldh = ndir * H
-        h_out = torch.empty((R, ldh), device=dev, dtype=torch.float32)
+        mode0 = current_mode()
+        s16 = mode0 == MODE_BF16 and H % 512 == 0         # bf16 state / gate-gradient storage (frame kernels with S16)
+        h_out = torch.empty((R, ldh), device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
+        esz = h_out.element_size()
         params = [(w_ih, w_hh, b_ih, b_hh), (w_ih_r, w_hh_r, b_ih_r, b_hh_r)][:ndir]
         dirs = (_lib.LstmDir * ndir)()
         # bf16 / fp32x3 compute modes: the recurrence runs on bf16 fragments (one plane / three planes) where such frame
@@ -465,20 +474,31 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].w_hh = ptr(wh)
             dirs[d].w_packed = ptr(der[d].pack_f)
             dirs[d].packed_mode = bf
-            dirs[d].h_out = h_out.data_ptr() + 4 * d * H
+            dirs[d].h_out = h_out.data_ptr() + esz * d * H
             dirs[d].c_all = ptr(c)
             dirs[d].reverse = d
+            dirs[d].state_bf16 = int(s16)
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
         ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
         ctx.der = der
-        ctx.cfg = (T, N, H, ndir, bfb, mode)
-        return h_out
+        ctx.cfg = (T, N, H, ndir, bfb, mode, s16)
+        if not s16:
+            return (h_out, None) if emit16 else h_out
+        if emit16:
+            ctx.mark_non_differentiable(h_out)
+            return _placeholder(R, ldh, dev), h_out
+        return h_out.float()          # stand-alone use in the bf16 mode: a real fp32 copy for the caller
 
     @staticmethod
-    def backward(ctx, dh):
-        T, N, H, ndir, bf, mode = ctx.cfg
+    def backward(ctx, dh, *_):
+        return LstmLayerFn._backward(ctx, dh)
+
+    @staticmethod
+    def _backward(ctx, dh):
+        T, N, H, ndir, bf, mode, s16 = ctx.cfg
         sv = ctx.saved_tensors
         x, h_out = sv[0], sv[1]
+        esz = 2 if s16 else 4                                 # bytes per element of h_out / dgates
         gates = sv[2:2 + ndir]
         cells = sv[2 + ndir:2 + 2 * ndir]
         flat = sv[2 + 2 * ndir:]
@@ -494,7 +514,7 @@ class LstmLayerFn(torch.autograd.Function):
         keep = []
         dgs = []
         for d in range(ndir):
-            dg = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
+            dg = torch.empty((R, 4 * H), device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
             dc = torch.empty((N, H), device=dev, dtype=torch.float32)
             keep.append(dc)
             dgs.append(dg)
@@ -507,6 +527,7 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].dgates = ptr(dg)
             dirs[d].dc_ws = ptr(dc)
             dirs[d].reverse = d
+            dirs[d].state_bf16 = int(s16)
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
@@ -524,16 +545,17 @@ class LstmLayerFn(torch.autograd.Function):
                     rows = R - N
                     # h_prev of frame t is h[t-1] (forward) / h[t+1] (reverse)
                     if d == 0:
-                        a_ptr, b_ptr = dg.data_ptr() + 4 * N * 4 * H, h_out.data_ptr()
+                        a_ptr, b_ptr = dg.data_ptr() + esz * N * 4 * H, h_out.data_ptr()
                     else:
-                        a_ptr, b_ptr = dg.data_ptr(), h_out.data_ptr() + 4 * (N * ldh + H)
+                        a_ptr, b_ptr = dg.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)
                     sk = _split_k(_tiles(4 * H, H), rows)
-                    gemm(a_ptr, b_ptr, gw, None, 4 * H, H, rows, 4 * H, ldh, H, False, False, ACT_NONE, EPI_ATOMIC, sk, mode)
+                    gemm(a_ptr, b_ptr, gw, None, 4 * H, H, rows, 4 * H, ldh, H, False, False, ACT_NONE, EPI_ATOMIC, sk, mode,
+                         flags=(A_BF16 | B_BF16) if s16 else 0)
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         for (wi, wh, bi, bh) in params:
             _ready(wi, wh, bi, bh)
         del keep
-        return (dx,) + (None,) * 12
+        return (dx,) + (None,) * 13
 
 
 class LstmStack2Fn(torch.autograd.Function):
@@ -560,9 +582,10 @@ class LstmStack2Fn(torch.autograd.Function):
         return layers == 2 and not bidirectional and H % 512 == 0 and Tc > 0 and T % Tc == 0 and T // Tc >= 2
 
     @staticmethod
-    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, derived=None, x16=None):
-        x = x if x16 is None else x16
-        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, act16=(x,))                     # bf16 mode: the DATA of a placeholder input (ConvBnActFn)
+    def forward(ctx, x, T, N, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, derived=None, x16=None, emit16=False):
+        """emit16: as LstmLayerFn.forward — (h2 placeholder, h2 in bf16) in the bf16 compute mode."""
+        x = x if x16 is None else x16                     # bf16 mode: the DATA of a placeholder input
+        _ok(x, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, act16=(x,))
         L, st, dev = lib(), stream(), x.device
         R, In = x.shape
         H = w_hh1.shape[1]
@@ -574,7 +597,10 @@ class LstmStack2Fn(torch.autograd.Function):
         f32 = dict(device=dev, dtype=torch.float32)
         g1, g2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
         c1, c2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
-        h1, h2 = torch.empty((R, H), **f32), torch.empty((R, H), **f32)
+        s16 = mode == MODE_BF16                               # bf16 state / gate-gradient storage (usable(): H % 512 == 0)
+        sdt = dict(device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
+        esz = 2 if s16 else 4
+        h1, h2 = torch.empty((R, H), **sdt), torch.empty((R, H), **sdt)
         gemm(x, w_ih1 if der[0].w_ih16 is None else der[0].w_ih16, g1, der[0].bias, R, 4 * H, In, In, In, 4 * H, True, True,
              mode=mode)
         dirs = (_lib.LstmDir * 2)()
@@ -582,21 +608,29 @@ class LstmStack2Fn(torch.autograd.Function):
             dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed = ptr(g), ptr(wh), ptr(der[d].pack_f)
             dirs[d].h_out, dirs[d].c_all = ptr(h), ptr(c)
             dirs[d].reverse, dirs[d].packed_mode, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
+            dirs[d].state_bf16 = int(s16)
         rows = Tc * N
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
                 r0 = (c0 - Tc) * N
-                gemm(h1.data_ptr() + 4 * r0 * H, w_ih2 if der[1].w_ih16 is None else der[1].w_ih16,
-                     g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias, rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode)
+                gemm(h1.data_ptr() + esz * r0 * H, w_ih2 if der[1].w_ih16 is None else der[1].w_ih16,
+                     g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias, rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode,
+                     flags=A_BF16 if s16 else 0)
             check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
         ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
         ctx.der = der
-        ctx.cfg = (T, N, H, bfb, mode)
-        return h2
+        ctx.cfg = (T, N, H, bfb, mode, s16)
+        if not s16:
+            return (h2, None) if emit16 else h2
+        if emit16:
+            ctx.mark_non_differentiable(h2)
+            return _placeholder(R, H, dev), h2
+        return h2.float()
 
     @staticmethod
-    def backward(ctx, dh2):
-        T, N, H, bf, mode = ctx.cfg
+    def backward(ctx, dh2, *_):
+        T, N, H, bf, mode, s16 = ctx.cfg
+        esz = 2 if s16 else 4
         (x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2) = ctx.saved_tensors
         der = ctx.der
         L, st, dev = lib(), stream(), x.device
@@ -604,7 +638,8 @@ class LstmStack2Fn(torch.autograd.Function):
         Tc = LstmStack2Fn.chunk(T)
         f32 = dict(device=dev, dtype=torch.float32)
         dh2 = dh2.contiguous()
-        dg1, dg2 = torch.empty((R, 4 * H), **f32), torch.empty((R, 4 * H), **f32)
+        sdt = dict(device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
+        dg1, dg2 = torch.empty((R, 4 * H), **sdt), torch.empty((R, 4 * H), **sdt)
         dh1 = torch.empty((R, H), **f32)                   # gradient w.r.t. layer 1's outputs = layer 2's dgrad
         dcs = [torch.empty((N, H), **f32) for _ in range(2)]
         # backward step s handles frame T-1-s.  Entry 0 = layer 2 (ahead), entry 1 = layer 1 (a chunk behind).
@@ -613,12 +648,13 @@ class LstmStack2Fn(torch.autograd.Function):
             dirs[d].gates, dirs[d].w_hh, dirs[d].w_packed, dirs[d].c_all = ptr(g), ptr(dd.w_hh_t), ptr(dd.pack_b), ptr(c)
             dirs[d].dh_out, dirs[d].dgates, dirs[d].dc_ws = ptr(dho), ptr(dg), ptr(dcs[d])
             dirs[d].reverse, dirs[d].packed_mode, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
+            dirs[d].state_bf16 = int(s16)
         rows = Tc * N
         for c0 in range(0, T + Tc, Tc):
             if c0 >= Tc:    # layer 2 finished backward steps [c0-Tc, c0) = frames [T-c0, T-c0+Tc): dgrad into dh1
                 r0 = (T - c0) * N
-                gemm(dg2.data_ptr() + 4 * r0 * 4 * H, der[1].w_ih_t, dh1.data_ptr() + 4 * r0 * H, None,
-                     rows, H, 4 * H, 4 * H, 4 * H, H, True, True, mode=mode)
+                gemm(dg2.data_ptr() + esz * r0 * 4 * H, der[1].w_ih_t, dh1.data_ptr() + 4 * r0 * H, None,
+                     rows, H, 4 * H, 4 * H, 4 * H, H, True, True, mode=mode, flags=A_BF16 if s16 else 0)
             check(L.dvae_lstm_seq_bwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_bwd_range")
         dx = None
         if ctx.needs_input_grad[0]:
@@ -631,13 +667,13 @@ class LstmStack2Fn(torch.autograd.Function):
                 gw = _grad_buf(wh)
                 rws = R - N
                 sk = _split_k(_tiles(4 * H, H), rws)
-                gemm(dg.data_ptr() + 4 * N * 4 * H, hh, gw, None, 4 * H, H, rws, 4 * H, H, H, False, False, ACT_NONE,
-                     EPI_ATOMIC, sk, mode)
+                gemm(dg.data_ptr() + esz * N * 4 * H, hh, gw, None, 4 * H, H, rws, 4 * H, H, H, False, False, ACT_NONE,
+                     EPI_ATOMIC, sk, mode, flags=A_BF16 if s16 else 0)
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         _ready(w_ih2, w_hh2, b_ih2, b_hh2)
         _ready(w_ih1, w_hh1, b_ih1, b_hh1)
         del dcs
-        return (dx,) + (None,) * 12
+        return (dx,) + (None,) * 13
 
 
 # ----------------------------------------------------------------------------- layout

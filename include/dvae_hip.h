@@ -163,7 +163,9 @@ typedef struct {
                          the plain calls).  Lets two STACKED layers share launches, the upper one a chunk of frames
                          behind the lower one (whose chunk of outputs has meanwhile gone through the upper layer's input
                          projection): twice the workgroups per launch, half the launches */
-  int pad_;
+  int state_bf16;     /* bf16 mode only: h_out (forward call) / dgates (backward call) are bf16 tensors — the storage their
+                         consumers (the next frame, the next layer's projection, the weight gradients) read; the same
+                         element strides */
 } dvae_lstm_dir_t;
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);

@@ -13,7 +13,12 @@ vectors) with ONE change, stated operation by operation, that defines what "bf16
       LSTM recurrence, H == 64         fp32 (the HIP path keeps W_hh of the small encoder LSTM in registers in fp32)
       dW_hh (every H)                  r(dg)^T r(h)
 
-Tensors between operations (activations, gates, BatchNorm, losses, gradients, master weights, Adam) are fp32.
+Tensors between operations (activations, gates, BatchNorm, losses, gradients, master weights, Adam) are fp32, with one
+exception that is visible in the results: the wide LSTM layers (H % 512 == 0) keep their OUTPUT h_t and their gate
+gradient dg_t in bf16 (the frame kernels write what the next frame's contraction reads).  Every consumer of h_t is a
+contraction, which would round it anyway; dg_t also feeds the bias gradient, which therefore sums r(dg_t):
+
+      LSTM, H % 512 == 0               h_t := r(h_t) as stored       db_ih = db_hh = sum_t r(dg_t)
 A product of two bf16 numbers is exact in fp32, so the HIP path and this oracle differ only by fp32 summation order
 (and by the occasional operand that such a difference pushes across a bf16 rounding boundary).
 """
@@ -72,10 +77,36 @@ def conv5(x, weight, bias):
     return _Conv5.apply(x, weight) + bias[None, :, None]
 
 
-def lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
-    """x [B, T, In] -> h [B, T, H]; gate order i, f, g, o; zero initial state (nn.LSTM semantics)."""
+class _RoundFwd(torch.autograd.Function):
+    """r16 forward, identity backward (a tensor STORED in bf16 whose gradient travels in fp32)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return r16(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity forward, r16 backward (a GRADIENT stored in bf16)"""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return r16(g)
+
+
+def lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse=False, state_bf16=None):
+    """x [B, T, In] -> h [B, T, H]; gate order i, f, g, o; zero initial state (nn.LSTM semantics).
+    state_bf16 (default: H % 512 == 0): h_t and dg_t are stored in bf16, see the header."""
     B, T, _ = x.shape
     H = w_hh.shape[1]
+    state_bf16 = (H % 512 == 0) if state_bf16 is None else state_bf16
     pre = _MatmulNT.apply(x, w_ih, True) + (b_ih + b_hh)
     h = x.new_zeros(B, H)
     c = x.new_zeros(B, H)
@@ -87,9 +118,13 @@ def lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse=False):
         if not first:
             g = g + _MatmulNT.apply(h, w_hh, H % 512 == 0)
         first = False
+        if state_bf16:
+            g = _RoundBwd.apply(g)
         i, f, gg, o = g.chunk(4, dim=1)
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
         h = torch.sigmoid(o) * torch.tanh(c)
+        if state_bf16:
+            h = _RoundFwd.apply(h)
         outs[t] = h
     return torch.stack(outs, dim=1)
 

@@ -15,6 +15,8 @@ H = int(sys.argv[1])
 stack = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 BF = int(os.environ.get("LSTM_MODE", "0"))        # DVAE_MODE_*: 0 fp32 MFMA, 1 bf16, 2 fp32x3 (three bf16 planes)
+S16 = int(os.environ.get("LSTM_S16", "0")) if BF == 1 else 0   # bf16 mode: h / dgates stored as bf16
+sdt = torch.bfloat16 if S16 else torch.float32
 T, N = 128, 128
 L = lib()
 nl = 2 if stack else 1
@@ -27,8 +29,9 @@ for l in range(nl):
     der = lstm_local(w_ih, w_hh, b, b, BF)
     MF, MB = lstm_pack_modes(BF, H)
     layers.append(dict(w_hh=w_hh, der=der, gates0=torch.randn(T * N, 4 * H, **f) * 0.5,
-                       gates=torch.empty(T * N, 4 * H, **f), h=torch.empty(T * N, H, **f), c=torch.empty(T * N, H, **f),
-                       dh=torch.randn(T * N, H, **f) * 0.1, dg=torch.empty(T * N, 4 * H, **f), dc=torch.empty(N, H, **f)))
+                       gates=torch.empty(T * N, 4 * H, **f), h=torch.empty(T * N, H, device=dev, dtype=sdt),
+                       c=torch.empty(T * N, H, **f), dh=torch.randn(T * N, H, **f) * 0.1,
+                       dg=torch.empty(T * N, 4 * H, device=dev, dtype=sdt), dc=torch.empty(N, H, **f)))
 
 
 def dirs(bwd):
@@ -41,6 +44,7 @@ def dirs(bwd):
         d[i].w_packed = ptr(y["der"].pack_b if bwd else y["der"].pack_f)
         d[i].h_out, d[i].dh_out, d[i].dgates, d[i].dc_ws = ptr(y["h"]), ptr(y["dh"]), ptr(y["dg"]), ptr(y["dc"])
         d[i].reverse, d[i].packed_mode, d[i].step_shift = 0, (MB if bwd else MF), (T // 2 if (stack and i == 1) else 0)
+        d[i].state_bf16 = S16
     return d
 
 
@@ -84,6 +88,6 @@ cp = timeit(copy_only)
 tf = timeit(fwd, cp)
 tb = timeit(bwd)
 per = T * nl
-print(f"H={H} stack={stack} mode={BF}: fwd {1e3 * tf / per:.2f} us/layer-frame ({tf:.3f} ms), bwd {1e3 * tb / per:.2f} us/layer-frame "
+print(f"H={H} stack={stack} mode={BF} s16={S16}: fwd {1e3 * tf / per:.2f} us/layer-frame ({tf:.3f} ms), bwd {1e3 * tb / per:.2f} us/layer-frame "
       f"({tb:.3f} ms)  [lib {os.path.basename(_lib.LIB_PATH)}]", flush=True)
-assert torch.isfinite(layers[-1]["h"]).all() and torch.isfinite(layers[0]["dg"]).all()
+assert torch.isfinite(layers[-1]["h"].float()).all() and torch.isfinite(layers[0]["dg"].float()).all()
