@@ -104,6 +104,8 @@ SIGNATURES = {
     "dvae_mel_db_normalize": (i32, [vp, vp, i32, i32, i64, i64, f32, f32, f32, vp]),
     "dvae_probe_launches": (i32, [i32, i32, i32, i32, vp, vp]),
     "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
+    "dvae_probe_mfma_bf16": (i32, [i32, i32, i32, vp, vp, vp]),
+    "dvae_probe_coissue": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "dvae_prof_enable": (i32, [i32]),
     "dvae_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "dvae_prof_collect_tags": (i32, [C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),

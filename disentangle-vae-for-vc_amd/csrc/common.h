@@ -12,6 +12,38 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Split mode (DVAE_MODE_F32X3): x (4 x fp32) -> three bf16x4 with x[i] == p[0][i] + p[1][i] + p[2][i] exactly (see the X3
+// note in gemm.hip): round to nearest-even twice (v_cvt_pk_bf16_f32 packs two values per instruction; x - rne(x) is
+// exact in fp32), the last residual has <= 8 significant bits and converts exactly.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// (written on pairs: hipcc turns the 4-wide form into one single-element conversion per value to get rne(x) back as fp32
+// — 7.5 VALU operations per element; here a pair costs one v_cvt_pk_bf16_f32, a shift, a mask and a packed subtract per level)
+__device__ __forceinline__ unsigned split3_pk(f32x2& r) {   // returns rne(r) as two packed bf16, r -= rne(r)
+  const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  f32x2 e;
+  e[0] = __builtin_bit_cast(float, u << 16);
+  e[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+  r = r - e;
+  return u;
+}
+__device__ __forceinline__ void split3(const f32x4& x, bf16x4 (&p)[3]) {
+  f32x2 lo = {x[0], x[1]}, hi = {x[2], x[3]};
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    u32x2 w;
+    if (q < 2) {
+      w[0] = split3_pk(lo);
+      w[1] = split3_pk(hi);
+    } else {   // the last residual is exact in bf16
+      w[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+      w[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+    }
+    p[q] = __builtin_bit_cast(bf16x4, w);
+  }
+}
+
 extern int g_dvae_compute_mode;   // gemm.hip: process default of the contraction arithmetic (DVAE_MODE_*)
 
 extern int g_dvae_last_hip_error;

@@ -22,8 +22,17 @@
 // matrix pipe runs back to back instead of paying one LDS round trip per k-step.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include "common.h"
 
+// Development ablations (build with -DDVAE_GEMM_ABL=<bits>, results are WRONG): 1 no operand split (one conversion),
+// 2 no global loads inside the k loop, 4 no LDS staging inside the loop, 8 no fragment reads inside the loop, 16 no MFMAs
+#ifndef DVAE_GEMM_ABL
+#define DVAE_GEMM_ABL 0
+#endif
+#ifndef DVAE_TALL_SCHED
+#define DVAE_TALL_SCHED 1   // gemm_x3_tall_kernel: 1 sched_group_barrier pipeline, 2 sched_barrier per MFMA group, 0 compiler's choice
+#endif
 #ifndef DVAE_X3_PD
 #define DVAE_X3_PD 2   // k-tiles in flight ahead of the one being computed (split mode), see the kernel
 #endif
@@ -40,17 +49,6 @@ __device__ unsigned long long g_gemm_ts[1024 * 8];
 __device__ __attribute__((aligned(16))) float g_gemm_zero[4] = {0.f, 0.f, 0.f, 0.f};   // what masked lanes load
 
 namespace {
-
-// x (4 x fp32) -> three bf16x4 with x[i] == p[0][i] + p[1][i] + p[2][i] exactly (see the X3 note at the kernel):
-// round to nearest-even twice (v_cvt_pk_bf16_f32 packs two values per instruction; x - rne(x) is exact in fp32), the
-// last residual has <= 8 significant bits and converts exactly.
-__device__ __forceinline__ void split3(const f32x4& x, bf16x4 (&p)[3]) {
-  p[0] = __builtin_convertvector(x, bf16x4);
-  const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
-  p[1] = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(p[1], f32x4);
-  p[2] = __builtin_convertvector(r2, bf16x4);
-}
 
 // Workgroup = WG x WG waves (WG = 2: 128 x 64*NTW tile, 256 threads; WG = 4: 256 x 128*NTW tile, 1024 threads).
 // The large tile halves the global-load instructions per MFMA (measured: loads cost ~15 % of the small tile's time).
@@ -271,6 +269,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
         const int off = A_KC ? (idx / KQA) * LDA + 4 * (idx % KQA) : (idx / (BM / 4)) * LDA + 4 * (idx % (BM / 4));
         if constexpr (X3) {
           bf16x4 pl[3];
+          if constexpr (DVAE_GEMM_ABL & 1) pl[0] = pl[1] = pl[2] = __builtin_convertvector(ra[j], bf16x4); else
           split3(ra[j], pl);
 #pragma unroll
           for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&As[buf][q * A_SZ + off]) = pl[q];
@@ -295,6 +294,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
         const int off = B_KC ? (idx / KQB) * LDB + 4 * (idx % KQB) : (idx / (BN / 4)) * LDB + 4 * (idx % (BN / 4));
         if constexpr (X3) {
           bf16x4 pl[3];
+          if constexpr (DVAE_GEMM_ABL & 1) pl[0] = pl[1] = pl[2] = __builtin_convertvector(rb[j], bf16x4); else
           split3(rb[j], pl);
 #pragma unroll
           for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&Bs[buf][q * B_SZ + off]) = pl[q];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 
   int cur = 0;
 #ifdef DVAE_GEMM_TS
-  const unsigned long long ts_t0 = TS_NOW();
+  const unsigned long long ts_t0 = TS_NOW(), ts_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   auto compute_tile = [&]() {
     if constexpr (B16) {
@@ -383,9 +383,15 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) av[s2][mt][q] = frag(&As[cur][q * A_SZ], A_KC, LDA, wm * 64 + mt * 32, s2);
+          for (int mt = 0; mt < 2; ++mt) {
+            if constexpr (DVAE_GEMM_ABL & 8) av[s2][mt][q] = __builtin_bit_cast(bf16x8, ra_[0][0]);
+            else av[s2][mt][q] = frag(&As[cur][q * A_SZ], A_KC, LDA, wm * 64 + mt * 32, s2);
+          }
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) bv[s2][nt][q] = frag(&Bs[cur][q * B_SZ], B_KC, LDB, wn * 32 * NTW + nt * 32, s2);
+          for (int nt = 0; nt < NTW; ++nt) {
+            if constexpr (DVAE_GEMM_ABL & 8) bv[s2][nt][q] = __builtin_bit_cast(bf16x8, rb_[0][0]);
+            else bv[s2][nt][q] = frag(&Bs[cur][q * B_SZ], B_KC, LDB, wn * 32 * NTW + nt * 32, s2);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
       // X3: the six partial products of weight >= 2^-16, (a1,b1) first: it needs only the first image of each operand
@@ -397,8 +403,12 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
         for (int term = 0; term < NT6; ++term)
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) {
+            if constexpr (DVAE_GEMM_ABL & 16) {
+              asm volatile("" ::"v"(av[s2][0][ia[term]]), "v"(av[s2][1][ia[term]]), "v"(bv[s2][nt][ib[term]]));
+            } else {
             acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][0][ia[term]], bv[s2][nt][ib[term]], acc[0][nt], 0, 0, 0);
             acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2][1][ia[term]], bv[s2][nt][ib[term]], acc[1][nt], 0, 0, 0);
+            }
           }
       __builtin_amdgcn_sched_barrier(0);
     } else {
@@ -479,12 +489,12 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 #pragma unroll
       for (int u = 0; u < PD; ++u) {
         // set u is free (tile it0+u was staged an iteration ago): tile it0 + u + PD goes there
-        load_tiles(ra_[u], rb_[u], tap_n, kit_n);
+        if constexpr (!(DVAE_GEMM_ABL & 2)) load_tiles(ra_[u], rb_[u], tap_n, kit_n);
         advance();
         compute_tile();
-        store_tiles(cur ^ 1, ra_[(u + 1) % PD], rb_[(u + 1) % PD]);
+        if constexpr (!(DVAE_GEMM_ABL & 4)) store_tiles(cur ^ 1, ra_[(u + 1) % PD], rb_[(u + 1) % PD]);
         __syncthreads();
-        cur ^= 1;
+        if constexpr (!(DVAE_GEMM_ABL & 4)) cur ^= 1;
       }
     }
   }
@@ -493,6 +503,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     unsigned long long* o = g_gemm_ts + blockIdx.x * 8;
     o[0] = TS_NOW() - ts_t0;
     o[1] = (unsigned long long)n_iters;
+    o[2] = __builtin_amdgcn_s_memrealtime() - ts_r0;   // 100 MHz reference: o[0] / o[2] x 100 MHz = the clock held
   }
 #endif
 
@@ -590,6 +601,395 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Split mode, 256 x 128 x 16 tile ("tall"): 4 waves (2 x 2), each a 128 x 64 output tile = 4 x 2 MFMA tiles, ONE
+// workgroup per CU, one wave per SIMD.  Why this shape (measured, scripts/coissue.py, gemm_ablate.py, mfma_peak.py):
+//  * the split arithmetic of one wave and the MFMAs of ANOTHER wave of the same SIMD do not overlap at all (776 + 508
+//    cycles alone, 1284 together): two workgroups per CU (the 128 x 128 kernel) or two alternating wave groups buy no
+//    overlap for VALU-heavy staging — only instructions of the wave's OWN stream placed in the 32-cycle shadow of its
+//    MFMAs (<= ~5 four-cycle issue slots per MFMA, MI355X_MICROARCH.md) are free;
+//  * a 128 x 64 wave tile has 48 MFMAs per k-step to hide under: ~240 issue slots against ~190 instructions of staging
+//    (split of 24 values, 9 ds_write_b128, 18 ds_read_b128, 6 buffer loads), and the 256 x 128 tile moves 3/4 of the
+//    L2 -> CU bytes of two 128 x 128 tiles (whose data movement alone runs at the L2 bandwidth limit).
+// So the k loop is ONE basic block, software-pipelined four k-tiles deep, with the interleave pinned by
+// sched_group_barrier:
+//     iteration i:   buffer loads of tile i+3 -> register set (i+1)%2       (out-of-range rows / conv padding / ragged
+//                    fragment reads of tile i+1 (LDS buffer (i+1)%2)         edges read as zeros: raw buffer bounds check,
+//                    48 MFMAs on fragment set i%2, the split + LDS writes     no per-load select)
+//                    of tile i+2 (register set i%2 -> LDS buffer i%2) in their shadow
+//                    ONE barrier
+// Tiles past the end read zeros (offsets past the operand), the iteration count is rounded up to even.
+// Requires: every k range a multiple of 16 and operands below 2 GiB (launch_gemm falls back to the 128 x 128 kernel).
+template <class F, int... Is>
+__device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+template <bool A_KC, bool B_KC, bool BNS>
+__global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 128, BK = 16, NTHR = 256, MTW = 4, NTW = 2;
+  constexpr int LD_KC = BK + 8;
+  constexpr int LDA = A_KC ? LD_KC : BM + 32;
+  constexpr int LDB = B_KC ? LD_KC : BN + 32;
+  constexpr int A_SZ = A_KC ? BM * LD_KC : BK * LDA;
+  constexpr int B_SZ = B_KC ? BN * LD_KC : BK * LDB;
+  constexpr int NUA = BM * BK / 8 / NTHR, NUB = BN * BK / 8 / NTHR;   // 8-element units per thread per k-tile: 2, 1
+  constexpr int NU = NUA + NUB;
+  // an offset no operand reaches (operands < 1 GiB, launch_gemm): reads zeros.  Sums stay outside: a real offset or a
+  // small negative tap offset plus OOB, and OOB + OOB = 0x80000000
+  constexpr unsigned OOB = 0xC0000000u;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][3 * A_SZ];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][3 * B_SZ];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  int tile_m, tile_n;
+  if (p.xcd_map) {
+    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    tile_m = x * per + q % per;
+    tile_n = q / per;
+  } else {
+    tile_m = blockIdx.x % p.tiles_m;
+    tile_n = blockIdx.x / p.tiles_m;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int tap_fixed = 0, ks = blockIdx.z;
+  if (p.tap_mode == 2) {
+    tap_fixed = blockIdx.z % p.taps;
+    ks = blockIdx.z / p.taps;
+  }
+  const int k_begin = ks * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int kiters = (k_end - k_begin) / BK;
+  const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
+  float* __restrict__ C = (float*)p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+
+  // ---- operands as raw buffers: byte offsets, unsigned 32-bit; anything outside [0, bytes) reads zeros.  A row shifted
+  // outside the matrix by a conv tap, a row past M / N, a k-row outside [0, K) (wgrad taps) or a tile past the end all
+  // land outside; what wraps INSIDE instead (columns past the edge of a row-contiguous operand) is masked per thread.
+  const int a_rows = A_KC ? p.M : p.K, b_rows = B_KC ? p.N : p.K;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((int64_t)a_rows * p.lda * 4), 0x00020000);
+  const int64_t b_bytes = (int64_t)b_rows * p.ldb * 4 * ((p.tap_mode == 1) ? p.taps : 1);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
+  unsigned a_vo[NUA], b_vo[NUB];   // byte offset of the unit's first element in k-tile 0 (tap 2)
+  int a_off[NUA], b_off[NUB];      // LDS element offset of the unit
+#pragma unroll
+  for (int j = 0; j < NUA; ++j) {
+    const int idx = t + NTHR * j;
+    if (A_KC) {
+      const int row = idx >> 1, k8 = (idx & 1) * 8;
+      a_off[j] = row * LDA + k8;
+      a_vo[j] = (unsigned)(((int64_t)(m0 + row) * p.lda + k_begin + k8) * 4);
+      if (m0 + row >= p.M) a_vo[j] = OOB;
+    } else {
+      const int kr = idx / (BM / 8), m8 = (idx % (BM / 8)) * 8;
+      a_off[j] = kr * LDA + m8;
+      a_vo[j] = (unsigned)(((int64_t)(k_begin + kr) * p.lda + m0 + m8) * 4);
+      if (m0 + m8 >= p.M) a_vo[j] = OOB;
+    }
+  }
+  const int64_t b_shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
+#pragma unroll
+  for (int j = 0; j < NUB; ++j) {
+    const int idx = t + NTHR * j;
+    if (B_KC) {
+      const int row = idx >> 1, k8 = (idx & 1) * 8;
+      b_off[j] = row * LDB + k8;
+      b_vo[j] = (unsigned)(((int64_t)(n0 + row) * p.ldb + k_begin + k8) * 4);
+      if (n0 + row >= p.N) b_vo[j] = OOB;
+    } else {
+      const int kr = idx / (BN / 8), n8 = (idx % (BN / 8)) * 8;
+      b_off[j] = kr * LDB + n8;
+      b_vo[j] = (unsigned)(((int64_t)(k_begin + kr) + b_shift) * p.ldb * 4 + (int64_t)(n0 + n8) * 4);   // may be "negative": outside
+      if (n0 + n8 >= p.N) b_vo[j] = OOB;
+    }
+  }
+  // per-tile scalar offsets (uniform): tap part + k part
+  const int ntaps_loop = (p.tap_mode == 1) ? p.taps : 1;
+  const int a_tap_step = (p.tap_mode == 1) ? (int)(p.a_row_shift * p.lda * 4) : 0;
+  const int b_tap_step = (p.tap_mode == 1) ? (int)(p.b_tap_stride * 4) : 0;
+  const int a_k_step = A_KC ? BK * 4 : (int)(BK * p.lda * 4);
+  const int b_k_step = B_KC ? BK * 4 : (int)(BK * p.ldb * 4);
+  int tap_n = 0, kit_n = 0;   // next tile to fetch
+  struct Regs {
+    u32x4 a[NUA][2], b[NUB][2];
+  };
+  auto load_tiles = [&](Regs& g) {
+    // past the last k-tile: an offset outside every operand
+    const bool live = kit_n < kiters;
+    const unsigned a_s = live ? (unsigned)((tap_n - 2) * a_tap_step + kit_n * a_k_step) : OOB;
+    const unsigned b_s = live ? (unsigned)(tap_n * b_tap_step + kit_n * b_k_step) : OOB;
+#pragma unroll
+    for (int j = 0; j < NUA; ++j) {
+      g.a[j][0] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[j] + a_s, 0, 0);
+      g.a[j][1] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[j] + a_s, 16, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < NUB; ++j) {
+      g.b[j][0] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[j] + b_s, 0, 0);
+      g.b[j][1] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[j] + b_s, 16, 0);
+    }
+    const bool wrap = (tap_n + 1 == ntaps_loop);
+    tap_n = wrap ? 0 : tap_n + 1;
+    kit_n += wrap ? 1 : 0;
+  };
+  // unit (8 values) -> three bf16x8, one ds_write_b128 per plane
+  auto stage_unit = [&](__bf16* img, int sz, const u32x4 (&v)[2]) {
+    bf16x4 lo[3], hi[3];
+    split3(__builtin_bit_cast(f32x4, v[0]), lo);
+    split3(__builtin_bit_cast(f32x4, v[1]), hi);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      *reinterpret_cast<bf16x8*>(&img[q * sz]) = __builtin_shufflevector(lo[q], hi[q], 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto stage_all = [&](int buf, Regs& g) {
+#pragma unroll
+    for (int j = 0; j < NUA; ++j) stage_unit(&As[buf][a_off[j]], A_SZ, g.a[j]);
+#pragma unroll
+    for (int j = 0; j < NUB; ++j) stage_unit(&Bs[buf][b_off[j]], B_SZ, g.b[j]);
+  };
+
+  // fragments of v_mfma_f32_32x32x16_bf16 (see compute_tile of the kernel above)
+  const int g16 = lane >> 4, li = lane & 15;
+  const int tr_k = 8 * (g16 >> 1) + (li >> 2), tr_r = 16 * (g16 & 1) + 4 * (li & 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto frag = [&](const __bf16* img, bool kc, int ld, int row0) -> bf16x8 {
+    if (kc) return *reinterpret_cast<const bf16x8*>(&img[(row0 + l31) * ld + 8 * kh]);
+    const __bf16* q0 = &img[tr_k * ld + row0 + tr_r];
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * ld));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  struct Frags {
+    bf16x8 a[MTW][3], b[NTW][3];
+  };
+  auto read_frags = [&](Frags& f, int buf) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) f.a[mt][q] = frag(&As[buf][q * A_SZ], A_KC, LDA, wm * 128 + mt * 32);
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) f.b[nt][q] = frag(&Bs[buf][q * B_SZ], B_KC, LDB, wn * 64 + nt * 32);
+    }
+  };
+
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Regs gs[2];
+  Frags fr[2];
+  // ---- prologue: tile 0 staged and its fragments read, tile 1 staged, tile 2 in flight
+  load_tiles(gs[0]);
+  load_tiles(gs[1]);
+  stage_all(0, gs[0]);
+  load_tiles(gs[0]);
+  __syncthreads();
+  read_frags(fr[0], 0);
+  stage_all(1, gs[1]);
+  __syncthreads();
+
+  // ---- the k loop as 48 pinned steps per k-tile: step g = MFMA g, then AT MOST five other instructions (what fits in
+  // the MFMA's 32-cycle shadow); sched_barrier(0) after every step keeps hipcc from clumping them (left alone it puts
+  // 37 MFMAs back to back and the split arithmetic behind them; sched_group_barrier pipelines came out no better).
+  //   steps 0-17   one fragment read of tile i+1 each; steps 0-5 also one buffer load of tile i+3
+  //   steps 18-46  the split of tile i+2, one PAIR-LEVEL per step (v_cvt_pk_bf16_f32, shift, mask, two subtracts: 5
+  //                instructions), a unit's three ds_write_b128 riding on its last step and the two after it
+  constexpr int ia[6] = {0, 0, 1, 1, 0, 2}, ib[6] = {0, 1, 0, 1, 2, 0};
+  unsigned a_s = 0, b_s = 0;    // scalar byte offsets of the tile being fetched (uniform)
+  unsigned pl[2][3][4];         // planes of the unit being split (4 pairs each); two sets: a unit's last two writes
+  float rr[2][8];               // overlap the next unit's first levels.  rr: the residuals
+  auto unit_regs = [&](Regs& g, int j) -> const u32x4(&)[2] { return j < NUA ? g.a[j] : g.b[j - NUA]; };
+  auto fsub = [](float a, float b) {   // (asm: a plain a - b gets SLP-packed into v_pk_add_f32, which costs ~13 extra cycles beside an MFMA)
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+  };
+  auto step = [&](auto G, auto U) {
+    constexpr int g = decltype(G)::value, u = decltype(U)::value;
+    {
+      constexpr int term = g / 8, mt = (g % 8) / 2, nt = g % 2;
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[u].a[mt][ia[term]], fr[u].b[nt][ib[term]], acc[mt][nt], 0, 0, 0);
+    }
+    // loads of tile i+3 -> set u^1 (steps 0-5); fragments of tile i+1 <- LDS buffer u^1, ONE read per step (steps 0-17):
+    // the four waves of the CU share one LDS pipe (a ds_read_b128 of a wave occupies it for 8 cycles) and pass the barrier
+    // together — three reads per step made each of them queue behind the other three
+    if constexpr (g < 6) {
+      Regs& gn = gs[u ^ 1];
+      constexpr int j = g / 2, hv = g % 2;
+      if constexpr (j < NUA) gn.a[j][hv] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_vo[j] + a_s, 16 * hv, 0);
+      else gn.b[j - NUA][hv] = __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_vo[j - NUA] + b_s, 16 * hv, 0);
+    }
+    if constexpr (g < 18) {
+      Frags& f = fr[u ^ 1];
+      constexpr int q = g / 6, w = g % 6;            // plane-major, A tiles then B tiles
+      if constexpr (w < MTW) f.a[w][q] = frag(&As[u ^ 1][q * A_SZ], A_KC, LDA, wm * 128 + w * 32);
+      else f.b[w - MTW][q] = frag(&Bs[u ^ 1][q * B_SZ], B_KC, LDB, wn * 64 + (w - MTW) * 32);
+    } else {
+      // the split of tile i+2 (set u -> LDS buffer u): unit j = steps 18 + 9 j .. 18 + 9 j + 8 (eight pair-levels and the
+      // last conversion); its three ds_write_b128 ride on its last step and the two steps after it
+      constexpr int s = g - 18;             // 0..29
+      constexpr int SPU = 9;
+      constexpr int j = s / SPU, w = s % SPU;
+      if constexpr (j < NU) {
+        const u32x4(&v)[2] = unit_regs(gs[u], j);
+        if constexpr (w < 8) {
+          constexpr int lvl = w / 4, i = w % 4;
+          if constexpr (lvl == 0) {   // (bit_cast of the whole vector: on a vector ELEMENT lvalue it reads element 0)
+            const f32x4 xv = __builtin_bit_cast(f32x4, v[i / 2]);
+            rr[j & 1][2 * i] = xv[2 * (i % 2)];
+            rr[j & 1][2 * i + 1] = xv[2 * (i % 2) + 1];
+          }
+          const f32x2 xy = {rr[j & 1][2 * i], rr[j & 1][2 * i + 1]};
+          const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(xy, bf16x2));
+          pl[j & 1][lvl][i] = pk;
+          rr[j & 1][2 * i] = fsub(rr[j & 1][2 * i], __builtin_bit_cast(float, pk << 16));
+          rr[j & 1][2 * i + 1] = fsub(rr[j & 1][2 * i + 1], __builtin_bit_cast(float, pk & 0xffff0000u));
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const f32x2 xy = {rr[j & 1][2 * i], rr[j & 1][2 * i + 1]};
+            pl[j & 1][2][i] = __builtin_bit_cast(unsigned, __builtin_convertvector(xy, bf16x2));
+          }
+        }
+      }
+      // writes of unit jw: plane 0 on the unit's last step, planes 1 and 2 on the next two steps
+      constexpr int sw = s - 8;             // >= 0 from the first unit's last step on
+      if constexpr (sw >= 0 && sw % SPU < 3 && sw / SPU < NU) {
+        constexpr int jw = sw / SPU, q = sw % SPU;
+        __bf16* img = jw < NUA ? &As[u][a_off[jw < NUA ? jw : 0]] : &Bs[u][b_off[jw < NUA ? 0 : jw - NUA]];
+        constexpr int sz = jw < NUA ? A_SZ : B_SZ;
+        const u32x4 o = {pl[jw & 1][q][0], pl[jw & 1][q][1], pl[jw & 1][q][2], pl[jw & 1][q][3]};
+        *reinterpret_cast<u32x4*>(&img[q * sz]) = o;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#ifdef DVAE_GEMM_TS
+  unsigned long long ts_a = 0, ts_b = 0, ts_c = 0, ts_bar = 0, ts_x = TS_NOW();
+  const unsigned long long ts_t0 = ts_x, ts_r0 = __builtin_amdgcn_s_memrealtime();
+#define TALL_LAP(acc_) do { const unsigned long long n_ = TS_NOW(); acc_ += n_ - ts_x; ts_x = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TALL_LAP(acc_) do { } while (0)
+#endif
+  auto all_steps = [&](auto U) {
+    for_seq([&](auto G) {
+      step(G, U);
+      if constexpr (decltype(G)::value == 17) TALL_LAP(ts_a);
+      if constexpr (decltype(G)::value == 35) TALL_LAP(ts_b);
+      if constexpr (decltype(G)::value == 47) TALL_LAP(ts_c);
+    }, std::make_integer_sequence<int, 48>{});
+  };
+  auto next_tile_offsets = [&]() {
+    const bool live = kit_n < kiters;
+    a_s = live ? (unsigned)((tap_n - 2) * a_tap_step + kit_n * a_k_step) : OOB;
+    b_s = live ? (unsigned)(tap_n * b_tap_step + kit_n * b_k_step) : OOB;
+    const bool wrap = (tap_n + 1 == ntaps_loop);
+    tap_n = wrap ? 0 : tap_n + 1;
+    kit_n += wrap ? 1 : 0;
+  };
+  for (int it0 = 0; it0 < n_iters; it0 += 2) {
+    next_tile_offsets();
+    all_steps(std::integral_constant<int, 0>{});
+    __syncthreads();
+    TALL_LAP(ts_bar);
+    next_tile_offsets();
+    all_steps(std::integral_constant<int, 1>{});
+    __syncthreads();
+    TALL_LAP(ts_bar);
+  }
+#ifdef DVAE_GEMM_TS
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && blockIdx.z == 0) {
+    unsigned long long* o = g_gemm_ts + (blockIdx.x * 4 + wave) * 8;
+    o[0] = TS_NOW() - ts_t0;
+    o[1] = (unsigned long long)n_iters;
+    o[2] = __builtin_amdgcn_s_memrealtime() - ts_r0;
+    o[3] = ts_a; o[4] = ts_b; o[5] = ts_c; o[6] = ts_bar;
+  }
+#endif
+
+  // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  const bool add_bias = (p.bias != nullptr) && (ks == 0);
+  const int epi = p.epi, act = p.act;
+#pragma unroll
+  for (int half = 0; half < MTW / 2; ++half) {     // 64 rows = one BatchNorm statistics chunk
+    float bst[NTW][4];
+    int bmod = 0;
+    if constexpr (BNS) {
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bst[nt][q] = 0.f;
+      bmod = (m0 + wm * 128 + half * 64 + 4 * kh) % p.bn_nseg;
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < 2; ++m2) {
+      const int mt = 2 * half + m2;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int col = n0 + wn * 64 + nt * 32 + l31;
+        if (col >= p.N) continue;
+        const float bias_v = add_bias ? p.bias[col] : 0.f;
+        const int row0 = m0 + wm * 128 + mt * 32 + 4 * kh;
+        float* cbase = C + (int64_t)row0 * p.ldc + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = (r & 3) + 8 * (r >> 2);
+          const bool ok = row0 + dr < p.M;
+          float v = acc[mt][nt][r] + bias_v;
+          if (epi == DVAE_EPI_STORE) {
+            v = act_apply(v, act);
+            if (ok) cbase[(int64_t)dr * p.ldc] = v;
+          } else if (epi == DVAE_EPI_ACCUM) {
+            if (ok) cbase[(int64_t)dr * p.ldc] += v;
+          } else {
+            if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
+          }
+          if constexpr (BNS) {
+            const int nseg = p.bn_nseg;
+            int rm = bmod + m2 * 32 + dr;
+            if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+            const float uu = ok ? v : 0.f;
+            const bool g1 = rm >= nseg / p.bn_groups;
+            bst[nt][0] += g1 ? 0.f : uu;
+            bst[nt][1] += g1 ? 0.f : uu * uu;
+            bst[nt][2] += g1 ? uu : 0.f;
+            bst[nt][3] += g1 ? uu * uu : 0.f;
+          }
+        }
+      }
+    }
+    if constexpr (BNS) {
+      const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+#pragma unroll
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int col = n0 + wn * 64 + nt * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
+        if (kh == 0 && col < p.N && chunk < nchunks) {
+          double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
+          o[0] = (double)bst[nt][0];
+          o[1] = (double)bst[nt][1];
+          if (p.bn_groups > 1) {
+            o[(int64_t)p.N * 2] = (double)bst[nt][2];
+            o[(int64_t)p.N * 2 + 1] = (double)bst[nt][3];
+          }
+        }
+      }
+    }
+  }
+}
+
+
 // conv forward with BatchNorm statistics (k-contiguous operands, 128-row tiles, unsplit, plain store)
 void launch_bns(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, int mode) {
 #define BNS_LAUNCH(NTW_, BK_, MODE_) hipLaunchKernelGGL((gemm_f32_kernel<true, true, NTW_, BK_, 2, MODE_, true>), grid, dim3(256), 0, s, p)
@@ -675,18 +1075,41 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
   p.split_k = (p.K + kps - 1) / kps;
-  const int zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
+  int zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
+  // split mode: the 256 x 128 tile (gemm_x3_tall_kernel, one workgroup per CU) when it still fills the chip; an
+  // atomically accumulated product (weight gradients) is cut into twice the k-splits for it
+  static const int tall_env = getenv("DVAE_GEMM_TALL") ? atoi(getenv("DVAE_GEMM_TALL")) : -1;
+  bool tall = false;
+  // (its raw-buffer addressing: every k range a multiple of 16, operands below 1 GiB)
+  const int64_t a_bytes = (int64_t)(a_kc ? p.M : p.K) * p.lda * 4;
+  const int64_t b_bytes = (int64_t)(b_kc ? p.N : p.K) * p.ldb * 4 * (p.tap_mode == 1 ? p.taps : 1);
+  const bool tall_ok = (p.K % 16 == 0) && a_bytes < (1ll << 30) && b_bytes < (1ll << 30);
+  if (mode == DVAE_MODE_F32X3 && tall_env != 0 && tall_ok && p.M >= 256 && p.N > 64) {
+    const int t2 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    if (t2 * zdim < 192 && p.split_k > 1 && p.epi == DVAE_EPI_ATOMIC && kps >= 1024) {
+      kps = ((kps / 2 + bk - 1) / bk) * bk;
+      p.k_per_split = kps;
+      p.split_k = (p.K + kps - 1) / kps;
+      zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
+    }
+    // one workgroup per CU: nothing hides a tile's prologue (cold loads) and epilogue (128 KB of C per CU), so the tile
+    // must be long: >= 60 k-steps (in the step: the convs, the weight gradients, the K = 1024 projections; shorter ones stay
+    // on the 128 x 128 kernel, whose two workgroups per CU cover each other's ends)
+    static const int tall_min = getenv("DVAE_GEMM_TALL_MIN") ? atoi(getenv("DVAE_GEMM_TALL_MIN")) : 60;
+    const int steps_per_tile = (kps / 16) * (p.tap_mode == 1 ? p.taps : 1);
+    tall = (t2 * zdim >= 192 && steps_per_tile >= tall_min) || tall_env == 1;
+  }
   static const int big_env = getenv("DVAE_GEMM_BIG") ? atoi(getenv("DVAE_GEMM_BIG")) : -1;
   // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
   bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0);
   if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0);
   if (mode != DVAE_MODE_F32) big = false;   // the 16-wave tile exists for the fp32 MFMA only (128 registers per lane)
-  const int bm = big ? 256 : 128;
+  const int bm = (big || tall) ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
   // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
   const int tiles128 = p.tiles_m * ((p.N + 127) / 128) * zdim;
-  const bool narrow = !big && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
+  const bool narrow = !big && !tall && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
   const int bn = big ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
   static const int xcd_env = getenv("DVAE_GEMM_XCDMAP") ? atoi(getenv("DVAE_GEMM_XCDMAP")) : 1;
@@ -694,14 +1117,25 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
   const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
-                       ((big ? 4u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15);
+                       ((big ? 4u : tall ? 1u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15) |
+                       ((unsigned)p.a16 << 17) | ((unsigned)p.b16 << 18) | ((p.bn_part ? 1u : 0u) << 19);
   // algorithmic bytes: every operand element once (the activation matrix of a conv once, not once per tap)
   const double ntap = p.tap_mode ? p.taps : 1;
-  const double alg_bytes = 4.0 * ((double)p.M * p.K + (double)p.K * p.N * (p.tap_mode == 1 ? ntap : 1.0) +
-                                  (double)p.M * p.N * (p.tap_mode == 2 ? ntap : 1.0));
+  const double ea = p.a16 ? 2.0 : 4.0, eb = p.b16 ? 2.0 : 4.0;   // bf16 mode: operands that are bf16 in memory
+  const double alg_bytes = ea * (double)p.M * p.K + eb * (double)p.K * p.N * (p.tap_mode == 1 ? ntap : 1.0) +
+                           (p.c16 ? 2.0 : 4.0) * (double)p.M * p.N * (p.tap_mode == 2 ? ntap : 1.0);
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap, tag, alg_bytes);
-  if (p.bn_part) {
-    if (!a_kc || !b_kc || big || p.split_k != 1 || p.epi != DVAE_EPI_STORE || p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
+  if (p.bn_part && (!a_kc || !b_kc || big || p.split_k != 1 || p.epi != DVAE_EPI_STORE || p.act != DVAE_ACT_NONE))
+    return DVAE_EINVAL;
+  if (tall) {
+#define TALL(AK_, BK_, BNS_) hipLaunchKernelGGL((gemm_x3_tall_kernel<AK_, BK_, BNS_>), grid, dim3(256), 0, s, p)
+    if (p.bn_part) TALL(true, true, true);
+    else if (a_kc && b_kc) TALL(true, true, false);
+    else if (a_kc && !b_kc) TALL(true, false, false);
+    else if (!a_kc && b_kc) TALL(false, true, false);
+    else TALL(false, false, false);
+#undef TALL
+  } else if (p.bn_part) {
     launch_bns(p, grid, s, narrow, bk, mode);
   } else if (a_kc && b_kc)
     launch_variant<true, true>(p, grid, s, narrow, bk, big, mode);

@@ -128,6 +128,117 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters, i
   }
 }
 }  // namespace
+namespace {
+// bf16 matrix-pipe ceiling with the split-mode MFMA stream (2 x 2 tiles, six partial products per k-step) on register
+// operands.  pattern 0: zero operands; 1: random bf16 bit patterns, constant over the run; 2: random and CHANGING every
+// k-step (one v_xor per operand register) — the switching activity of real data, which sets the clock the chip holds.
+// out2[0..1] of block 0: shader-clock cycles (s_memtime) and 100 MHz reference ticks (s_memrealtime) of the loop.
+__global__ __launch_bounds__(256) void mfma_bf16_peak_kernel(float* out, unsigned long long* out2, int iters, int pattern) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 a[2][3], b[2][3];
+  unsigned seed = (threadIdx.x + 1) * 2654435761u + blockIdx.x * 40503u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return pattern ? ((seed >> 1) & 0x3f7f3f7fu) : 0u; };   // |x| < 1
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[i][q][e] = rnd(); b[i][q][e] = rnd(); }
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr int ia[6] = {0, 0, 1, 1, 0, 2}, ib[6] = {0, 1, 0, 1, 2, 0};
+  const unsigned flip = (pattern == 2) ? 0x00550033u : 0u;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt][ia[term]]),
+                                                               __builtin_bit_cast(bf16x8, b[nt][ib[term]]), acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        a[i][q] ^= flip * (unsigned)(it & 1 ? 1 : 3);
+        b[i][q] ^= flip * (unsigned)(it & 1 ? 3 : 1);
+      }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+  if (s == 123.456f) out[0] = s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = t1 - t0; out2[1] = r1 - r0; }
+}
+}  // namespace
+namespace {
+// Do VALU work and MFMAs of two DIFFERENT waves of one SIMD overlap?  512-thread workgroups: waves 0-3 run the split-mode
+// MFMA stream, waves 4-7 the split arithmetic (v_cvt_pk_bf16_f32 / shift / mask / subtract) on registers.
+// which: 1 MFMA waves only, 2 VALU waves only, 3 both.  out2[0..3] of block 0: cycles of wave 0 (MFMA), wave 4 (VALU),
+// and the instruction counts behind them (MFMAs, VALU operations) per wave.
+__global__ __launch_bounds__(512) void coissue_kernel(float* out, unsigned long long* out2, int iters, int which, int prio) {
+  const int wave = threadIdx.x >> 6;
+  const bool mf = wave < 4;
+  if ((mf && !(which & 1)) || (!mf && !(which & 2))) return;
+  unsigned seed = (threadIdx.x + 1) * 2654435761u + blockIdx.x * 40503u;
+  auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (seed >> 1) & 0x3f7f3f7fu; };
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  float s = 0.f;
+  if (mf) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 a[2][3], b[2][3];
+    for (int i = 0; i < 2; ++i) for (int q = 0; q < 3; ++q) for (int e = 0; e < 4; ++e) { a[i][q][e] = rnd(); b[i][q][e] = rnd(); }
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int ia[6] = {0, 0, 1, 1, 0, 2}, ib[6] = {0, 1, 0, 1, 2, 0};
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt][ia[term]]),
+                                                                 __builtin_bit_cast(bf16x8, b[nt][ib[term]]), acc[mt][nt], 0, 0, 0);
+    }
+    for (int r = 0; r < 16; ++r) s += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+  } else {
+    f32x4 x[4];
+    for (int i = 0; i < 4; ++i) for (int e = 0; e < 4; ++e) x[i][e] = __builtin_bit_cast(float, rnd());
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {      // 4 pieces of 4 values: 4.5 operations per value x 16 = 72, + 16 below
+        bf16x4 pl[3];
+        split3(x[i], pl);
+        sum += __builtin_convertvector(pl[1], f32x4) + __builtin_convertvector(pl[2], f32x4);
+        x[i] += sum * 1e-3f;
+      }
+    }
+    s = sum[0] + sum[1] + sum[2] + sum[3];
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (s == 123.456f) out[0] = s;
+  if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) out2[mf ? 0 : 1] = t1 - t0;
+}
+}  // namespace
+DVAE_API int dvae_probe_coissue(int blocks, int iters, int which, int prio, float* out, unsigned long long* out2, void* stream) {
+  hipLaunchKernelGGL(coissue_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, out, out2, iters, which, prio);
+  return dvae_check_launch();
+}
+DVAE_API int dvae_probe_mfma_bf16(int blocks, int iters, int pattern, float* out, unsigned long long* out2, void* stream) {
+  hipLaunchKernelGGL(mfma_bf16_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, out2, iters, pattern);
+  return dvae_check_launch();
+}
 DVAE_API int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream) {
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, shape);
   return dvae_check_launch();

@@ -84,7 +84,6 @@ int dvae_last_hip_error(void);
 int dvae_gemm_f32(const void* A, const void* B, void* C, const float* bias,
                   int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                   int a_kcontig, int b_kcontig, int act, int epi, int split_k, int mode, void* stream);
-
 /* ---- Conv1d(k=5, stride 1, pad 2) on frame-major data (disentangled_vae.py:111-114, 178-181) ----
  * Weights are used in PACKED form Wp[5][Cout][Cin] (see dvae_conv_pack_w).
  * fwd : Y[R,Cout]   = sum_tap X[r+(tap-2)*N, :] * Wp[tap]^T + bias      (rows outside [0,R) are zero)
@@ -324,6 +323,12 @@ int dvae_prof_collect_tags(unsigned* tags, double* ms, int64_t* launches, double
 int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
 /* experiments: register-only MFMA chains (shape 32 -> 32x32x2 f32, else 16x16x4 f32): the matrix-pipe ceiling of THIS chip */
 int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream);
+/* bf16 matrix-pipe ceiling with the split-mode MFMA stream on register operands; pattern 0 zeros, 1 random constant,
+ * 2 random changing every k-step; out2[0..1] = shader-clock cycles and 100 MHz reference ticks of block 0's loop */
+/* do the split arithmetic (VALU) of one wave and the MFMAs of another wave of the same SIMD overlap?  which: 1 MFMA waves,
+ * 2 VALU waves, 3 both; out2[0] / out2[1] = cycles of an MFMA / a VALU wave of block 0 */
+int dvae_probe_coissue(int blocks, int iters, int which, int prio, float* out, unsigned long long* out2, void* stream);
+int dvae_probe_mfma_bf16(int blocks, int iters, int pattern, float* out, unsigned long long* out2, void* stream);
 #ifdef __cplusplus
 }
 #endif
