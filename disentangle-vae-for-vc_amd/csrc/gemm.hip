@@ -941,29 +941,55 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
         const float bias_v = add_bias ? p.bias[col] : 0.f;
         const int row0 = m0 + wm * 128 + mt * 32 + 4 * kh;
         float* cbase = C + (int64_t)row0 * p.ldc + col;
+        // Stores as 16 bytes per lane: a wave's 128 single-dword stores per tile cost ~20 us per workgroup (the store path
+        // takes ~70 cycles per wave-instruction whatever its width).  The accumulator holds 4 consecutive ROWS of one
+        // column per lane (r & 3); a 4 x 4 transpose inside each quad of lanes (two DPP butterfly stages) turns them
+        // into 4 consecutive COLUMNS of one row.  Atomic accumulation keeps the scalar form.
+        const int q4 = lane & 3;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int dr = (r & 3) + 8 * (r >> 2);
-          const bool ok = row0 + dr < p.M;
-          float v = acc[mt][nt][r] + bias_v;
-          if (epi == DVAE_EPI_STORE) {
-            v = act_apply(v, act);
-            if (ok) cbase[(int64_t)dr * p.ldc] = v;
-          } else if (epi == DVAE_EPI_ACCUM) {
-            if (ok) cbase[(int64_t)dr * p.ldc] += v;
-          } else {
-            if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
+        for (int g = 0; g < 4; ++g) {
+          float x[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e, dr = e + 8 * g;
+            const bool ok = row0 + dr < p.M;
+            float v = acc[mt][nt][r] + bias_v;
+            if (epi == DVAE_EPI_STORE) v = act_apply(v, act);
+            if (epi == DVAE_EPI_ATOMIC && ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
+            x[e] = v;
+            if constexpr (BNS) {
+              const int nseg = p.bn_nseg;
+              int rm = bmod + m2 * 32 + dr;
+              if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+              const float uu = ok ? v : 0.f;
+              const bool g1 = rm >= nseg / p.bn_groups;
+              bst[nt][0] += g1 ? 0.f : uu;
+              bst[nt][1] += g1 ? 0.f : uu * uu;
+              bst[nt][2] += g1 ? uu : 0.f;
+              bst[nt][3] += g1 ? uu * uu : 0.f;
+            }
           }
-          if constexpr (BNS) {
-            const int nseg = p.bn_nseg;
-            int rm = bmod + m2 * 32 + dr;
-            if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
-            const float uu = ok ? v : 0.f;
-            const bool g1 = rm >= nseg / p.bn_groups;
-            bst[nt][0] += g1 ? 0.f : uu;
-            bst[nt][1] += g1 ? 0.f : uu * uu;
-            bst[nt][2] += g1 ? uu : 0.f;
-            bst[nt][3] += g1 ? uu * uu : 0.f;
+          if (epi != DVAE_EPI_ATOMIC) {
+            // stage 1: lane bit 0 <-> element bit 0 (quad_perm [1,0,3,2] = 0xB1); stage 2: bit 1 (quad_perm [2,3,0,1] = 0x4E)
+            float y[4], z[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
+              y[e] = ((q4 ^ e) & 1) ? o : x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
+              z[e] = ((q4 ^ e) & 2) ? o : y[e];
+            }
+            // this lane now holds row (8 g + 4 kh + q4) of the tile, columns 4 (l31 >> 2) .. + 3
+            const int row = row0 + 8 * g + q4;
+            if (row < p.M) {
+              f32x4* dst = reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4));
+              f32x4 o4 = {z[0], z[1], z[2], z[3]};
+              if (epi == DVAE_EPI_ACCUM) o4 += *dst;
+              *dst = o4;
+            }
           }
         }
       }
@@ -1083,7 +1109,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   // (its raw-buffer addressing: every k range a multiple of 16, operands below 1 GiB)
   const int64_t a_bytes = (int64_t)(a_kc ? p.M : p.K) * p.lda * 4;
   const int64_t b_bytes = (int64_t)(b_kc ? p.N : p.K) * p.ldb * 4 * (p.tap_mode == 1 ? p.taps : 1);
-  const bool tall_ok = (p.K % 16 == 0) && a_bytes < (1ll << 30) && b_bytes < (1ll << 30);
+  const bool tall_ok = (p.K % 16 == 0) && a_bytes < (1ll << 30) && b_bytes < (1ll << 30) &&   // + 16-byte stores of C
+                       (p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.c_tap_stride % 4 == 0);
   if (mode == DVAE_MODE_F32X3 && tall_env != 0 && tall_ok && p.M >= 256 && p.N > 64) {
     const int t2 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     if (t2 * zdim < 192 && p.split_k > 1 && p.epi == DVAE_EPI_ATOMIC && kps >= 1024) {
