@@ -279,7 +279,7 @@ def main():
                     traffic_src = "profiles/pmc_traffic.json was collected for other kernel sources / another workload: not used"
             except Exception:
                 pass
-            roof = {"bound": "mfma", "kernel": "gemm_f32_kernel family (" + ARITH[dtype] + ")",
+            roof = {"bound": "mfma", "kernel": "contraction family: gemm_f32_kernel<...> + gemm_x3_tall_kernel<...> (" + ARITH[dtype] + ")",
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "peak_note": {"fp32x3": "2500 TFLOP/s dense bf16 MFMA / 6 bf16 partial products per fp32 product",
                                   "fp32": "fp32 MFMA = vector rate", "bf16": "dense bf16 MFMA"}[dtype],

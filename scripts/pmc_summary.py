@@ -16,7 +16,7 @@ root, steps = sys.argv[1], float(sys.argv[2])
 tag = sys.argv[3] if len(sys.argv) > 3 else "pmc"
 traffic_json = sys.argv[4] if len(sys.argv) > 4 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-fam = lambda n: ("gemm_f32_kernel" if "gemm_f32" in n else "lstm_step_* (H>=512)" if "lstm_step" in n else
+fam = lambda n: ("gemm_f32_kernel" if ("gemm_f32" in n or "gemm_x3" in n) else "lstm_step_* (H>=512)" if "lstm_step" in n else
                  "lstm_seq_*_h64" if "lstm_seq" in n else "adam" if "adam" in n else "bn_*" if "bn_" in n else
                  "colsum" if "colsum" in n else "repack_all" if "repack" in n else "other")
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -29,6 +29,7 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
 print(f"# {tag} PMC summary (rocprofv3 --pmc, three separate passes over `bench.py --steps 2 --warmup 1 --graph 0`; counters "
       f"summed per kernel family over the {steps:.0f} steps run, divided by {steps:.0f})\n")
 print(__doc__.split("\n\n", 1)[1] + "\n")
+print("(gemm_f32_kernel = the contraction family: gemm_f32_kernel<...> and gemm_x3_tall_kernel<...>)\n")
 print("| kernel family | launches/step | MFMA busy | fabric-side read MB/step (2 x FETCH_SIZE KB) | write MB/step (WRITE_SIZE KB) |")
 print("|---|---|---|---|---|")
 for k in sorted(acc, key=lambda k: -acc[k].get("GRBM_GUI_ACTIVE", 0)):
