@@ -917,102 +917,129 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   }
 #endif
 
-  // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // One straight-line copy per (epilogue kind, activation): with `epi` / `act` tested per element the 128 values of a
+  // lane went through ~1 000 scalar branches — 37 k cycles per tile (in-kernel stamps), a quarter of a 64-step k loop.
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
-  const int epi = p.epi, act = p.act;
+  auto emit = [&](auto EPI_, auto ACT_) {
+    constexpr int epi = decltype(EPI_)::value, act = decltype(ACT_)::value;
+    if constexpr (epi == DVAE_EPI_ATOMIC) {
+      // bias into the accumulators FIRST: a bias load pending beside the atomics (both count in vmcnt) made hipcc put
+      // `s_waitcnt vmcnt(0)` in front of every one of the 128 atomics of a lane — each waited for the one before it
+      if (add_bias) {
 #pragma unroll
-  for (int half = 0; half < MTW / 2; ++half) {     // 64 rows = one BatchNorm statistics chunk
-    float bst[NTW][4];
-    int bmod = 0;
-    if constexpr (BNS) {
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+          const float bv = col < p.N ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt)
+          for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bst[nt][q] = 0.f;
-      bmod = (m0 + wm * 128 + half * 64 + 4 * kh) % p.bn_nseg;
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bv;
+        }
+      }
     }
 #pragma unroll
-    for (int m2 = 0; m2 < 2; ++m2) {
-      const int mt = 2 * half + m2;
+    for (int half = 0; half < MTW / 2; ++half) {     // 64 rows = one BatchNorm statistics chunk
+      float bst[NTW][4];
+      int bmod = 0;
+      if constexpr (BNS) {
 #pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + l31;
-        if (col >= p.N) continue;
-        const float bias_v = add_bias ? p.bias[col] : 0.f;
-        const int row0 = m0 + wm * 128 + mt * 32 + 4 * kh;
-        float* cbase = C + (int64_t)row0 * p.ldc + col;
-        // Stores as 16 bytes per lane: a wave's 128 single-dword stores per tile cost ~20 us per workgroup (the store path
-        // takes ~70 cycles per wave-instruction whatever its width).  The accumulator holds 4 consecutive ROWS of one
-        // column per lane (r & 3); a 4 x 4 transpose inside each quad of lanes (two DPP butterfly stages) turns them
-        // into 4 consecutive COLUMNS of one row.  Atomic accumulation keeps the scalar form.
-        const int q4 = lane & 3;
+        for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float x[4];
+          for (int q = 0; q < 4; ++q) bst[nt][q] = 0.f;
+        bmod = (m0 + wm * 128 + half * 64 + 4 * kh) % p.bn_nseg;
+      }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e, dr = e + 8 * g;
-            const bool ok = row0 + dr < p.M;
-            float v = acc[mt][nt][r] + bias_v;
-            if (epi == DVAE_EPI_STORE) v = act_apply(v, act);
-            if (epi == DVAE_EPI_ATOMIC && ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
-            x[e] = v;
-            if constexpr (BNS) {
-              const int nseg = p.bn_nseg;
-              int rm = bmod + m2 * 32 + dr;
-              if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
-              const float uu = ok ? v : 0.f;
-              const bool g1 = rm >= nseg / p.bn_groups;
-              bst[nt][0] += g1 ? 0.f : uu;
-              bst[nt][1] += g1 ? 0.f : uu * uu;
-              bst[nt][2] += g1 ? uu : 0.f;
-              bst[nt][3] += g1 ? uu * uu : 0.f;
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const int mt = 2 * half + m2;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+          if (col >= p.N) continue;            // (N % 4 == 0: a quad of lanes is inside or outside as a whole)
+          const float bias_v = (epi != DVAE_EPI_ATOMIC && add_bias) ? p.bias[col] : 0.f;
+          const int row0 = m0 + wm * 128 + mt * 32 + 4 * kh;
+          float* cbase = C + (int64_t)row0 * p.ldc + col;
+          // Stores as 16 bytes per lane (a wave-instruction costs the store path ~70 cycles whatever its width).  The
+          // accumulator holds 4 consecutive ROWS of one column per lane (r & 3); a 4 x 4 transpose inside each quad of
+          // lanes (two DPP butterfly stages) turns them into 4 consecutive COLUMNS of one row.  Atomic accumulation
+          // keeps the scalar form (one 128-byte segment per row and instruction).
+          const int q4 = lane & 3;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e, dr = e + 8 * g;
+              const bool ok = row0 + dr < p.M;
+              float v = acc[mt][nt][r] + bias_v;
+              v = act_apply(v, act);     // (act is a constant here)
+              if constexpr (epi == DVAE_EPI_ATOMIC) {
+                if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
+              }
+              x[e] = v;
+              if constexpr (BNS) {
+                const int nseg = p.bn_nseg;
+                int rm = bmod + m2 * 32 + dr;
+                if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+                const float uu = ok ? v : 0.f;
+                const bool g1 = rm >= nseg / p.bn_groups;
+                bst[nt][0] += g1 ? 0.f : uu;
+                bst[nt][1] += g1 ? 0.f : uu * uu;
+                bst[nt][2] += g1 ? uu : 0.f;
+                bst[nt][3] += g1 ? uu * uu : 0.f;
+              }
+            }
+            if constexpr (epi != DVAE_EPI_ATOMIC) {
+              // stage 1: lane bit 0 <-> element bit 0 (quad_perm [1,0,3,2] = 0xB1); stage 2: bit 1 (quad_perm [2,3,0,1] = 0x4E)
+              float y[4], z[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
+                y[e] = ((q4 ^ e) & 1) ? o : x[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
+                z[e] = ((q4 ^ e) & 2) ? o : y[e];
+              }
+              // this lane now holds row (8 g + 4 kh + q4) of the tile, columns 4 (l31 >> 2) .. + 3
+              const int row = row0 + 8 * g + q4;
+              if (row < p.M) {
+                f32x4* dst = reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4));
+                f32x4 o4 = {z[0], z[1], z[2], z[3]};
+                if constexpr (epi == DVAE_EPI_ACCUM) o4 += *dst;
+                *dst = o4;
+              }
             }
           }
-          if (epi != DVAE_EPI_ATOMIC) {
-            // stage 1: lane bit 0 <-> element bit 0 (quad_perm [1,0,3,2] = 0xB1); stage 2: bit 1 (quad_perm [2,3,0,1] = 0x4E)
-            float y[4], z[4];
+        }
+      }
+      if constexpr (BNS) {
+        const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
-              y[e] = ((q4 ^ e) & 1) ? o : x[e];
-            }
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
-              z[e] = ((q4 ^ e) & 2) ? o : y[e];
-            }
-            // this lane now holds row (8 g + 4 kh + q4) of the tile, columns 4 (l31 >> 2) .. + 3
-            const int row = row0 + 8 * g + q4;
-            if (row < p.M) {
-              f32x4* dst = reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4));
-              f32x4 o4 = {z[0], z[1], z[2], z[3]};
-              if (epi == DVAE_EPI_ACCUM) o4 += *dst;
-              *dst = o4;
+          for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
+          if (kh == 0 && col < p.N && chunk < nchunks) {
+            double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
+            o[0] = (double)bst[nt][0];
+            o[1] = (double)bst[nt][1];
+            if (p.bn_groups > 1) {
+              o[(int64_t)p.N * 2] = (double)bst[nt][2];
+              o[(int64_t)p.N * 2 + 1] = (double)bst[nt][3];
             }
           }
         }
       }
     }
-    if constexpr (BNS) {
-      const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
-#pragma unroll
-      for (int nt = 0; nt < NTW; ++nt) {
-        const int col = n0 + wn * 64 + nt * 32 + l31;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
-        if (kh == 0 && col < p.N && chunk < nchunks) {
-          double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
-          o[0] = (double)bst[nt][0];
-          o[1] = (double)bst[nt][1];
-          if (p.bn_groups > 1) {
-            o[(int64_t)p.N * 2] = (double)bst[nt][2];
-            o[(int64_t)p.N * 2 + 1] = (double)bst[nt][3];
-          }
-        }
-      }
-    }
-  }
+  };
+  using std::integral_constant;
+  if (p.epi == DVAE_EPI_ATOMIC) emit(integral_constant<int, DVAE_EPI_ATOMIC>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.epi == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.act == DVAE_ACT_NONE) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
+  else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_TANH>{});
 }
 
 

@@ -45,15 +45,6 @@
 
 namespace {
 
-// x (4 x fp32) -> three bf16x4 planes with x == p[0] + p[1] + p[2] exactly (see gemm.hip, split3)
-__device__ __forceinline__ void split3_bf16(const f32x4& x, bf16x4 (&p)[3]) {
-  p[0] = __builtin_convertvector(x, bf16x4);
-  const f32x4 r1 = x - __builtin_convertvector(p[0], f32x4);
-  p[1] = __builtin_convertvector(r1, bf16x4);
-  const f32x4 r2 = r1 - __builtin_convertvector(p[1], f32x4);
-  p[2] = __builtin_convertvector(r2, bf16x4);
-}
-
 struct StepDir {
   float* gates;         // [T,N,4H]
   const float* w;       // fwd [4H,H] ; bwd W_hh^T [H,4H]
@@ -453,7 +444,7 @@ __global__ __launch_bounds__(512, (KR <= 64 && MT <= 2 ? 4 : 2)) void lstm_step_
             *reinterpret_cast<bf16x4*>(&As[buf][skh][off]) = v;
           } else if constexpr (PM == 2) {
             bf16x4 pl[3];
-            split3_bf16(v, pl);
+            split3(v, pl);
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(&As[buf][skh][p * PL + off]) = pl[p];
           } else if constexpr (PM == 1) {
@@ -653,7 +644,7 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
             *reinterpret_cast<bf16x4*>(dst) = st[i][q];
           } else if constexpr (PM == 2) {
             bf16x4 pl[3];
-            split3_bf16(st[i][q], pl);
+            split3(st[i][q], pl);
 #pragma unroll
             for (int p = 0; p < 3; ++p) *reinterpret_cast<bf16x4*>(dst + p * PL) = pl[p];
           } else if constexpr (PM == 1) {

@@ -36,6 +36,8 @@ print(f"shader clock during the k loops: {100.0 * a[:, 0].sum() / max(1.0, a[:, 
 if os.environ.get("TALL") == "1":   # tall kernel: rows = (workgroup, wave); steps 0-17 | 18-35 | 36-47 | barrier
     r = a[a[:, 1] > 0]
     n = r[:, 1].mean()
+    print(f"  tall: entry -> loop {r[:, 7].mean():.0f} cycles; loop {r[:, 0].mean():.0f}; epilogue: stores issued after {r[:, 4].mean():.0f}, drained after {r[:, 5].mean():.0f} "
+          f"(slowest wave: {r[:, 7].max():.0f} / {r[:, 0].max():.0f} / {r[:, 5].max():.0f})")
     print(f"  tall: per k-tile  steps 0-17 {r[:, 3].mean() / n:.0f}  18-35 {r[:, 4].mean() / n:.0f}  36-47 {r[:, 5].mean() / n:.0f}  barrier {r[:, 6].mean() / n:.0f}  "
           f"total {r[:, 0].mean() / n:.0f} cycles ({len(r)} waves; 48 MFMAs = 1536)")
 elif a[:, 3].sum() > 0:   # ping-pong kernel: per-phase cycles (M stage, barrier, C compute, barrier) per k-tile
