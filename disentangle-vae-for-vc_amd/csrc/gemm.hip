@@ -1043,6 +1043,323 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
 }
 
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 mode, both operands bf16 IN MEMORY: the tall structure (256 x 128 tile, one workgroup of four waves per CU, each
+// wave 128 x 64 = 4 x 2 MFMA tiles, every MFMA followed by a pinned handful of the next tiles' staging instructions)
+// with nothing to convert: staging is buffer_load_dwordx4 (8 bf16) -> ds_write_b128.  64-deep k-tiles = four 16-deep
+// sub-steps of 8 MFMAs; fragments are read ONE SUB-STEP ahead (two fragment sets of 24 registers), k-tile i+1 is staged
+// during sub-steps 0-2 of iteration i and the iteration's single barrier sits BEFORE sub-step 3, whose fragment reads are
+// the first of tile i+1: a buffer is dead (no reader) from that barrier of iteration i-1... i.e. two LDS buffers suffice.
+// Global loads run two k-tiles ahead of their staging (a piece's registers are reloaded right after its ds_write).
+//   iteration i   sub-steps 0-2: MFMAs of tile i; reads of its next sub-step; ds_write of tile i+1 -> buffer (i+1)%2;
+//                                buffer loads of tile i+3
+//                 barrier
+//                 sub-step 3:    MFMAs; fragment reads of tile i+1, sub-step 0
+// Requires k ranges that are multiples of 64 and operands < 1 GiB (else the 128 x 128 kernel).
+template <bool A_KC, bool B_KC, bool BNS>
+__global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 128, BK = 64, NTHR = 256, MTW = 4, NTW = 2;
+  constexpr int LD_KC = BK + 8;
+  constexpr int LDA = A_KC ? LD_KC : BM + 32;
+  constexpr int LDB = B_KC ? LD_KC : BN + 32;
+  constexpr int A_SZ = A_KC ? BM * LD_KC : BK * LDA;
+  constexpr int B_SZ = B_KC ? BN * LD_KC : BK * LDB;
+  constexpr int NPA = BM * BK / 8 / NTHR, NPB = BN * BK / 8 / NTHR;   // 16-byte pieces per thread per k-tile: 8, 4
+  constexpr int NP = NPA + NPB;
+  constexpr unsigned OOB = 0xC0000000u;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][A_SZ];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][B_SZ];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  int tile_m, tile_n;
+  if (p.xcd_map) {
+    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    tile_m = x * per + q % per;
+    tile_n = q / per;
+  } else {
+    tile_m = blockIdx.x % p.tiles_m;
+    tile_n = blockIdx.x / p.tiles_m;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int tap_fixed = 0, ks = blockIdx.z;
+  if (p.tap_mode == 2) {
+    tap_fixed = blockIdx.z % p.taps;
+    ks = blockIdx.z / p.taps;
+  }
+  const int k_begin = ks * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int kiters = (k_end - k_begin) / BK;
+  const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
+  float* __restrict__ C = (float*)p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+
+  // operands as raw buffers (see gemm_x3_tall_kernel): byte offsets, anything outside reads zeros
+  const int a_rows = A_KC ? p.M : p.K, b_rows = B_KC ? p.N : p.K;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((int64_t)a_rows * p.lda * 2), 0x00020000);
+  const int64_t b_bytes = (int64_t)b_rows * p.ldb * 2 * ((p.tap_mode == 1) ? p.taps : 1);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
+  unsigned vo[NP];     // byte offset of the piece in k-tile 0 (tap 2); pieces 0..NPA-1 = A, the rest B
+  int off[NP];         // LDS element offset of the piece
+#pragma unroll
+  for (int j = 0; j < NPA; ++j) {
+    const int idx = t + NTHR * j;
+    if (A_KC) {
+      const int row = idx >> 3, k8 = (idx & 7) * 8;
+      off[j] = row * LDA + k8;
+      vo[j] = (unsigned)(((int64_t)(m0 + row) * p.lda + k_begin + k8) * 2);
+      if (m0 + row >= p.M) vo[j] = OOB;
+    } else {
+      const int kr = idx / (BM / 8), m8 = (idx % (BM / 8)) * 8;
+      off[j] = kr * LDA + m8;
+      vo[j] = (unsigned)(((int64_t)(k_begin + kr) * p.lda + m0 + m8) * 2);
+      if (m0 + m8 >= p.M) vo[j] = OOB;
+    }
+  }
+  const int64_t b_shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
+#pragma unroll
+  for (int j = 0; j < NPB; ++j) {
+    const int idx = t + NTHR * j;
+    if (B_KC) {
+      const int row = idx >> 3, k8 = (idx & 7) * 8;
+      off[NPA + j] = row * LDB + k8;
+      vo[NPA + j] = (unsigned)(((int64_t)(n0 + row) * p.ldb + k_begin + k8) * 2);
+      if (n0 + row >= p.N) vo[NPA + j] = OOB;
+    } else {
+      const int kr = idx / (BN / 8), n8 = (idx % (BN / 8)) * 8;
+      off[NPA + j] = kr * LDB + n8;
+      vo[NPA + j] = (unsigned)(((int64_t)(k_begin + kr) + b_shift) * p.ldb * 2 + (int64_t)(n0 + n8) * 2);
+      if (n0 + n8 >= p.N) vo[NPA + j] = OOB;
+    }
+  }
+  const int ntaps_loop = (p.tap_mode == 1) ? p.taps : 1;
+  const int a_tap_step = (p.tap_mode == 1) ? (int)(p.a_row_shift * p.lda * 2) : 0;
+  const int b_tap_step = (p.tap_mode == 1) ? (int)(p.b_tap_stride * 2) : 0;
+  const int a_k_step = A_KC ? BK * 2 : (int)(BK * p.lda * 2);
+  const int b_k_step = B_KC ? BK * 2 : (int)(BK * p.ldb * 2);
+  int tap_n = 0, kit_n = 0;       // next tile to fetch
+  unsigned a_s = 0, b_s = 0;      // its scalar byte offsets (uniform)
+  auto next_tile_offsets = [&]() {
+    const bool live = kit_n < kiters;
+    a_s = live ? (unsigned)((tap_n - 2) * a_tap_step + kit_n * a_k_step) : OOB;
+    b_s = live ? (unsigned)(tap_n * b_tap_step + kit_n * b_k_step) : OOB;
+    const bool wrap = (tap_n + 1 == ntaps_loop);
+    tap_n = wrap ? 0 : tap_n + 1;
+    kit_n += wrap ? 1 : 0;
+  };
+  u32x4 gr[2][NP];
+  auto load_piece = [&](u32x4& dst, int j) {
+    if (j < NPA) dst = __builtin_amdgcn_raw_buffer_load_b128(a_rs, vo[j] + a_s, 0, 0);
+    else dst = __builtin_amdgcn_raw_buffer_load_b128(b_rs, vo[j] + b_s, 0, 0);
+  };
+  auto stage_piece = [&](int buf, const u32x4& v, int j) {
+    __bf16* img = j < NPA ? &As[buf][off[j]] : &Bs[buf][off[j]];
+    *reinterpret_cast<u32x4*>(img) = v;
+  };
+
+  const int g16 = lane >> 4, li = lane & 15;
+  const int tr_k = 8 * (g16 >> 1) + (li >> 2), tr_r = 16 * (g16 & 1) + 4 * (li & 3);
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  auto frag = [&](const __bf16* img, bool kc, int ld, int row0, int sub) -> bf16x8 {
+    if (kc) return *reinterpret_cast<const bf16x8*>(&img[(row0 + l31) * ld + 16 * sub + 8 * kh]);
+    const __bf16* q0 = &img[(16 * sub + tr_k) * ld + row0 + tr_r];
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q0 + 4 * ld));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  struct Frags {
+    bf16x8 a[MTW], b[NTW];
+  };
+  auto read_frag = [&](Frags& f, int buf, int sub, int w) {    // w = 0..5: A tiles, then B tiles
+    if (w < MTW) f.a[w] = frag(&As[buf][0], A_KC, LDA, wm * 128 + w * 32, sub);
+    else f.b[w - MTW] = frag(&Bs[buf][0], B_KC, LDB, wn * 64 + (w - MTW) * 32, sub);
+  };
+
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Frags fr[2];
+  // ---- prologue: tile 0 staged, tiles 1 and 2 in flight, fragments of (tile 0, sub-step 0) read
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < NP; ++j) load_piece(gr[0][j], j);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) stage_piece(0, gr[0][j], j);
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < NP; ++j) load_piece(gr[1][j], j);     // tile 1 -> set 1
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < NP; ++j) load_piece(gr[0][j], j);     // tile 2 -> set 0
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < MTW + NTW; ++w) read_frag(fr[0], 0, 0, w);
+
+  // one k-tile = 32 pinned steps (see gemm_x3_tall_kernel): step g = MFMA g, then at most three staging instructions
+  auto step = [&](auto G, auto U) {
+    constexpr int g = decltype(G)::value, u = decltype(U)::value;    // u = parity of the k-tile being computed
+    constexpr int sub = g / 8, e = g % 8, mt = e / 2, nt = e % 2;
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sub & 1].a[mt], fr[sub & 1].b[nt], acc[mt][nt], 0, 0, 0);
+    // fragments of the next sub-step (the first sub-step of tile i+1 after the barrier)
+    if constexpr (e < MTW + NTW) {
+      if constexpr (sub < 3) read_frag(fr[(sub + 1) & 1], u, sub + 1, e);
+      else read_frag(fr[0], u ^ 1, 0, e);
+    }
+    // staging of tile i+1 (set u^1 -> buffer u^1) and reload of the set with tile i+3: four pieces per sub-step 0-2
+    if constexpr (sub < 3) {
+      constexpr int j = 4 * sub + e / 2;
+      if constexpr (e % 2 == 0) stage_piece(u ^ 1, gr[u ^ 1][j], j);
+      else load_piece(gr[u ^ 1][j], j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto run = [&](auto U) {
+    for_seq([&](auto G) { step(G, U); }, std::make_integer_sequence<int, 24>{});
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    for_seq([&](auto G) { step(std::integral_constant<int, 24 + decltype(G)::value>{}, U); }, std::make_integer_sequence<int, 8>{});
+  };
+  for (int it0 = 0; it0 < n_iters; it0 += 2) {
+    next_tile_offsets();      // tile it0 + 3
+    run(std::integral_constant<int, 0>{});
+    next_tile_offsets();
+    run(std::integral_constant<int, 1>{});
+  }
+
+  // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // One straight-line copy per (epilogue kind, activation): with `epi` / `act` tested per element the 128 values of a
+  // lane went through ~1 000 scalar branches — 37 k cycles per tile (in-kernel stamps), a quarter of a 64-step k loop.
+  const bool add_bias = (p.bias != nullptr) && (ks == 0);
+  auto emit = [&](auto EPI_, auto ACT_) {
+    constexpr int epi = decltype(EPI_)::value, act = decltype(ACT_)::value;
+    if constexpr (epi == DVAE_EPI_ATOMIC) {
+      // bias into the accumulators FIRST: a bias load pending beside the atomics (both count in vmcnt) made hipcc put
+      // `s_waitcnt vmcnt(0)` in front of every one of the 128 atomics of a lane — each waited for the one before it
+      if (add_bias) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+          const float bv = col < p.N ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bv;
+        }
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < MTW / 2; ++half) {     // 64 rows = one BatchNorm statistics chunk
+      float bst[NTW][4];
+      int bmod = 0;
+      if constexpr (BNS) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bst[nt][q] = 0.f;
+        bmod = (m0 + wm * 128 + half * 64 + 4 * kh) % p.bn_nseg;
+      }
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const int mt = 2 * half + m2;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+          if (col >= p.N) continue;            // (N % 4 == 0: a quad of lanes is inside or outside as a whole)
+          const float bias_v = (epi != DVAE_EPI_ATOMIC && add_bias) ? p.bias[col] : 0.f;
+          const int row0 = m0 + wm * 128 + mt * 32 + 4 * kh;
+          float* cbase = C + (int64_t)row0 * p.ldc + col;
+          // Stores as 16 bytes per lane (a wave-instruction costs the store path ~70 cycles whatever its width).  The
+          // accumulator holds 4 consecutive ROWS of one column per lane (r & 3); a 4 x 4 transpose inside each quad of
+          // lanes (two DPP butterfly stages) turns them into 4 consecutive COLUMNS of one row.  Atomic accumulation
+          // keeps the scalar form (one 128-byte segment per row and instruction).
+          const int q4 = lane & 3;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e, dr = e + 8 * g;
+              const bool ok = row0 + dr < p.M;
+              float v = acc[mt][nt][r] + bias_v;
+              v = act_apply(v, act);     // (act is a constant here)
+              if constexpr (epi == DVAE_EPI_ATOMIC) {
+                if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
+              }
+              x[e] = v;
+              if constexpr (BNS) {
+                const int nseg = p.bn_nseg;
+                int rm = bmod + m2 * 32 + dr;
+                if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+                const float uu = ok ? v : 0.f;
+                const bool g1 = rm >= nseg / p.bn_groups;
+                bst[nt][0] += g1 ? 0.f : uu;
+                bst[nt][1] += g1 ? 0.f : uu * uu;
+                bst[nt][2] += g1 ? uu : 0.f;
+                bst[nt][3] += g1 ? uu * uu : 0.f;
+              }
+            }
+            if constexpr (epi != DVAE_EPI_ATOMIC) {
+              // stage 1: lane bit 0 <-> element bit 0 (quad_perm [1,0,3,2] = 0xB1); stage 2: bit 1 (quad_perm [2,3,0,1] = 0x4E)
+              float y[4], z[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
+                y[e] = ((q4 ^ e) & 1) ? o : x[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
+                z[e] = ((q4 ^ e) & 2) ? o : y[e];
+              }
+              // this lane now holds row (8 g + 4 kh + q4) of the tile, columns 4 (l31 >> 2) .. + 3
+              const int row = row0 + 8 * g + q4;
+              if (row < p.M) {
+                f32x4* dst = reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4));
+                f32x4 o4 = {z[0], z[1], z[2], z[3]};
+                if constexpr (epi == DVAE_EPI_ACCUM) o4 += *dst;
+                *dst = o4;
+              }
+            }
+          }
+        }
+      }
+      if constexpr (BNS) {
+        const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
+          if (kh == 0 && col < p.N && chunk < nchunks) {
+            double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
+            o[0] = (double)bst[nt][0];
+            o[1] = (double)bst[nt][1];
+            if (p.bn_groups > 1) {
+              o[(int64_t)p.N * 2] = (double)bst[nt][2];
+              o[(int64_t)p.N * 2 + 1] = (double)bst[nt][3];
+            }
+          }
+        }
+      }
+    }
+  };
+  using std::integral_constant;
+  if (p.epi == DVAE_EPI_ATOMIC) emit(integral_constant<int, DVAE_EPI_ATOMIC>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.epi == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.act == DVAE_ACT_NONE) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
+  else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_TANH>{});
+}
+
 // conv forward with BatchNorm statistics (k-contiguous operands, 128-row tiles, unsplit, plain store)
 void launch_bns(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, int bk, int mode) {
 #define BNS_LAUNCH(NTW_, BK_, MODE_) hipLaunchKernelGGL((gemm_f32_kernel<true, true, NTW_, BK_, 2, MODE_, true>), grid, dim3(256), 0, s, p)
@@ -1147,11 +1464,34 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
       zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
     }
     // one workgroup per CU: nothing hides a tile's prologue (cold loads) and epilogue (128 KB of C per CU), so the tile
-    // must be long: >= 60 k-steps (in the step: the convs, the weight gradients, the K = 1024 projections; shorter ones stay
+    // must be long: >= 24 k-steps (measured: 24 and 12 equal, 60 slower by 0.1 ms per step; shorter ones stay
     // on the 128 x 128 kernel, whose two workgroups per CU cover each other's ends)
-    static const int tall_min = getenv("DVAE_GEMM_TALL_MIN") ? atoi(getenv("DVAE_GEMM_TALL_MIN")) : 60;
+    static const int tall_min = getenv("DVAE_GEMM_TALL_MIN") ? atoi(getenv("DVAE_GEMM_TALL_MIN")) : 24;
     const int steps_per_tile = (kps / 16) * (p.tap_mode == 1 ? p.taps : 1);
     tall = (t2 * zdim >= 192 && steps_per_tile >= tall_min) || tall_env == 1;
+  }
+  // bf16 mode, both operands bf16 in memory, fp32 result: gemm_bf16_tall_kernel (64-deep k-tiles) under the same rules
+  bool tall16 = false;
+  if (bf && p.a16 && p.b16 && !p.c16 && tall_env != 0 && p.M >= 256 && p.N > 64 && (p.K % 64 == 0) &&
+      (p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.c_tap_stride % 4 == 0) &&
+      a_bytes < (1ll << 31) && b_bytes < (1ll << 31)) {      // (a_bytes / b_bytes above count 4 bytes per element)
+    int kps64 = ((kps + 63) / 64) * 64;
+    int sk64 = (p.K + kps64 - 1) / kps64;
+    const int t2 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    if (t2 * sk64 * (p.tap_mode == 2 ? p.taps : 1) < 192 && p.split_k > 1 && p.epi == DVAE_EPI_ATOMIC && kps64 >= 1024) {
+      kps64 = ((kps64 / 2 + 63) / 64) * 64;
+      sk64 = (p.K + kps64 - 1) / kps64;
+    }
+    const int z64 = sk64 * (p.tap_mode == 2 ? p.taps : 1);
+    static const int tall16_min = getenv("DVAE_GEMM_TALL16_MIN") ? atoi(getenv("DVAE_GEMM_TALL16_MIN")) : 8;
+    const int iters = (kps64 / 64) * (p.tap_mode == 1 ? p.taps : 1);
+    if (t2 * z64 >= 192 && iters >= tall16_min) {
+      tall16 = true;
+      kps = kps64;
+      p.k_per_split = kps;
+      p.split_k = sk64;
+      zdim = z64;
+    }
   }
   static const int big_env = getenv("DVAE_GEMM_BIG") ? atoi(getenv("DVAE_GEMM_BIG")) : -1;
   // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
@@ -1159,11 +1499,11 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0);
   if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0);
   if (mode != DVAE_MODE_F32) big = false;   // the 16-wave tile exists for the fp32 MFMA only (128 registers per lane)
-  const int bm = (big || tall) ? 256 : 128;
+  const int bm = (big || tall || tall16) ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
   // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
   const int tiles128 = p.tiles_m * ((p.N + 127) / 128) * zdim;
-  const bool narrow = !big && !tall && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
+  const bool narrow = !big && !tall && !tall16 && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
   const int bn = big ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
   static const int xcd_env = getenv("DVAE_GEMM_XCDMAP") ? atoi(getenv("DVAE_GEMM_XCDMAP")) : 1;
@@ -1171,7 +1511,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
   const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
-                       ((big ? 4u : tall ? 1u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15) |
+                       ((big ? 4u : (tall || tall16) ? 1u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15) |
                        ((unsigned)p.a16 << 17) | ((unsigned)p.b16 << 18) | ((p.bn_part ? 1u : 0u) << 19);
   // algorithmic bytes: every operand element once (the activation matrix of a conv once, not once per tap)
   const double ntap = p.tap_mode ? p.taps : 1;
@@ -1181,7 +1521,15 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap, tag, alg_bytes);
   if (p.bn_part && (!a_kc || !b_kc || big || p.split_k != 1 || p.epi != DVAE_EPI_STORE || p.act != DVAE_ACT_NONE))
     return DVAE_EINVAL;
-  if (tall) {
+  if (tall16) {
+#define TALL16(AK_, BK_, BNS_) hipLaunchKernelGGL((gemm_bf16_tall_kernel<AK_, BK_, BNS_>), grid, dim3(256), 0, s, p)
+    if (p.bn_part) TALL16(true, true, true);
+    else if (a_kc && b_kc) TALL16(true, true, false);
+    else if (a_kc && !b_kc) TALL16(true, false, false);
+    else if (!a_kc && b_kc) TALL16(false, true, false);
+    else TALL16(false, false, false);
+#undef TALL16
+  } else if (tall) {
 #define TALL(AK_, BK_, BNS_) hipLaunchKernelGGL((gemm_x3_tall_kernel<AK_, BK_, BNS_>), grid, dim3(256), 0, s, p)
     if (p.bn_part) TALL(true, true, true);
     else if (a_kc && b_kc) TALL(true, true, false);

@@ -865,8 +865,9 @@ def prof_collect_tags(max_tags: int = 64):
     for i in range(n):
         t = int(tags[i])
         bns, a16, b16 = (t >> 19) & 1, (t >> 17) & 1, (t >> 18) & 1
-        if (t >> 10) & 7 == 1:      # the 256 x 128 split-mode tile
-            name = f"gemm_x3_tall_kernel<A_KC={t & 1}, B_KC={(t >> 1) & 1}, BNS={bns}> tap_mode={(t >> 15) & 3}"
+        if (t >> 10) & 7 == 1:      # the 256 x 128 tile, one workgroup per CU
+            kn = "gemm_bf16_tall_kernel" if (t >> 13) & 3 == 1 else "gemm_x3_tall_kernel"
+            name = f"{kn}<A_KC={t & 1}, B_KC={(t >> 1) & 1}, BNS={bns}> tap_mode={(t >> 15) & 3}"
         else:
             name = (f"gemm_f32_kernel<A_KC={t & 1}, B_KC={(t >> 1) & 1}, NTW={(t >> 2) & 3}, BK={(t >> 4) & 63}, "
                     f"WG={(t >> 10) & 7}, MODE={(t >> 13) & 3}, BNS={bns}, A16={a16}, B16M={b16}> tap_mode={(t >> 15) & 3}")

@@ -400,11 +400,12 @@ def test_model_bf16_t512_losses_against_bf16_oracle(ops):
 
 
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 80), (1024, 512, 520)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 80), (1024, 512, 520), (16384, 512, 512)])
 def test_gemm_bf16_operands_in_memory(ops, a_kc, b_kc, M, N, K):
     """DVAE_MODE_A/B/C_BF16: operands that are ALREADY bf16 in memory (activations written as bf16 by their producers,
     bf16 weight copies) give bit-identical results to fp32 operands holding the same (bf16-exact) values — only the
-    staging differs — and a bf16 result is the rounded fp32 result."""
+    staging differs — and a bf16 result is the rounded fp32 result.  The last shape is large enough for the 256 x 128
+    kernel (gemm_bf16_tall_kernel, both operands bf16): it must reproduce the 128 x 128 kernel bit for bit."""
     a, b = r16(rnd(M, K, seed=1)), r16(rnd(K, N, seed=2))
     A = a if a_kc else a.t().contiguous()
     B = b.t().contiguous() if b_kc else b
