@@ -126,3 +126,50 @@ def test_mode_is_fixed_at_forward(ops):
     assert torch.equal(grads["x3"][0], grads["x3_flipped"][0])
     assert float((grads["x3"][1] - grads["x3_flipped"][1]).abs().max()) <= 1e-6 * float(grads["x3"][1].abs().max())
     assert not torch.equal(grads["x3"][0], grads["bf16"][0])
+
+
+# ------------------------------------------------------------------ the tall (256 x 128) kernels
+def _tall_case(ops, a_kc, b_kc, mode, bf16_storage):
+    """A shape the library runs on its tall kernel (>= 192 tiles of 256 x 128, long k): 16384 x 512 x 1024."""
+    M, N, K = 16384, 512, 1024
+    a, b = rnd(M, K, seed=11), rnd(K, N, seed=12) * 0.1
+    if bf16_storage:
+        a, b = a.bfloat16().float(), b.bfloat16().float()
+    A = (a if a_kc else a.t().contiguous()).cuda()
+    B = (b.t().contiguous() if b_kc else b).cuda()
+    flags = 0
+    if bf16_storage:
+        A, B, flags = A.bfloat16(), B.bfloat16(), ops.A_BF16 | ops.B_BF16
+    lda, ldb = (K if a_kc else M), (K if b_kc else N)
+
+    def full():
+        C = torch.empty(M, N, device="cuda")
+        ops.gemm(A, B, C, None, M, N, K, lda, ldb, N, a_kc, b_kc, 0, ops.EPI_STORE, 1, mode | flags)
+        return C
+
+    def by_column_blocks():
+        # the same product, 128 output columns at a time: 64 tiles per launch, which the library gives to the 128 x 128
+        # kernel.  Every output element sums the same partial products in the same order in both kernels.
+        C = torch.empty(M, N, device="cuda")
+        esz = B.element_size()
+        for n0 in range(0, N, 128):
+            bptr = B.data_ptr() + esz * (n0 * K if b_kc else n0)
+            ops.gemm(A.data_ptr(), bptr, C.data_ptr() + 4 * n0, None, M, 128, K, lda, ldb, N, a_kc, b_kc, 0,
+                     ops.EPI_STORE, 1, mode, flags=flags)
+        return C
+    return full, by_column_blocks, a, b
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("arith", ["fp32x3", "bf16"])
+def test_tall_kernel_equals_the_128x128_kernel_and_is_repeatable(ops, a_kc, b_kc, arith):
+    """gemm_x3_tall_kernel / gemm_bf16_tall_kernel (software-pipelined k loop, one barrier per k-tile, LDS buffers reused
+    across iterations): bit-identical to the 128 x 128 kernel on the same product, and 100 launches in a row give the same
+    bits (a race in the pipeline shows up as rare differing tiles)."""
+    mode = ops.MODE_F32X3 if arith == "fp32x3" else ops.MODE_BF16
+    full, blocks, a, b = _tall_case(ops, a_kc, b_kc, mode, arith == "bf16")
+    first = full()
+    assert err(first, a.double() @ b.double()) < (2e-6 if arith == "fp32x3" else 1e-5)
+    assert torch.equal(first, blocks()), "tall kernel != 128 x 128 kernel"
+    for i in range(100):
+        assert torch.equal(full(), first), f"launch {i} differs"
