@@ -30,9 +30,6 @@
 #ifndef DVAE_GEMM_ABL
 #define DVAE_GEMM_ABL 0
 #endif
-#ifndef DVAE_TALL_SCHED
-#define DVAE_TALL_SCHED 1   // gemm_x3_tall_kernel: 1 sched_group_barrier pipeline, 2 sched_barrier per MFMA group, 0 compiler's choice
-#endif
 #ifndef DVAE_X3_PD
 #define DVAE_X3_PD 2   // k-tiles in flight ahead of the one being computed (split mode), see the kernel
 #endif

@@ -129,9 +129,8 @@ def test_mode_is_fixed_at_forward(ops):
 
 
 # ------------------------------------------------------------------ the tall (256 x 128) kernels
-def _tall_case(ops, a_kc, b_kc, mode, bf16_storage):
-    """A shape the library runs on its tall kernel (>= 192 tiles of 256 x 128, long k): 16384 x 512 x 1024."""
-    M, N, K = 16384, 512, 1024
+def _tall_case(ops, a_kc, b_kc, mode, bf16_storage, M=16384, N=512, K=1024):
+    """A shape the library runs on its tall kernel (>= 192 tiles of 256 x 128, long k)."""
     a, b = rnd(M, K, seed=11), rnd(K, N, seed=12) * 0.1
     if bf16_storage:
         a, b = a.bfloat16().float(), b.bfloat16().float()
@@ -148,13 +147,14 @@ def _tall_case(ops, a_kc, b_kc, mode, bf16_storage):
         return C
 
     def by_column_blocks():
-        # the same product, 128 output columns at a time: 64 tiles per launch, which the library gives to the 128 x 128
+        # the same product, 128 output columns at a time: few tiles per launch, which the library gives to the 128 x 128
         # kernel.  Every output element sums the same partial products in the same order in both kernels.
         C = torch.empty(M, N, device="cuda")
         esz = B.element_size()
         for n0 in range(0, N, 128):
+            nb = min(128, N - n0)
             bptr = B.data_ptr() + esz * (n0 * K if b_kc else n0)
-            ops.gemm(A.data_ptr(), bptr, C.data_ptr() + 4 * n0, None, M, 128, K, lda, ldb, N, a_kc, b_kc, 0,
+            ops.gemm(A.data_ptr(), bptr, C.data_ptr() + 4 * n0, None, M, nb, K, lda, ldb, N, a_kc, b_kc, 0,
                      ops.EPI_STORE, 1, mode, flags=flags)
         return C
     return full, by_column_blocks, a, b
@@ -173,3 +173,21 @@ def test_tall_kernel_equals_the_128x128_kernel_and_is_repeatable(ops, a_kc, b_kc
     assert torch.equal(first, blocks()), "tall kernel != 128 x 128 kernel"
     for i in range(100):
         assert torch.equal(full(), first), f"launch {i} differs"
+
+
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (False, False), (True, False)])
+@pytest.mark.parametrize("arith", ["fp32x3", "bf16"])
+def test_tall_kernel_ragged_edges(ops, a_kc, b_kc, arith):
+    """Rows past M, columns past N and the last (partial) 256 x 128 tiles are handled by the raw-buffer bounds check and
+    the per-thread masks of the tall kernels: M = 16384 + 40 (40 rows in the last tile), N = 500 (116 columns in the last
+    tile); K a multiple of the k-tile (16 / 64: anything else goes to the 128 x 128 kernel, covered by the tests above)."""
+    mode = ops.MODE_F32X3 if arith == "fp32x3" else ops.MODE_BF16
+    K = 1040 if arith == "fp32x3" else 1088
+    if not a_kc or not b_kc:      # a row-contiguous bf16 operand needs row lengths that are multiples of 8
+        M, N = 16384 + 40, 504
+    else:
+        M, N = 16384 + 40, 500
+    full, blocks, a, b = _tall_case(ops, a_kc, b_kc, mode, arith == "bf16", M, N, K)
+    got = full()
+    assert err(got, a.double() @ b.double()) < (2e-6 if arith == "fp32x3" else 1e-5)
+    assert torch.equal(got, blocks())
