@@ -397,9 +397,11 @@ class DisentangledVAE(nn.Module):
         eps_c = torch.randn((2 * Bh, Cn), device=dev, dtype=torch.float32) if train else None
         return eps_c, torch.randn((Bh, S), device=dev, dtype=torch.float32)
 
-    def forward(self, x1, x2, train=True):
-        """-> (recons_x1, recons_x2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar, q_z2_mu, q_z2_logvar,
-        z_style_mu, z_style_logvar)   (disentangled_vae.py:250-279)"""
+    def forward_full(self, x1, x2, train=True):
+        """The forward pass with its outputs UNSPLIT: (rec, rec_hat, q_mu, q_lv, s_mu, s_lv) with rec / rec_hat [2*Bh, 80, T]
+        and q_mu / q_lv [2*Bh, Cn] holding the x1 half first.  `forward` returns the reference's ten tensors as views of
+        these; the training step hands the unsplit tensors to the fused loss (ops.LossGVAE2FullFn), so that autograd
+        has no slice to undo (each `t[:Bh]` costs a zero-fill and a copy in backward)."""
         self._check(x1)
         self._check(x2)
         self._refresh_derived()
@@ -417,6 +419,13 @@ class DisentangledVAE(nn.Module):
                                             w16=[self._w16(f"postnet.{i}") for i in range(5)])
         rec = FramesToMelFn.apply(y, N, N_MEL, T)
         rec_hat = FramesToMelFn.apply(y_hat, N, N_MEL, T)
+        return rec, rec_hat, q_mu, q_lv, s_mu, s_lv
+
+    def forward(self, x1, x2, train=True):
+        """-> (recons_x1, recons_x2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar, q_z2_mu, q_z2_logvar,
+        z_style_mu, z_style_logvar)   (disentangled_vae.py:250-279)"""
+        rec, rec_hat, q_mu, q_lv, s_mu, s_lv = self.forward_full(x1, x2, train)
+        Bh = x1.shape[0]
         return (rec[:Bh], rec[Bh:], rec_hat[:Bh], rec_hat[Bh:], q_mu[:Bh], q_lv[:Bh], q_mu[Bh:], q_lv[Bh:],
                 s_mu, s_lv)
 
@@ -459,6 +468,12 @@ class ConvolutionalMulVAE(VariationalBaseModelVAE):
         The variables are named MSE_* in the reference but are L1 sums divided by the CONFIGURED batch size."""
         return self.losses_vector(x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar,
                                   q_z2_mu, q_z2_logvar, style_mu1, style_logvar1).unbind(0)
+
+    def losses_vector_full(self, x1, x2, rec, rec_hat, q_mu, q_lv, s_mu, s_lv):
+        """losses_vector on the unsplit outputs of `DisentangledVAE.forward_full` (the training step's path)."""
+        inv_b = 1.0 / float(self.batch_size)
+        return ops.LossGVAE2FullFn.apply(x1, x2, rec, rec_hat, q_mu, q_lv, s_mu, s_lv, inv_b, -0.5 / x1.shape[0], -inv_b,
+                                         self.mse_cof, self.kl_cof)
 
     def losses_vector(self, x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar, q_z2_mu,
                       q_z2_logvar, style_mu1, style_logvar1):

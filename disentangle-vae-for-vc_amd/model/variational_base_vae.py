@@ -89,16 +89,24 @@ class VariationalBaseModelVAE:
 
     def _eager_train_step(self, data1, data2):
         self.optimizer.zero_grad()
-        outs = self.model(data1, data2)
-        if hasattr(self, "losses_vector"):
-            vec = self.losses_vector(data1, data2, *outs)      # the eight scalars as one vector (fused loss kernels)
-            losses = (vec[0],)
+        if hasattr(self, "losses_vector_full") and hasattr(self.model, "forward_full"):
+            # the eight scalars as one vector (fused loss kernels) on the UNSPLIT outputs; backward is seeded with the
+            # constant (1, 0, ..., 0): `vec[0].backward()` and the reference's ten output slices cost ~25 zero-fill /
+            # copy launches of autograd glue per step
+            vec = self.losses_vector_full(data1, data2, *self.model.forward_full(data1, data2))
+            losses = None
         else:
             vec = None
-            losses = self.loss_functionGVAE2(data1, data2, *outs, train=True)
+            losses = self.loss_functionGVAE2(data1, data2, *self.model(data1, data2), train=True)
         if self.reducer is not None:
             self.reducer.begin()
-        losses[0].backward()
+        if vec is not None:
+            if getattr(self, "_loss_seed", None) is None or self._loss_seed.device != vec.device:
+                self._loss_seed = torch.zeros(8, device=vec.device)
+                self._loss_seed[0] = 1.0
+            torch.autograd.backward(vec, self._loss_seed)
+        else:
+            losses[0].backward()
         scale = 1.0
         if self.reducer is not None:
             self.reducer.finish()

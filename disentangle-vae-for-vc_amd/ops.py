@@ -850,6 +850,58 @@ class LossGVAE2Fn(torch.autograd.Function):
         return (None, None, *[grads[i] if need[i] else None for i in range(2, 12)], None, None, None, None, None)
 
 
+class LossGVAE2FullFn(torch.autograd.Function):
+    """LossGVAE2Fn on the UNSPLIT forward outputs (model.forward_full): rec / rec_hat [2*Bh, ...] and q_mu / q_lv
+    [2*Bh, Cn] hold the x1 half first, so the kernels get the halves as pointer offsets and backward writes both halves of
+    one full-size gradient tensor — autograd never sees a slice (whose backward is a zero-fill plus a copy)."""
+
+    @staticmethod
+    def _desc(x1, x2, rec, rec_hat, q_mu, q_lv, s_mu, s_lv, scales):
+        d = _lib.LossDesc()
+        n, nq = x1.numel(), q_mu.numel() // 2
+        d.x1, d.x2 = ptr(x1), ptr(x2)
+        d.recon1, d.recon2 = rec.data_ptr(), rec.data_ptr() + 4 * n
+        d.recon1_hat, d.recon2_hat = rec_hat.data_ptr(), rec_hat.data_ptr() + 4 * n
+        d.q1_mu, d.q2_mu = q_mu.data_ptr(), q_mu.data_ptr() + 4 * nq
+        d.q1_lv, d.q2_lv = q_lv.data_ptr(), q_lv.data_ptr() + 4 * nq
+        d.s_mu, d.s_lv = ptr(s_mu), ptr(s_lv)
+        d.n, d.nq, d.ns = n, nq, s_mu.numel()
+        d.l1_scale, d.kl_scale, d.style_scale, d.mse_cof, d.kl_cof = scales
+        return d
+
+    @staticmethod
+    def forward(ctx, x1, x2, rec, rec_hat, q_mu, q_lv, s_mu, s_lv, l1_scale, kl_scale, style_scale, mse_cof, kl_cof):
+        ts = [t.contiguous() for t in (x1, x2, rec, rec_hat, q_mu, q_lv, s_mu, s_lv)]
+        _ok(*ts)
+        if not (ts[0].numel() == ts[1].numel() and ts[2].numel() == ts[3].numel() == 2 * ts[0].numel()):
+            raise ValueError("loss: reconstructions must hold the x1 and the x2 half")
+        if not (ts[4].numel() == ts[5].numel() and ts[4].numel() % 2 == 0 and ts[6].numel() == ts[7].numel()):
+            raise ValueError("loss: mu / logvar shapes do not match")
+        scales = (float(l1_scale), float(kl_scale), float(style_scale), float(mse_cof), float(kl_cof))
+        L = lib()
+        out = torch.empty(8, device=ts[0].device, dtype=torch.float32)
+        ws = torch.empty((L.dvae_loss_ws_bytes(ts[0].numel()),), device=ts[0].device, dtype=torch.uint8)
+        d = LossGVAE2FullFn._desc(*ts, scales)
+        check(L.dvae_loss_fwd(C.byref(d), ptr(out), ptr(ws), stream()), "dvae_loss_fwd")
+        ctx.save_for_backward(*ts)
+        ctx.scales = scales
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        g = g.contiguous()
+        grads = [torch.empty_like(t) for t in ts[2:]]            # rec, rec_hat, q_mu, q_lv, s_mu, s_lv
+        d = LossGVAE2FullFn._desc(*ts, ctx.scales)
+        n, nq = ts[0].numel(), ts[4].numel() // 2
+        gp = lambda t, off=0: t.data_ptr() + 4 * off
+        check(lib().dvae_loss_bwd(C.byref(d), ptr(g), gp(grads[0]), gp(grads[0], n), gp(grads[1]), gp(grads[1], n),
+                                  gp(grads[2]), gp(grads[3]), gp(grads[2], nq), gp(grads[3], nq), gp(grads[4]), gp(grads[5]),
+                                  stream()), "dvae_loss_bwd")
+        need = ctx.needs_input_grad
+        return (None, None, *[grads[i] if need[i + 2] else None for i in range(6)], None, None, None, None, None)
+
+
 def prof_enable(family: int):
     check(lib().dvae_prof_enable(family), "dvae_prof_enable")
 
