@@ -17,7 +17,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 BF = int(os.environ.get("LSTM_MODE", "0"))        # DVAE_MODE_*: 0 fp32 MFMA, 1 bf16, 2 fp32x3 (three bf16 planes)
 S16 = int(os.environ.get("LSTM_S16", "0")) if BF == 1 else 0   # bf16 mode: h / dgates stored as bf16
 sdt = torch.bfloat16 if S16 else torch.float32
-T, N = 128, 128
+T, N = 128, int(os.environ.get("LSTM_N", "128"))
 L = lib()
 nl = 2 if stack else 1
 dev = "cuda"
