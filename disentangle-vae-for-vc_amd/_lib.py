@@ -22,7 +22,7 @@ class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
                 ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_mode", i32),
-                ("step_shift", i32), ("state_bf16", i32)]
+                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint)]
 
 
 class RepackDesc(C.Structure):
@@ -47,6 +47,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
+ABI_VERSION = 300     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
@@ -69,6 +70,9 @@ SIGNATURES = {
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_x3": (i32, [vp, vp, vp, i32, vp]),
     "dvae_repack_all": (i32, [C.POINTER(RepackDesc), i32, vp]),
+    "dvae_lstm_pers_ws_bytes": (i64, [i32, i32]),
+    "dvae_lstm_pers_check": (i32, [vp, C.POINTER(i32), vp]),
+    "dvae_lstm_pers_selftest": (i32, [C.POINTER(LstmDir), i32, i32, i32, i64, i32, vp]),
     "dvae_lstm_seq_fwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_bwd": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, vp]),
     "dvae_lstm_seq_fwd_range": (i32, [C.POINTER(LstmDir), i32, i32, i32, i32, i64, i32, i32, vp]),
@@ -137,6 +141,10 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        got = h.dvae_version()
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI {got}, this binding is for {ABI_VERSION} (include/dvae_hip.h): "
+                               "stale library — rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = h
         # process default of the contraction arithmetic (ops.set_compute_dtype changes it): fp32 results on the bf16
         # matrix pipe unless the environment says otherwise

@@ -5,7 +5,7 @@
 
 int g_dvae_last_hip_error = 0;
 
-DVAE_API int dvae_version(void) { return 100; }
+DVAE_API int dvae_version(void) { return DVAE_ABI_VERSION; }
 DVAE_API int dvae_last_hip_error(void) { return g_dvae_last_hip_error; }
 
 namespace {

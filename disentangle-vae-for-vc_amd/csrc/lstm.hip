@@ -997,8 +997,12 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
 
 }  // namespace
 
+// lstm_pers.hip: the W_hh-resident persistent recurrence (one launch per sequence)
+int dvae_pers_usable(int N, int H, int pm);
+int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, int64_t ldh, int drop_bid, hipStream_t s);
+
 namespace {
-// Three kernel families, chosen by H alone (every one of them is reached by tests/test_hip_kernels.py::test_lstm_layer):
+// Kernel families, chosen by H (and, for the persistent one, by the caller handing in a workspace) (every one of them is reached by tests/test_hip_kernels.py::test_lstm_layer):
 //   H == 64            lstm_seq_*_h64      whole sequence in one launch, W_hh in registers
 //   H % 512 == 0       lstm_step_*_v5      one launch per frame, fragment-packed W_hh (needs dirs[i].w_packed)
 //   other H % 64 == 0  lstm_step_*_kernel  one launch per frame, W_hh staged through LDS (generic fallback)
@@ -1031,6 +1035,8 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
+  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm))
+    return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_fwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
@@ -1085,6 +1091,8 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
+  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm))
+    return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_bwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);

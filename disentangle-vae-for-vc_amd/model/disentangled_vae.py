@@ -314,7 +314,10 @@ class DisentangledVAE(nn.Module):
         """x16: bf16 data of x when x is a placeholder (output of a conv block in the bf16 compute mode).
         Returns (h, h16) the same way: h16 is None unless the layer keeps its state in bf16 (then h is the placeholder)."""
         mod = getattr(self, mname)
-        if LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
+        from ..derived import lstm_pack_modes
+        pers = ops.lstm_persistent_usable(n_seg, mod.hidden_size, lstm_pack_modes(ops.current_mode(), mod.hidden_size)[0],
+                                          2 if mod.bidirectional else 1)
+        if not pers and LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
             # two stacked layers of equal width share their frame launches (ops.LstmStack2Fn)
             der = self._lstm_der(mname, 0, False) + self._lstm_der(mname, 1, False)
             return LstmStack2Fn.apply(x, T, n_seg, *mod.layer(0)[:4], *mod.layer(1)[:4], der, x16, True)

@@ -422,6 +422,41 @@ class ConvBnActFn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- LSTM layer
+# W_hh-resident persistent recurrence (csrc/lstm_pers.hip): one launch per sequence where the shape has such a kernel
+# (bf16 compute mode, H = 512 / 1024, (H/32) * ceil(N/32) <= CU count); DVAE_LSTM_PERSISTENT=0 keeps one launch per frame.
+LSTM_PERSISTENT = os.environ.get("DVAE_LSTM_PERSISTENT", "1") != "0"
+LSTM_PERS_TIMEOUT_US = 0                    # 0: the library's default bound (2 s) on every cross-workgroup wait
+_PERS_WS_BYTES = 8192 + 2 * 16 * 128 * 2 * 1024     # the largest workspace any supported (N, H) needs
+_pers_ws: dict = {}
+
+
+def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1) -> bool:
+    return bool(LSTM_PERSISTENT and ndir == 1 and int(mode) == MODE_BF16 and lib().dvae_lstm_pers_ws_bytes(N, H) > 0)
+
+
+def lstm_pers_workspace(dev) -> torch.Tensor:
+    """Flags + sticky error record + exchange ring of the persistent LSTM launches of one device (zeroed once; every
+    launch re-zeroes its flags with a memset node of its own; launches of one stream share it)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    ws = _pers_ws.get(key)
+    if ws is None:
+        ws = _pers_ws[key] = torch.zeros(_PERS_WS_BYTES, device=f"cuda:{key}", dtype=torch.uint8)
+        assert ws.data_ptr() % 256 == 0
+    return ws
+
+
+def lstm_pers_check():
+    """Synchronises the current stream of every device that ran a persistent LSTM launch and raises if a bounded
+    cross-workgroup wait gave up (the launch's outputs are garbage then).  Call where the host synchronises anyway."""
+    for key, ws in _pers_ws.items():
+        info = (C.c_int * 4)()
+        with torch.cuda.device(key):
+            rc = lib().dvae_lstm_pers_check(ptr(ws), info, stream())
+        if rc != 0:
+            raise _lib.DvaeHipError(f"persistent LSTM launch gave up a bounded wait: pass {info[0]} (1 fwd, 2 bwd), "
+                                    f"workgroup {info[1]}, step {info[2]}, wave {info[3]} (rc={rc})")
+
+
 def _lstm_derived(derived, params, mode):
     """Per direction: (bias sum, W_ih^T, W_hh^T, fragment packs) — from the model's DerivedWeights when given, else
     computed on the spot (stand-alone use)."""
@@ -478,6 +513,9 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].c_all = ptr(c)
             dirs[d].reverse = d
             dirs[d].state_bf16 = int(s16)
+        pers = lstm_persistent_usable(N, H, bf, ndir)
+        if pers:
+            dirs[0].pers_ws, dirs[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
         ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
         ctx.der = der
@@ -528,6 +566,8 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].dc_ws = ptr(dc)
             dirs[d].reverse = d
             dirs[d].state_bf16 = int(s16)
+        if lstm_persistent_usable(N, H, bf, ndir):
+            dirs[0].pers_ws, dirs[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         dx = None
         if ctx.needs_input_grad[0]:

@@ -42,6 +42,9 @@ extern "C" {
 #define DVAE_EPI_ACCUM 1  /* C += result (plain read-modify-write, no split-K) */
 #define DVAE_EPI_ATOMIC 2 /* C += result with global_atomic_add_f32 (split-K allowed) */
 
+/* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
+ * refuses anything else: a stale .so would misread the argument lists below) */
+#define DVAE_ABI_VERSION 300
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -165,6 +168,12 @@ typedef struct {
   int state_bf16;     /* bf16 mode only: h_out (forward call) / dgates (backward call) are bf16 tensors — the storage their
                          consumers (the next frame, the next layer's projection, the weight gradients) read; the same
                          element strides */
+  void* pers_ws;      /* optional: >= dvae_lstm_pers_ws_bytes(N, H) bytes, 256-byte aligned, zero-initialised ONCE by the
+                         caller.  When given to a plain one-direction dvae_lstm_seq_fwd / _bwd call whose shape has a
+                         persistent kernel (bf16 mode, H = 512 / 1024, (H/32) * ceil(N/32) <= CU count), the whole sequence
+                         runs in ONE W_hh-resident launch (csrc/lstm_pers.hip) instead of one launch per frame; same
+                         arithmetic, same tensors.  One workspace serves every layer run on one stream */
+  unsigned pers_timeout_us; /* bound of every cross-workgroup wait of that launch (0: 2 s); see dvae_lstm_pers_check */
 } dvae_lstm_dir_t;
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
@@ -196,6 +205,18 @@ typedef struct {
   void* dst2;
 } dvae_repack_desc_t;
 int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
+
+/* ---- W_hh-resident persistent recurrence (nn.LSTM at disentangled_vae.py:172,193; H = 512 / 1024, bf16 mode) ----
+ * dvae_lstm_pers_ws_bytes: size of the synchronisation workspace (flags + sticky error record + exchange ring) for
+ *   (N, H); 0 when the shape has no persistent kernel.
+ * dvae_lstm_pers_check: SYNCHRONISES `stream`, then returns DVAE_ELAUNCH if a bounded wait of any persistent launch on
+ *   this workspace gave up since the last check (info4 = {code 1 fwd / 2 bwd, workgroup, step, wave}; the outputs of
+ *   that launch are garbage), DVAE_OK otherwise.  Not capturable; call it wherever the host synchronises anyway.
+ * dvae_lstm_pers_selftest: a forward launch in which workgroup `drop_bid` never publishes — every waiter must give up
+ *   within dir->pers_timeout_us and dvae_lstm_pers_check must then report it (tests/test_hip_lstm_pers.py). */
+int64_t dvae_lstm_pers_ws_bytes(int N, int H);
+int dvae_lstm_pers_check(void* ws, int* info4, void* stream);
+int dvae_lstm_pers_selftest(const dvae_lstm_dir_t* dir, int T, int N, int H, int64_t ldh, int drop_bid, void* stream);
 
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
 int dvae_lstm_seq_bwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);

@@ -17,7 +17,8 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 BF = int(os.environ.get("LSTM_MODE", "0"))        # DVAE_MODE_*: 0 fp32 MFMA, 1 bf16, 2 fp32x3 (three bf16 planes)
 S16 = int(os.environ.get("LSTM_S16", "0")) if BF == 1 else 0   # bf16 mode: h / dgates stored as bf16
 sdt = torch.bfloat16 if S16 else torch.float32
-T, N = 128, int(os.environ.get("LSTM_N", "128"))
+T, N = int(os.environ.get("LSTM_T", "128")), int(os.environ.get("LSTM_N", "128"))
+PERS = int(os.environ.get("LSTM_PERS", "0"))      # 1: the W_hh-resident persistent launch (one per sequence; unstacked only)
 L = lib()
 nl = 2 if stack else 1
 dev = "cuda"
@@ -45,6 +46,9 @@ def dirs(bwd):
         d[i].h_out, d[i].dh_out, d[i].dgates, d[i].dc_ws = ptr(y["h"]), ptr(y["dh"]), ptr(y["dg"]), ptr(y["dc"])
         d[i].reverse, d[i].packed_mode, d[i].step_shift = 0, (MB if bwd else MF), (T // 2 if (stack and i == 1) else 0)
         d[i].state_bf16 = S16
+        if PERS and not stack:
+            from dvae_amd import ops
+            d[i].pers_ws = ptr(ops.lstm_pers_workspace(dev))
     return d
 
 
@@ -87,7 +91,10 @@ def copy_only():
 cp = timeit(copy_only)
 tf = timeit(fwd, cp)
 tb = timeit(bwd)
+if PERS:
+    from dvae_amd import ops
+    ops.lstm_pers_check()
 per = T * nl
-print(f"H={H} stack={stack} mode={BF} s16={S16}: fwd {1e3 * tf / per:.2f} us/layer-frame ({tf:.3f} ms), bwd {1e3 * tb / per:.2f} us/layer-frame "
+print(f"H={H} N={N} T={T} stack={stack} mode={BF} s16={S16} pers={PERS}: fwd {1e3 * tf / per:.2f} us/layer-frame ({tf:.3f} ms), bwd {1e3 * tb / per:.2f} us/layer-frame "
       f"({tb:.3f} ms)  [lib {os.path.basename(_lib.LIB_PATH)}]", flush=True)
 assert torch.isfinite(layers[-1]["h"].float()).all() and torch.isfinite(layers[0]["dg"].float()).all()

@@ -1,0 +1,173 @@
+"""W_hh-resident persistent LSTM recurrence (csrc/lstm_pers.hip; nn.LSTM at /root/reference/model/disentangled_vae.py:172,193).
+
+One launch walks all T frames; workgroups hand h[t] / dG[t] to each other through flags.  Checked here, through the C ABI:
+  * against the one-launch-per-frame kernels on the same inputs (same arithmetic, other summation order), every shape
+    class: H = 512 / 1024, 16- and 32-row workgroups, ragged N, reverse direction, bf16 and fp32 state storage;
+  * hand-offs under UNEVEN load (a second stream hammering HBM meanwhile), repeated, every word compared;
+  * a 10 000-frame soak;
+  * the bounded spin: a workgroup that never publishes makes every waiter give up inside the timeout and
+    dvae_lstm_pers_check report DVAE_ELAUNCH; the next launch on the same workspace is clean.
+(The bf16 oracle comparison of the same path is tests/test_hip_bf16.py::test_lstm_layer_bf16, which runs LstmLayerFn.)"""
+import time
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def env():
+    import dvae_amd  # noqa: F401
+    from dvae_amd import _lib, ops
+    from dvae_amd.derived import lstm_local
+    ops.set_compute_dtype("bf16")
+    yield _lib, ops, lstm_local
+    ops.set_compute_dtype(ops.DEFAULT_COMPUTE_DTYPE)
+
+
+class Layer:
+    """Buffers of one LSTM layer-direction for direct dvae_lstm_seq_fwd / _bwd calls."""
+
+    def __init__(self, env, T, N, H, s16, reverse=0, seed=0):
+        _lib, ops, lstm_local = env
+        self.env, self.T, self.N, self.H, self.s16, self.reverse = env, T, N, H, s16, reverse
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        f = dict(device="cuda", dtype=torch.float32)
+        sdt = torch.bfloat16 if s16 else torch.float32
+        self.w_hh = (torch.rand(4 * H, H, generator=g, **f) * 2 - 1) / H ** 0.5
+        w_ih = torch.zeros(4 * H, 64, **f)
+        b = torch.zeros(4 * H, **f)
+        self.der = lstm_local(w_ih, self.w_hh, b, b, _lib.MODE_BF16)
+        self.gates0 = (torch.rand(T * N, 4 * H, generator=g, **f) * 2 - 1)
+        self.dh = (torch.rand(T * N, H, generator=g, **f) * 2 - 1) * 0.1
+        self.gates = torch.empty(T * N, 4 * H, **f)
+        self.h = torch.empty(T * N, H, device="cuda", dtype=sdt)
+        self.c = torch.empty(T * N, H, **f)
+        self.dg = torch.empty(T * N, 4 * H, device="cuda", dtype=sdt)
+        self.dc = torch.empty(N, H, **f)
+
+    def dirs(self, bwd, pers, timeout_us=0):
+        _lib, ops, _ = self.env
+        ptr = _lib.ptr
+        d = (_lib.LstmDir * 1)()
+        d[0].gates, d[0].c_all = ptr(self.gates), ptr(self.c)
+        d[0].w_hh = ptr(self.der.w_hh_t if bwd else self.w_hh)
+        d[0].w_packed = ptr(self.der.pack_b if bwd else self.der.pack_f)
+        d[0].h_out, d[0].dh_out, d[0].dgates, d[0].dc_ws = ptr(self.h), ptr(self.dh), ptr(self.dg), ptr(self.dc)
+        d[0].reverse, d[0].packed_mode, d[0].step_shift, d[0].state_bf16 = self.reverse, _lib.MODE_BF16, 0, int(self.s16)
+        if pers:
+            d[0].pers_ws, d[0].pers_timeout_us = ptr(ops.lstm_pers_workspace("cuda")), timeout_us
+        return d
+
+    def run(self, pers, timeout_us=0):
+        """forward + backward; returns clones of (gates, c, h, dgates)"""
+        _lib, ops, _ = self.env
+        L, st = _lib.lib(), _lib.stream()
+        self.gates.copy_(self.gates0)
+        self.h.fill_(float("nan"))
+        self.dg.fill_(float("nan"))
+        _lib.check(L.dvae_lstm_seq_fwd(self.dirs(False, pers, timeout_us), 1, self.T, self.N, self.H, self.H, st), "fwd")
+        _lib.check(L.dvae_lstm_seq_bwd(self.dirs(True, pers, timeout_us), 1, self.T, self.N, self.H, self.H, st), "bwd")
+        if pers:
+            ops.lstm_pers_check()
+        return [t.float().clone() for t in (self.gates, self.c, self.h, self.dg)]
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def compare(got, ref, tag):
+    # same products, another fp32 summation order; the state / gate gradients are ROUNDED to bf16 for the next frame on
+    # both sides, so a last-bit difference in front of a rounding can flip one bf16 ulp (2^-8) of single elements:
+    # relative L2 over the tensor stays tiny, no element may be further away than a few bf16 ulps
+    for name, g, r in zip(("gates", "c", "h", "dgates"), got, ref):
+        assert torch.isfinite(g).all(), f"{tag}: {name} not finite"
+        e = rel_l2(g, r)
+        assert e < 2e-3, f"{tag}: {name} rel-L2 {e:.3e}"
+        worst = float((g - r).abs().max())
+        scale = float(r.abs().max())
+        assert worst <= 2e-2 * scale, f"{tag}: {name} max |diff| {worst:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("H,T,N,s16,reverse", [
+    (512, 6, 128, True, 0),      # 16 x 8 = 128 workgroups of 16 rows
+    (512, 5, 256, True, 0),      # 16 x 16 = 256 workgroups
+    (1024, 8, 128, True, 0),     # configs[1]/[4] per-GPU shape: 32 x 8 workgroups of 16 rows
+    (1024, 6, 256, True, 0),     # configs[2]: 32 x 8 workgroups of 32 rows
+    (1024, 4, 17, True, 0),      # ragged: 2 row blocks, the second with one live row
+    (512, 3, 40, False, 0),      # fp32 state storage
+    (1024, 5, 128, False, 1),    # reverse direction, fp32 state storage
+    (1024, 1, 128, True, 0),     # a single frame: nothing is ever handed over
+])
+def test_persistent_matches_frame_kernels(env, H, T, N, s16, reverse):
+    _lib, ops, _ = env
+    assert ops.lstm_persistent_usable(N, H, _lib.MODE_BF16)
+    lay = Layer(env, T, N, H, s16, reverse, seed=H + T + N)
+    ref = lay.run(pers=False)
+    got = lay.run(pers=True)
+    compare(got, ref, f"H={H} T={T} N={N} s16={s16} rev={reverse}")
+
+
+def test_persistent_handoffs_under_uneven_load(env):
+    """A second stream streams 1 GiB copies through HBM while the persistent launches run: hand-offs must not depend on
+    timing.  Every output word is compared with the per-frame kernels' each round."""
+    lay = Layer(env, 48, 256, 1024, True, seed=5)
+    ref = lay.run(pers=False)
+    side = torch.cuda.Stream()
+    a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+    b = torch.empty_like(a)
+    for rnd in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(rnd):          # 0 .. 5 GiB of foreign traffic: the load differs round to round
+                b.copy_(a)
+        got = lay.run(pers=True)
+        compare(got, ref, f"uneven load, round {rnd}")
+    torch.cuda.synchronize()
+
+
+def test_persistent_soak_10000_frames(env):
+    """10 000 frames in ONE launch per pass (forward and backward): no hang, no drift against the per-frame kernels."""
+    T, N, H = 10000, 32, 1024
+    lay = Layer(env, T, N, H, True, seed=9)
+    ref = lay.run(pers=False)
+    t0 = time.time()
+    got = lay.run(pers=True)
+    dt = time.time() - t0
+    compare(got, ref, "soak")
+    # the last frames of each pass in particular (the end of a 10 000-deep dependency chain)
+    for g, r in zip(got, ref):
+        assert rel_l2(g[-N:], r[-N:]) < 5e-3 and rel_l2(g[:N], r[:N]) < 5e-3
+    assert dt < 60.0, f"soak took {dt:.1f} s"
+
+
+def test_bounded_spin_gives_up_and_reports(env):
+    """Workgroup 3 never publishes: every waiter must give up within the timeout (here 20 ms), the launch must END, and
+    dvae_lstm_pers_check must turn the sticky record into DVAE_ELAUNCH; the next launch on the workspace is clean."""
+    _lib, ops, _ = env
+    L, st = _lib.lib(), _lib.stream()
+    lay = Layer(env, 16, 128, 1024, True, seed=3)
+    ref = lay.run(pers=False)
+    lay.gates.copy_(lay.gates0)
+    d = lay.dirs(False, True, timeout_us=20000)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _lib.check(L.dvae_lstm_pers_selftest(d, lay.T, lay.N, lay.H, lay.H, 3, st), "selftest")
+    with pytest.raises(_lib.DvaeHipError, match="gave up"):
+        ops.lstm_pers_check()
+    dt = time.time() - t0
+    assert dt < 5.0, f"the give-up took {dt:.2f} s"
+    ops.lstm_pers_check()                   # the record is cleared once reported
+    got = lay.run(pers=True)
+    compare(got, ref, "after a timed-out launch")
+
+
+def test_workspace_size_contract(env):
+    _lib, ops, _ = env
+    L = _lib.lib()
+    assert L.dvae_lstm_pers_ws_bytes(128, 1024) > 0 and L.dvae_lstm_pers_ws_bytes(256, 1024) > 0
+    assert L.dvae_lstm_pers_ws_bytes(128, 64) == 0 and L.dvae_lstm_pers_ws_bytes(128, 768) == 0
+    assert L.dvae_lstm_pers_ws_bytes(600, 1024) == 0           # would need more workgroups than CUs
+    for N, H in ((128, 512), (256, 512), (512, 512), (128, 1024), (256, 1024), (17, 1024)):
+        assert L.dvae_lstm_pers_ws_bytes(N, H) <= ops.lstm_pers_workspace("cuda").numel()
