@@ -35,30 +35,44 @@ namespace {
 
 typedef unsigned u32x4v __attribute__((__vector_size__(16)));
 
-constexpr int PERS_FLAG_LD = 64;              // flag words per row group (H/32 <= 32 producers, padded to 256 B)
+// Flags: one 128-byte line per producer (32 producers x 128 B per row group).  Packed into one line (32 producers x 4 B)
+// the write-through flag stores of a group and its pollers all hit ONE line and a frame took 6.7 us instead of 3.7
+// (H = 1024, N = 128, measured): partial-line stores of 32 CUs serialise behind each other.
+constexpr int PERS_FLAG_STRIDE = 32;          // words between the flags of two producers
+constexpr int PERS_FLAG_LD = 32 * PERS_FLAG_STRIDE;   // words per row group (H/32 <= 32 producers)
 constexpr int PERS_MAX_RB = 16;               // row groups
-constexpr int PERS_FLAG_BYTES = PERS_MAX_RB * PERS_FLAG_LD * 4;   // 4 KiB, zeroed by a memset node before every launch
+constexpr int PERS_FLAG_BYTES = PERS_MAX_RB * PERS_FLAG_LD * 4;   // 64 KiB; a launch zeroes the n_rb groups it uses
 constexpr int PERS_ERR_OFF = PERS_FLAG_BYTES; // sticky error record: 16 words (never cleared by a launch)
-constexpr int PERS_XCH_OFF = 8192;            // exchange ring
+constexpr int PERS_XCH_OFF = PERS_FLAG_BYTES + 4096;   // exchange ring
 constexpr int PERS_PAD_LDS = 84 * 1024;       // total LDS per workgroup >= this: exactly one workgroup fits a CU
 
 struct PersArgs {
   float* gates;          // [T,N,4H]
   const char* wp;        // fragment pack (forward: packed_fwd, backward: packed_bwd), bf16
-  char* h_out;           // forward: [T,N,ldh] bf16 (S16) or fp32
+  char* h_out;           // forward: [T,N,ldh] bf16 (s16) or fp32
   float* c_all;          // [T,N,H]
   const float* dh_out;   // backward: [T,N,ldh]
-  char* dgates;          // backward: [T,N,4H] bf16 (S16) or fp32
+  char* dgates;          // backward: [T,N,4H] bf16 (s16) or fp32
   unsigned* flags;       // ws + 0
   unsigned* err;         // ws + PERS_ERR_OFF
   char* xch;             // ws + PERS_XCH_OFF
   int T, N;
   int64_t ldh;
-  int reverse, n_rb;
+  int reverse, n_rb, s16;
   unsigned timeout;      // 100 MHz ticks
   int xch_bytes;
   int drop_bid;          // self-test: this workgroup never publishes (-1: none)
+#ifdef DVAE_PERS_TS
+  unsigned long long* ts;   // dev build: [frame][wave][8] s_memrealtime stamps of workgroup ts_bid (scripts/lstm_pers_timeline.py)
+  int ts_bid;
+#endif
 };
+
+#ifdef DVAE_PERS_TS
+#define PERS_STAMP(p_) do { if (a.ts && bid == a.ts_bid && lane == 0) a.ts[((int64_t)step * 8 + wave) * 8 + (p_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PERS_STAMP(p_) do {} while (0)
+#endif
 
 // wave-level bounded poll: lanes with `active` re-read their word until every one of them has reached `target`
 __device__ __forceinline__ bool poll_ge(const unsigned* p, bool active, unsigned target, unsigned timeout) {
@@ -83,54 +97,73 @@ __device__ __forceinline__ void pers_give_up(unsigned* err, int code, int bid, i
   }
 }
 
+// Frame structure of both kernels (four waves; wave 3 polls, wave 0 publishes, wave 1 archives the bf16 state):
+//   [wave 3: bounded poll of the group's flags]  barrier A
+//   every wave: sc1 loads of its k-quarter of the handed-over fragments -> MFMAs against its resident W_hh fragments
+//               (next frame's epilogue operands are fetched meanwhile) -> partial tiles to LDS (16-byte accesses)  barrier B
+//   fused epilogue on 2*MT elements per thread; the new state goes to LDS in fragment order, everything else the frame
+//   leaves in HBM goes to an LDS staging tile                                                                     barrier C
+//   wave 0: payload (sc1) -> drain -> flag;   meanwhile waves 1..3 (wave 0 joins): whole-line stores of the staging tile
+constexpr int NWV = 4;
+
 // ======================================================================================================================
 // forward:  G = Xproj[t] + h[t-1] W_hh^T ; i,f,o = sigmoid, g = tanh ; c = f c' + i g ; h = o tanh(c)
 // ======================================================================================================================
-template <int H, int MT, bool S16>
-__global__ __launch_bounds__(256, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
+// KL = k-chunks of a wave's W_hh slice kept in LDS instead of registers (MT = 2 at H = 1024: 256 registers of W_hh
+// next to 64 accumulators and the fragments in flight spilled; 64 KB of LDS are free)
+template <int MT, int KL>
+struct FwdLds {
+  bf16x8 wl[KL > 0 ? NWV : 1][4][2][KL > 0 ? KL : 1][64];   // [wave][g][u][k - KR][lane]
+  f32x4 red[NWV][MT * 8][64];            // partial gate tiles [wave][(mt*4+g)*2+u][lane]
+  float stage[16 * MT][6 * 32 + 4];      // per row: activated i,f,g,o, c, h (fp32) of the 32 units -> whole-line stores
+                                         // (+4: rows 4 apart — the q groups of a wave — land in different banks)
+  __bf16 hx[MT][16][40];                 // h in A-fragment order (32 units + pad per row)
+  int dead;
+};
+
+template <int H, int MT, int KL>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
   constexpr int NCH = H / 32;           // 32-deep k-chunks of h = producers of a row group
-  constexpr int KW = NCH / 4;           // chunks (= producers) per wave
-  constexpr int NEL = 2 * MT;           // (segment, unit) elements per thread
+  constexpr int KW = NCH / NWV;         // chunks per wave
+  constexpr int KR = KW - KL;           // ... of which in registers
+  constexpr int NEL = 2 * MT;           // (segment, unit) elements per thread: e = e0 .. e0 + NEL - 1 of ONE (mt, u) tile
   constexpr int PD = (KW * MT > 8) ? KW / 2 : KW;   // chunks of h[t-1] in flight (registers: 256 hold W_hh)
-  using h_t = typename std::conditional<S16, __bf16, float>::type;
+  typedef float fvec __attribute__((ext_vector_type(NEL)));
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;
   const int rb = bid % a.n_rb, jb = bid / a.n_rb;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
+  const bool s16 = a.s16 != 0;
 
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  float (*red)[MT * 32][64] = reinterpret_cast<float (*)[MT * 32][64]>(lds_raw);            // [wave][(mt,g,u,e)][lane]
-  __bf16 (*hx)[16][40] = reinterpret_cast<__bf16 (*)[16][40]>(lds_raw + 4 * MT * 32 * 64 * 4);   // [mt][row][32 units + pad]
-  volatile int* dead = reinterpret_cast<volatile int*>(lds_raw + 4 * MT * 32 * 64 * 4 + MT * 16 * 40 * 2);
+  FwdLds<MT, KL>& L = *reinterpret_cast<FwdLds<MT, KL>*>(lds_raw);
+  volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
 
   // resident W_hh fragments: gate g, 16-unit tile u, chunk k of this wave's k-quarter
-  bf16x8 W[4][2][KW];
+  bf16x8 W[4][2][KR];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int k = 0; k < KW; ++k)
-        W[g][u][k] = *reinterpret_cast<const bf16x8*>(
+      for (int k = 0; k < KW; ++k) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(
             a.wp + ((((int64_t)(g * (H / 16) + 2 * jb + u)) * NCH + wave * KW + k) * 64 + lane) * 16);
+        if (k < KR) W[g][u][k < KR ? k : 0] = w;
+        else L.wl[wave][g][u][k >= KR ? k - KR : 0][lane] = w;
+      }
 
-  // this thread's elements: accumulator-layout positions (mt, u, e) of the 16*MT x 32 tile
-  int el_row[NEL], el_unit[NEL], el_red[NEL];
-  int64_t el_n[NEL];
-  bool el_ok[NEL];
+  // this thread's elements: accumulator-layout positions e0 .. e0+NEL-1 of tile (mt, u): rows mt*16 + q*4 + e, unit u*16 + r
+  const int tile = (wave * NEL) >> 2, e0 = (wave * NEL) & 3, emt = tile >> 1, eu = tile & 1;
+  const int erow0 = emt * 16 + q * 4 + e0, eunit = eu * 16 + r;
+  int el_n[NEL];
   float creg[NEL];
 #pragma unroll
   for (int i = 0; i < NEL; ++i) {
-    const int s = wave * NEL + i, tile = s >> 2, e = s & 3, mt = tile >> 1, u = tile & 1;
-    el_row[i] = mt * 16 + q * 4 + e;
-    el_unit[i] = u * 16 + r;
-    el_red[i] = (mt * 8 + u) * 4 + e;          // + g*8 (gate stride) inside red
-    const int n = rb * 16 * MT + el_row[i];
-    el_ok[i] = n < N;
-    el_n[i] = min(n, N - 1);
+    el_n[i] = min(rb * 16 * MT + erow0 + i, N - 1);
     creg[i] = 0.f;
   }
   const int j0 = jb * 32;
@@ -140,16 +173,16 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
   const int slot_bytes = a.n_rb * NCH * MT * 1024;
   const int xld = (rb * NCH + wave * KW) * MT * 1024 + lane * 16;      // this wave's first fragment inside a slot
   const int xst = (rb * NCH + jb) * MT * 1024 + lane * 16;             // where this workgroup publishes
-  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD + wave * KW + (lane < KW ? lane : 0);
-  unsigned* myflag = a.flags + rb * PERS_FLAG_LD + jb;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD + (lane < NCH ? lane : 0) * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD + jb * PERS_FLAG_STRIDE;
 
   auto fetch = [&](int step_, float (&x)[NEL][4]) {
     const int t_ = a.reverse ? (T - 1 - step_) : step_;
-    const float* __restrict__ G_ = a.gates + (int64_t)t_ * N * H4 + j0;
+    const float* __restrict__ G_ = a.gates + (int64_t)t_ * N * H4 + j0 + eunit;
 #pragma unroll
     for (int i = 0; i < NEL; ++i)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) x[i][g] = G_[el_n[i] * H4 + g * H + el_unit[i]];
+      for (int g = 0; g < 4; ++g) x[i][g] = G_[(int64_t)el_n[i] * H4 + g * H];
   };
 
   auto frame = [&](int step, float (&xp)[NEL][4], float (&xn)[NEL][4]) -> bool {
@@ -162,11 +195,14 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[mt][g][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    PERS_STAMP(0);
     if (step > 0) {
-      if (!poll_ge(pflag, lane < KW, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 1, bid, step, wave);
         *dead = 1;
       }
+      __syncthreads();                                             // barrier A
+      PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the loads below the poll
       const int so = ((step - 1) & 1) * slot_bytes;
       bf16x8 av[PD][MT];                      // PD chunks of h[t-1] in flight
@@ -182,12 +218,14 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
 #pragma unroll
       for (int k = 0; k < KW; ++k) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+          for (int u = 0; u < 2; ++u) {
+            const bf16x8 w = (k < KR) ? W[g][u][k < KR ? k : 0] : L.wl[wave][g][u][k >= KR ? k - KR : 0][lane];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-              acc[mt][g][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[k % PD][mt], W[g][u][k], acc[mt][g][u], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt)
+              acc[mt][g][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[k % PD][mt], w, acc[mt][g][u], 0, 0, 0);
+          }
         if (k + PD < KW) {
           __builtin_amdgcn_sched_barrier(0);
           load(k + PD);
@@ -202,59 +240,81 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) red[wave][((mt * 4 + g) * 2 + u) * 4 + e][lane] = acc[mt][g][u][e];
-    __syncthreads();
+        for (int u = 0; u < 2; ++u) L.red[wave][(mt * 4 + g) * 2 + u][lane] = acc[mt][g][u];
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
     if (*dead) return false;
 
-    float* __restrict__ G = a.gates + (int64_t)t * N * H4 + j0;
-#pragma unroll
-    for (int i = 0; i < NEL; ++i) {
-      float gsum[4];
+    {
+      fvec gs[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int ri = el_red[i] + g * 8;
-        gsum[g] = (red[0][ri][lane] + red[1][ri][lane]) + (red[2][ri][lane] + red[3][ri][lane]) + xp[i][g];
+        const int ti = (emt * 4 + g) * 2 + eu;
+        fvec sacc = *reinterpret_cast<const fvec*>(reinterpret_cast<const float*>(&L.red[0][ti][lane]) + e0);
+#pragma unroll
+        for (int w = 1; w < NWV; ++w)
+          sacc += *reinterpret_cast<const fvec*>(reinterpret_cast<const float*>(&L.red[w][ti][lane]) + e0);
+        gs[g] = sacc;
       }
-      const float gi = gate_sigmoid(gsum[0]);
-      const float gf = gate_sigmoid(gsum[1]);
-      const float gg = gate_tanh(gsum[2]);
-      const float go = gate_sigmoid(gsum[3]);
-      const float c = gf * creg[i] + gi * gg;
-      const float h = go * gate_tanh(c);
-      creg[i] = c;
-      hx[el_row[i] >> 4][el_row[i] & 15][el_unit[i]] = (__bf16)h;
-      if (el_ok[i]) {
-        float* g = G + el_n[i] * H4 + el_unit[i];
-        g[0] = gi;
-        g[H] = gf;
-        g[2 * H] = gg;
-        g[3 * H] = go;
-        a.c_all[((int64_t)t * N + el_n[i]) * H + j0 + el_unit[i]] = c;
-        if constexpr (!S16)
-          reinterpret_cast<float*>(a.h_out)[((int64_t)t * N + el_n[i]) * a.ldh + j0 + el_unit[i]] = h;
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const float gi = gate_sigmoid(gs[0][i] + xp[i][0]);
+        const float gf = gate_sigmoid(gs[1][i] + xp[i][1]);
+        const float gg = gate_tanh(gs[2][i] + xp[i][2]);
+        const float go = gate_sigmoid(gs[3][i] + xp[i][3]);
+        const float c = gf * creg[i] + gi * gg;
+        const float h = go * gate_tanh(c);
+        creg[i] = c;
+        const int row = erow0 + i;
+        L.hx[row >> 4][row & 15][eunit] = (__bf16)h;
+        L.stage[row][0 * 32 + eunit] = gi;
+        L.stage[row][1 * 32 + eunit] = gf;
+        L.stage[row][2 * 32 + eunit] = gg;
+        L.stage[row][3 * 32 + eunit] = go;
+        L.stage[row][4 * 32 + eunit] = c;
+        L.stage[row][5 * 32 + eunit] = h;
       }
     }
-    __syncthreads();
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
+    // lane (r, q) of a wave: units 8q..8q+7 of row r = the 16 bytes of the A fragment AND of the bf16 h_out row
     if (wave == 0) {
-      // lane (r, q) holds units 8q..8q+7 of row r: the 16 bytes of the A fragment AND of the bf16 h_out row
-      const bool pub = (step + 1 < T) && (bid != a.drop_bid);
-      const int so = (step & 1) * slot_bytes;
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&L.hx[mt][r][q * 8]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + mt * 1024, so, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through payload has left before the flag does
+        PERS_STAMP(6);
+        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (wave == 1 && s16) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&hx[mt][r][q * 8]);
-        if (pub) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v),
-                                                        xrs, xst + mt * 1024, so, 16);
-        if constexpr (S16) {
-          const int n = rb * 16 * MT + mt * 16 + r;
-          if (n < N)
-            *reinterpret_cast<f32x4*>(reinterpret_cast<h_t*>(a.h_out) + ((int64_t)t * N + n) * a.ldh + j0 + q * 8) = v;
-        }
+        const int n = rb * 16 * MT + mt * 16 + r;
+        if (n < N)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.h_out) + ((int64_t)t * N + n) * a.ldh + j0 + q * 8) =
+              *reinterpret_cast<const f32x4*>(&L.hx[mt][r][q * 8]);
       }
-      if (pub) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through payload has left before the flag does
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the frame's fp32 outputs: 16-byte pieces of whole 128-byte lines, off the hand-off's critical path
+    {
+      const int npc = s16 ? 5 : 6;                       // i, f, g, o, c (, h when the state is kept in fp32)
+      const int pieces = 16 * MT * npc * 8;
+      for (int p = tid; p < pieces; p += 64 * NWV) {
+        const int row = p / (npc * 8), rem = p - row * (npc * 8), k = rem >> 3, seg = rem & 7;
+        const int n = rb * 16 * MT + row;
+        if (n < N) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(&L.stage[row][k * 32 + seg * 4]);
+          float* dst = k < 4 ? a.gates + ((int64_t)t * N + n) * H4 + k * H + j0 + seg * 4
+                     : k == 4 ? a.c_all + ((int64_t)t * N + n) * H + j0 + seg * 4
+                              : reinterpret_cast<float*>(a.h_out) + ((int64_t)t * N + n) * a.ldh + j0 + seg * 4;
+          *reinterpret_cast<f32x4*>(dst) = v;
+        }
       }
     }
     return true;
@@ -272,51 +332,58 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_fwd_bf16(const PersArgs a) {
 // ======================================================================================================================
 // backward:  dH = dHout[t] + dG[t+1] W_hh ; gate derivatives -> dG[t] ; dC carry in registers
 // ======================================================================================================================
-template <int H, int MT, bool S16>
-__global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
+template <int MT, int KL>
+struct BwdLds {
+  bf16x8 wl[KL > 0 ? NWV : 1][4][2][KL > 0 ? KL : 1][64];   // [wave][g][u][k - KR][lane]
+  f32x4 red[NWV][MT * 2][64];            // partial dH tiles [wave][mt*2+u][lane]
+  float stage[16 * MT][4 * 32 + 4];      // fp32 dG (state kept in fp32 only)
+  __bf16 gx[4 * MT][16][40];             // dG in A-fragment order [(g, mt)][row][32 units + pad]
+  int dead;
+};
+
+template <int H, int MT, int KL>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
   constexpr int NCH = H / 32;           // chunks per gate = producers of a row group
-  constexpr int KW = NCH / 4;
+  constexpr int KW = NCH / NWV;
+  constexpr int KR = KW - KL;
   constexpr int NEL = 2 * MT;
   constexpr int NC = 4 * KW;            // chunks a wave contracts per frame (its unit quarter of all four gates)
-  constexpr int PD = (NC >= 16 && MT == 1) ? 8 : 4;   // chunks of dG in flight (registers: 256 hold W_hh)
-  using g_t = typename std::conditional<S16, __bf16, float>::type;
+  constexpr int PD = (NC * MT > 32) ? 4 : (NC > 8 ? 8 : NC);   // chunks of dG in flight (registers: 256 hold W_hh)
+  typedef float fvec __attribute__((ext_vector_type(NEL)));
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;
   const int rb = bid % a.n_rb, jb = bid / a.n_rb;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
+  const bool s16 = a.s16 != 0;
 
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  float (*red)[MT * 8][64] = reinterpret_cast<float (*)[MT * 8][64]>(lds_raw);                 // [wave][(mt,u,e)][lane]
-  __bf16 (*gx)[16][40] = reinterpret_cast<__bf16 (*)[16][40]>(lds_raw + 4 * MT * 8 * 64 * 4);    // [(g,mt)][row][32 units + pad]
-  volatile int* dead = reinterpret_cast<volatile int*>(lds_raw + 4 * MT * 8 * 64 * 4 + 4 * MT * 16 * 40 * 2);
+  BwdLds<MT, KL>& L = *reinterpret_cast<BwdLds<MT, KL>*>(lds_raw);
+  volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
 
   // resident W_hh fragments (rows g*H + k-quarter of this wave, columns = the 32 units of this workgroup)
-  bf16x8 W[4][2][KW];
+  bf16x8 W[4][2][KR];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int k = 0; k < KW; ++k)
-        W[g][u][k] = *reinterpret_cast<const bf16x8*>(
+      for (int k = 0; k < KW; ++k) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(
             a.wp + ((((int64_t)((2 * jb + u) * 4 + g)) * NCH + wave * KW + k) * 64 + lane) * 16);
+        if (k < KR) W[g][u][k < KR ? k : 0] = w;
+        else L.wl[wave][g][u][k >= KR ? k - KR : 0][lane] = w;
+      }
 
-  int el_row[NEL], el_unit[NEL], el_red[NEL];
-  int64_t el_n[NEL];
-  bool el_ok[NEL];
+  const int tile = (wave * NEL) >> 2, e0 = (wave * NEL) & 3, emt = tile >> 1, eu = tile & 1;
+  const int erow0 = emt * 16 + q * 4 + e0, eunit = eu * 16 + r;
+  int el_n[NEL];
   float dcreg[NEL], ccreg[NEL];
 #pragma unroll
   for (int i = 0; i < NEL; ++i) {
-    const int s = wave * NEL + i, tile = s >> 2, e = s & 3, mt = tile >> 1, u = tile & 1;
-    el_row[i] = mt * 16 + q * 4 + e;
-    el_unit[i] = u * 16 + r;
-    el_red[i] = (mt * 2 + u) * 4 + e;
-    const int n = rb * 16 * MT + el_row[i];
-    el_ok[i] = n < N;
-    el_n[i] = min(n, N - 1);
+    el_n[i] = min(rb * 16 * MT + erow0 + i, N - 1);
     dcreg[i] = 0.f;
   }
   const int j0 = jb * 32;
@@ -326,8 +393,8 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
   const int slot_bytes = a.n_rb * 4 * NCH * MT * 1024;
   const int xld = (rb * 4 * NCH + wave * KW) * MT * 1024 + lane * 16;     // + g*NCH*MT*1024 per gate
   const int xst = (rb * 4 * NCH + jb) * MT * 1024 + lane * 16;
-  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD + wave * KW + (lane < KW ? lane : 0);
-  unsigned* myflag = a.flags + rb * PERS_FLAG_LD + jb;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD + (lane < NCH ? lane : 0) * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD + jb * PERS_FLAG_STRIDE;
 
   struct Ops {
     float gt[NEL][4], cp[NEL], dho[NEL];
@@ -339,9 +406,9 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
 #pragma unroll
     for (int i = 0; i < NEL; ++i) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) o.gt[i][g] = a.gates[((int64_t)t_ * N + el_n[i]) * H4 + g * H + j0 + el_unit[i]];
-      o.cp[i] = a.c_all[((int64_t)tp_ * N + el_n[i]) * H + j0 + el_unit[i]];
-      o.dho[i] = a.dh_out[((int64_t)t_ * N + el_n[i]) * a.ldh + j0 + el_unit[i]];
+      for (int g = 0; g < 4; ++g) o.gt[i][g] = a.gates[((int64_t)t_ * N + el_n[i]) * H4 + g * H + j0 + eunit];
+      o.cp[i] = a.c_all[((int64_t)tp_ * N + el_n[i]) * H + j0 + eunit];
+      o.dho[i] = a.dh_out[((int64_t)t_ * N + el_n[i]) * a.ldh + j0 + eunit];
     }
   };
 
@@ -354,11 +421,14 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) acc[mt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    PERS_STAMP(0);
     if (step > 0) {
-      if (!poll_ge(pflag, lane < KW, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
+      __syncthreads();                                             // barrier A
+      PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int so = ((step - 1) & 1) * slot_bytes;
       // chunk c of this wave: gate g = c / KW, chunk k = c % KW of its k-quarter; PD chunks in flight
@@ -378,10 +448,12 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
       for (int c = 0; c < NC; ++c) {
         const int g = c / KW, k = c % KW;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int u = 0; u < 2; ++u) {
+          const bf16x8 w = (k < KR) ? W[g][u][k < KR ? k : 0] : L.wl[wave][g][u][k >= KR ? k - KR : 0][lane];
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
-            acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[c % PD][mt], W[g][u][k], acc[mt][u], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[c % PD][mt], w, acc[mt][u], 0, 0, 0);
+        }
         if (c + PD < NC) {
           __builtin_amdgcn_sched_barrier(0);
           load(c + PD);
@@ -394,58 +466,76 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) red[wave][(mt * 2 + u) * 4 + e][lane] = acc[mt][u][e];
-    __syncthreads();
+      for (int u = 0; u < 2; ++u) L.red[wave][mt * 2 + u][lane] = acc[mt][u];
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
     if (*dead) return false;
 
+    {
+      const int ti = emt * 2 + eu;
+      fvec rec = *reinterpret_cast<const fvec*>(reinterpret_cast<const float*>(&L.red[0][ti][lane]) + e0);
 #pragma unroll
-    for (int i = 0; i < NEL; ++i) {
-      const int ri = el_red[i];
-      const float rec = (red[0][ri][lane] + red[1][ri][lane]) + (red[2][ri][lane] + red[3][ri][lane]);
-      const float dh = cur.dho[i] + rec;
-      const float gi = cur.gt[i][0], gf = cur.gt[i][1], gg = cur.gt[i][2], go = cur.gt[i][3];
-      const float cp = fstep > 0 ? cur.cp[i] : 0.f;
-      const float tc = gate_tanh(ccreg[i]);
-      const float dc = dcreg[i] + dh * go * (1.f - tc * tc);
-      float o[4];
-      o[0] = dc * gg * gi * (1.f - gi);
-      o[1] = dc * cp * gf * (1.f - gf);
-      o[2] = dc * gi * (1.f - gg * gg);
-      o[3] = dh * tc * go * (1.f - go);
-      dcreg[i] = dc * gf;
-      ccreg[i] = cp;                      // c[t-1] is the cell state of the next (earlier) frame
+      for (int w = 1; w < NWV; ++w)
+        rec += *reinterpret_cast<const fvec*>(reinterpret_cast<const float*>(&L.red[w][ti][lane]) + e0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gx[g * MT + (el_row[i] >> 4)][el_row[i] & 15][el_unit[i]] = (__bf16)o[g];
-      if constexpr (!S16) {
-        if (el_ok[i]) {
-          float* dst = reinterpret_cast<float*>(a.dgates) + ((int64_t)t * N + el_n[i]) * H4 + j0 + el_unit[i];
+      for (int i = 0; i < NEL; ++i) {
+        const float dh = cur.dho[i] + rec[i];
+        const float gi = cur.gt[i][0], gf = cur.gt[i][1], gg = cur.gt[i][2], go = cur.gt[i][3];
+        const float cp = fstep > 0 ? cur.cp[i] : 0.f;
+        const float tc = gate_tanh(ccreg[i]);
+        const float dc = dcreg[i] + dh * go * (1.f - tc * tc);
+        float o[4];
+        o[0] = dc * gg * gi * (1.f - gi);
+        o[1] = dc * cp * gf * (1.f - gf);
+        o[2] = dc * gi * (1.f - gg * gg);
+        o[3] = dh * tc * go * (1.f - go);
+        dcreg[i] = dc * gf;
+        ccreg[i] = cp;                      // c[t-1] is the cell state of the next (earlier) frame
+        const int row = erow0 + i;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) dst[g * H] = o[g];
+        for (int g = 0; g < 4; ++g) L.gx[g * MT + (row >> 4)][row & 15][eunit] = (__bf16)o[g];
+        if (!s16) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) L.stage[row][g * 32 + eunit] = o[g];
         }
       }
     }
-    __syncthreads();
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
     if (wave == 0) {
-      const bool pub = (step + 1 < T) && (bid != a.drop_bid);
-      const int so = (step & 1) * slot_bytes;
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(&gx[g * MT + mt][r][q * 8]);
-          if (pub) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v),
-                                                          xrs, xst + (g * NCH * MT + mt) * 1024, so, 16);
-          if constexpr (S16) {
-            const int n = rb * 16 * MT + mt * 16 + r;
-            if (n < N)
-              *reinterpret_cast<f32x4*>(reinterpret_cast<g_t*>(a.dgates) + ((int64_t)t * N + n) * H4 + g * H + j0 + q * 8) = v;
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&L.gx[g * MT + mt][r][q * 8]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + (g * NCH * MT + mt) * 1024, so, 16);
           }
-        }
-      if (pub) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_STAMP(6);
         if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (s16) {
+      // waves 1..3 archive dG[t] (bf16, whole 64-byte row pieces) for the weight-gradient / dx contractions
+      for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
+        const int g = f / MT, mt = f - g * MT;
+        const int n = rb * 16 * MT + mt * 16 + r;
+        if (n < N)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<__bf16*>(a.dgates) + ((int64_t)t * N + n) * H4 + g * H + j0 + q * 8) =
+              *reinterpret_cast<const f32x4*>(&L.gx[f][r][q * 8]);
+      }
+    }
+    if (!s16) {
+      const int pieces = 16 * MT * 4 * 8;
+      for (int p = tid; p < pieces; p += 64 * NWV) {
+        const int row = p >> 5, k = (p >> 3) & 3, seg = p & 7;
+        const int n = rb * 16 * MT + row;
+        if (n < N)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dgates) + ((int64_t)t * N + n) * H4 + k * H + j0 + seg * 4) =
+              *reinterpret_cast<const f32x4*>(&L.stage[row][k * 32 + seg * 4]);
       }
     }
     return true;
@@ -455,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
   {
     const int t0 = frame_t(0);
 #pragma unroll
-    for (int i = 0; i < NEL; ++i) ccreg[i] = a.c_all[((int64_t)t0 * N + el_n[i]) * H + j0 + el_unit[i]];
+    for (int i = 0; i < NEL; ++i) ccreg[i] = a.c_all[((int64_t)t0 * N + el_n[i]) * H + j0 + eunit];
   }
   Ops oa, ob;
   fetch(0, oa);
@@ -466,6 +556,10 @@ __global__ __launch_bounds__(256, 1) void lstm_pers_bwd_bf16(const PersArgs a) {
   }
 }
 
+#ifdef DVAE_PERS_TS
+unsigned long long* g_pers_ts = nullptr;
+int g_pers_ts_bid = 0;
+#endif
 int g_pers_cus = -1;
 int pers_cu_count() {
   if (g_pers_cus < 0) {
@@ -485,6 +579,25 @@ int pers_mt(int N, int H, int cus) {
     if (n_rb <= PERS_MAX_RB && n_jb * n_rb <= cus) return mt;
   }
   return 0;
+}
+
+#ifndef PERS_KL
+#define PERS_KL 2
+#endif
+template <int H, int MT>
+int pers_launch_one(bool bwd, const PersArgs& a, int grid, hipStream_t s) {
+  // LDS: partial tiles + staging + fragment-ordered state (+ part of W_hh); padded so that exactly one workgroup fits a CU
+  constexpr int KL = (H == 1024 && MT == 2) ? PERS_KL : 0;
+  const int need = bwd ? (int)sizeof(BwdLds<MT, KL>) : (int)sizeof(FwdLds<MT, KL>);
+  const int lds = need > PERS_PAD_LDS ? need : PERS_PAD_LDS;
+  auto kern = bwd ? lstm_pers_bwd_bf16<H, MT, KL> : lstm_pers_fwd_bf16<H, MT, KL>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[bwd]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set[bwd] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, s, a);
+  return dvae_check_launch();
 }
 
 }  // namespace
@@ -517,40 +630,25 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   a.dh_out = d.dh_out; a.dgates = (char*)d.dgates;
   char* ws = (char*)d.pers_ws;
   a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
-  a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse;
+  a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = s16 ? 1 : 0;
   a.n_rb = (N + 16 * mt - 1) / (16 * mt);
   const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
   a.timeout = us > 40000000u ? 4000000000u : us * 100u;
   a.xch_bytes = 2 * a.n_rb * (bwd ? 4 : 1) * (H / 32) * mt * 1024;
   a.drop_bid = drop_bid;
+#ifdef DVAE_PERS_TS
+  a.ts = g_pers_ts;
+  a.ts_bid = g_pers_ts_bid;
+#endif
   const int grid = (H / 32) * a.n_rb;
-  if (hipMemsetAsync(ws, 0, PERS_FLAG_BYTES, s) != hipSuccess) return dvae_check_launch() ? DVAE_ELAUNCH : DVAE_ELAUNCH;
-#define PERS_LAUNCH(K, H_, MT_, S_)                                                                      \
-  do {                                                                                                   \
-    auto kern = K<H_, MT_, S_>;                                                                          \
-    static bool attr_set = false;                                                                        \
-    if (!attr_set) {                                                                                     \
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PERS_PAD_LDS); \
-      attr_set = true;                                                                                   \
-    }                                                                                                    \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), PERS_PAD_LDS, s, a);                                 \
-  } while (0)
-#define PERS_DISPATCH(K)                                            \
-  do {                                                              \
-    if (H == 1024 && mt == 1 && s16) PERS_LAUNCH(K, 1024, 1, true); \
-    else if (H == 1024 && mt == 2 && s16) PERS_LAUNCH(K, 1024, 2, true); \
-    else if (H == 1024 && mt == 1) PERS_LAUNCH(K, 1024, 1, false);  \
-    else if (H == 1024) PERS_LAUNCH(K, 1024, 2, false);             \
-    else if (mt == 1 && s16) PERS_LAUNCH(K, 512, 1, true);          \
-    else if (mt == 2 && s16) PERS_LAUNCH(K, 512, 2, true);          \
-    else if (mt == 1) PERS_LAUNCH(K, 512, 1, false);                \
-    else PERS_LAUNCH(K, 512, 2, false);                             \
-  } while (0)
-  if (bwd) PERS_DISPATCH(lstm_pers_bwd_bf16);
-  else PERS_DISPATCH(lstm_pers_fwd_bf16);
-#undef PERS_DISPATCH
-#undef PERS_LAUNCH
-  return dvae_check_launch();
+  if (hipMemsetAsync(ws, 0, (size_t)a.n_rb * PERS_FLAG_LD * 4, s) != hipSuccess) {
+    g_dvae_last_hip_error = (int)hipGetLastError();
+    return DVAE_ELAUNCH;
+  }
+  if (H == 1024 && mt == 1) return pers_launch_one<1024, 1>(bwd, a, grid, s);
+  if (H == 1024) return pers_launch_one<1024, 2>(bwd, a, grid, s);
+  if (mt == 1) return pers_launch_one<512, 1>(bwd, a, grid, s);
+  return pers_launch_one<512, 2>(bwd, a, grid, s);
 }
 
 DVAE_API int dvae_lstm_pers_check(void* ws, int* info4, void* stream) {
@@ -577,3 +675,12 @@ DVAE_API int dvae_lstm_pers_selftest(const dvae_lstm_dir_t* dir, int T, int N, i
   if (!dir) return DVAE_EINVAL;
   return dvae_pers_launch(*dir, false, T, N, H, ldh, drop_bid, (hipStream_t)stream);
 }
+
+#ifdef DVAE_PERS_TS
+// dev build only (scripts/lstm_pers_timeline.py): stamps of workgroup `bid` go to buf[frame][wave][8]
+DVAE_API int dvae_lstm_pers_set_ts(void* buf, int bid) {
+  g_pers_ts = (unsigned long long*)buf;
+  g_pers_ts_bid = bid;
+  return DVAE_OK;
+}
+#endif

@@ -49,6 +49,7 @@ class GradReducer:
                 self.pending_init.append(count)
                 lo, count = end, 0
         self.pending = list(self.pending_init)
+        self.next_bucket = 0    # buckets are LAUNCHED in buffer order on every rank, whatever order they complete in
         self.works = []
         self.active = False
         self.force = False      # issue the collective even with one rank (tests of the RCCL path)
@@ -57,6 +58,7 @@ class GradReducer:
 
     def begin(self):
         self.pending = list(self.pending_init)
+        self.next_bucket = 0
         self.works = []
         self.active = True
         ops.grad_ready_hook = self._ready
@@ -74,9 +76,13 @@ class GradReducer:
         if b is None:
             return
         self.pending[b] -= 1
-        if self.pending[b] == 0:
+        # Collectives pair up across ranks by ISSUE order, so bucket b goes out only after buckets 0..b-1 have: a rank
+        # whose hooks fire in another order (or that skips a parameter) still issues the same sequence as its peers.
+        # The flat buffer is laid out in backward-completion order, so in the normal case nothing waits.
+        while self.next_bucket < len(self.buckets) and self.pending[self.next_bucket] == 0:
             self.stats["hook"] += 1
-            self._launch(b)
+            self._launch(self.next_bucket)
+            self.next_bucket += 1
 
     def finish(self):
         """Enqueue whatever was not triggered (parameters without gradient this step) and join."""
@@ -84,10 +90,10 @@ class GradReducer:
         ops.join_side()
         self.active = False
         self.stats["steps"] += 1
-        for b, left in enumerate(self.pending):
-            if left > 0:
-                self.stats["finish"] += 1
-                self._launch(b)
+        for b in range(self.next_bucket, len(self.buckets)):
+            self.stats["finish"] += 1
+            self._launch(b)
+        self.next_bucket = len(self.buckets)
         for w in self.works:
             w.wait()
         self.works = []

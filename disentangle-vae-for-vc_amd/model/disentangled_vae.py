@@ -440,6 +440,13 @@ class DisentangledVAE(nn.Module):
             return mod.torch_layout(tensor)
         return tensor
 
+    def storage_layout(self, name, tensor):
+        """Inverse of reference_layout: a tensor in the reference's layout -> how parameter `name` is stored here."""
+        mod = self.get_submodule(name.rsplit(".", 1)[0])
+        if isinstance(mod, _Conv1dParams) and name.endswith(".weight"):
+            return tensor.permute(2, 0, 1)
+        return tensor
+
     def update_c(self):
         self._c += self._c_delta
 
@@ -462,7 +469,7 @@ class ConvolutionalMulVAE(VariationalBaseModelVAE):
         n_frames = width if n_frames is None else n_frames
         self.model = DisentangledVAE(latent_dim=self.latent_dim, beta=0.1, batch_size=batch_size,
                                      speaker_size=speaker_size, n_frames=n_frames).to(device)
-        self.optimizer = FlatAdam(self.model.backward_param_order(), lr=self.lr)
+        self.optimizer = FlatAdam(self.model.backward_param_order(), lr=self.lr, layout=self.model)
         self.train_losses, self.test_losses = [], []
 
     def loss_functionGVAE2(self, x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar,

@@ -72,20 +72,24 @@ class VariationalBaseModelVAE:
         1/batch_size, BatchNorm train/eval, shapes): `_graph_signature` is compared on every step and the graph is
         re-captured when any of them changed, so `optimizer.param_groups[0]['lr'] = ...`, `update_kl()` or
         `model.eval()` take effect exactly as in the eager path.
-        `ddp`: with a reducer attached the bucketed RCCL all-reduces are captured INSIDE the graph (ranks replay the
-        same step a single GPU does).  Default: on, unless DVAE_DDP_GRAPH=0; with it off a data-parallel step runs
-        eagerly whatever `flag` says."""
+        `ddp`: with a reducer attached the bucketed RCCL all-reduces can be captured INSIDE the graph (ranks replay the
+        same step a single GPU does).  OPT-IN (ddp=True or DVAE_DDP_GRAPH=1): no run with two or more ranks has shown
+        it equal to the eager data-parallel step yet; without it a data-parallel step runs eagerly whatever `flag` says.
+        A capture that fails falls back to the eager step with a warning (`graph_fallback` holds the reason)."""
         self._use_graph = flag
-        self._graph_ddp = (os.environ.get("DVAE_DDP_GRAPH", "1") != "0") if ddp is None else bool(ddp)
+        self._graph_ddp = (os.environ.get("DVAE_DDP_GRAPH", "0") == "1") if ddp is None else bool(ddp)
+        self.graph_fallback = None
         self._graph = None
         self._graph_sig = None
         self._graph_calls = 0
 
     def _graph_signature(self, data1):
+        from .. import ops
         opt = self.optimizer
         return (tuple(data1.shape), float(opt.param_groups[0]["lr"]), tuple(opt.betas), float(opt.eps),
                 float(self.mse_cof), float(self.kl_cof), int(self.batch_size), bool(self.model.training),
-                self.reducer is not None, getattr(self.reducer, "world_size", 1))
+                self.reducer is not None, getattr(self.reducer, "world_size", 1), ops.current_mode(),
+                bool(ops.LSTM_PERSISTENT))
 
     def _eager_train_step(self, data1, data2):
         self.optimizer.zero_grad()
@@ -140,11 +144,22 @@ class VariationalBaseModelVAE:
             if self._graph is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                # with a reducer the RCCL collectives are captured too (opt-in, see step_async); its watchdog thread
+                # with a reducer the RCCL collectives are captured too (opt-in, see enable_graph); its watchdog thread
                 # makes HIP calls of its own, hence thread-local capture checking
                 mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
-                with torch.cuda.graph(g, **mode):
-                    self._g_losses = self._eager_train_step(self._g_x1, self._g_x2)
+                try:
+                    with torch.cuda.graph(g, **mode):
+                        self._g_losses = self._eager_train_step(self._g_x1, self._g_x2)
+                except Exception as e:      # nothing of the step has run: fall back to the eager step, for good
+                    if self.reducer is None:
+                        raise
+                    import warnings
+                    self.graph_fallback = repr(e)[:300]
+                    warnings.warn("hipGraph capture of the data-parallel step failed; running eagerly: " + self.graph_fallback)
+                    self._use_graph = False
+                    self._graph = None
+                    torch.cuda.synchronize()
+                    return self._eager_train_step(self._g_x1, self._g_x2)
                 self._graph = g
             self._graph.replay()
         finally:
@@ -162,10 +177,19 @@ class VariationalBaseModelVAE:
     # ---- variational_base_vae.py:58-70
     def step(self, data1, data2, speaker_ids, train=False):
         if train:
-            return tuple(self.step_async(data1, data2, speaker_ids).tolist())   # one D2H copy, not 8 .item() syncs
+            out = tuple(self.step_async(data1, data2, speaker_ids).tolist())   # one D2H copy, not 8 .item() syncs
+            self._check_device_errors()
+            return out
         outs = self.model(data1, data2)
         losses = self.loss_functionGVAE2(data1, data2, *outs, train=train)
         return tuple(torch.stack([l.detach() for l in losses]).tolist())
+
+    @staticmethod
+    def _check_device_errors():
+        """Raises if a bounded cross-workgroup wait of a persistent LSTM launch gave up since the last check (the host is
+        synchronised at every call site of this)."""
+        from .. import ops
+        ops.lstm_pers_check()
 
     # ---- variational_base_vae.py:74-101
     def train(self, train_loader, epoch, logging_func=print):
@@ -181,6 +205,7 @@ class VariationalBaseModelVAE:
             last = self.step_async(data1, data2, speaker_ids)
             tot.add_(last)
         tot = tot.tolist()
+        self._check_device_errors()
         last_style = float(last[7]) if last is not None else 0.0
         if hasattr(train_loader, "dataset") and hasattr(train_loader.dataset, "shuffle_data"):
             train_loader.dataset.shuffle_data()
@@ -207,11 +232,17 @@ class VariationalBaseModelVAE:
             sd = torch.load(opt, map_location="cpu")
             self.optimizer.load_state_dict(sd)
             if sd.get("cuda_rng_state") is not None and torch.device(self.device).type == "cuda":
-                torch.cuda.set_rng_state(sd["cuda_rng_state"], self.device)   # eps stream continues where it stopped
+                g = torch.cuda.default_generators[torch.device(self.device).index or 0]
                 if self.reducer is not None and self.reducer.rank > 0:
-                    # the checkpoint holds rank 0's generator; the other ranks must not replay ITS noise on their shards
-                    g = torch.cuda.default_generators[torch.device(self.device).index or 0]
-                    g.manual_seed(g.initial_seed() + 7919 * self.reducer.rank)
+                    # the checkpoint holds rank 0's generator.  The other ranks keep THEIR seed (train.py / bench.py seed
+                    # rank r with seed + 7919 r) and continue at the checkpointed Philox offset — every rank draws the
+                    # same number of normals per step — instead of replaying rank 0's noise or their own from offset 0
+                    seed = int(sd.get("cuda_rng_seed", g.initial_seed())) + 7919 * self.reducer.rank
+                    g.manual_seed(seed)
+                    if sd.get("cuda_rng_offset") is not None:
+                        g.set_offset(int(sd["cuda_rng_offset"]))
+                else:
+                    torch.cuda.set_rng_state(sd["cuda_rng_state"], self.device)   # eps stream continues where it stopped
         logging_func(f"Loading {name} model from last checkpoint ({start_epoch})...")
         return start_epoch + 1
 
@@ -329,7 +360,12 @@ class VariationalBaseModelVAE:
                     torch.save(self.model.state_dict(), base + ".pth")      # reference format: weights only
                     osd = self.optimizer.state_dict()                        # added: Adam moments + step count
                     osd["cuda_rng_state"] = torch.cuda.get_rng_state(self.device)   # + the eps generator state
+                    gen = torch.cuda.default_generators[torch.device(self.device).index or 0]
+                    osd["cuda_rng_seed"], osd["cuda_rng_offset"] = int(gen.initial_seed()), int(gen.get_offset())
                     torch.save(osd, base + ".opt")
+                # variational_base_vae.py:196-201: reconstructions of one test batch from the checkpoint just written
+                if estimation_dir and test_loader is not None:
+                    self.estimate_trained_model(test_loader, checkpoints_path, estimation_dir)
         if log_f:
             log_f.close()
         return history

@@ -426,7 +426,7 @@ class ConvBnActFn(torch.autograd.Function):
 # (bf16 compute mode, H = 512 / 1024, (H/32) * ceil(N/32) <= CU count); DVAE_LSTM_PERSISTENT=0 keeps one launch per frame.
 LSTM_PERSISTENT = os.environ.get("DVAE_LSTM_PERSISTENT", "1") != "0"
 LSTM_PERS_TIMEOUT_US = 0                    # 0: the library's default bound (2 s) on every cross-workgroup wait
-_PERS_WS_BYTES = 8192 + 2 * 16 * 128 * 2 * 1024     # the largest workspace any supported (N, H) needs
+_PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the largest workspace any supported (N, H) needs
 _pers_ws: dict = {}
 
 

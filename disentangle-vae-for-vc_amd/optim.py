@@ -18,7 +18,11 @@ _ALIGN = 4  # elements (16 bytes)
 
 
 class FlatAdam:
-    def __init__(self, named_params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    def __init__(self, named_params: Iterable, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, layout=None):
+        """layout: object with reference_layout(name, t) / storage_layout(name, t) (the model): how a tensor shaped like
+        parameter `name` maps between its STORAGE here and the reference's layout (conv weights are stored packed).
+        Checkpointed moments are kept in the reference's layout, so they do not depend on how parameters are stored."""
+        self.layout = layout
         items = list(named_params)
         if items and not isinstance(items[0], (tuple, list)):
             items = [(f"p{i}", p) for i, p in enumerate(items)]
@@ -84,16 +88,56 @@ class FlatAdam:
         """Number of optimiser steps taken (kept on the device so a captured graph can advance it)."""
         return int(self.dev_state[0].item())
 
+    STATE_FORMAT = 2      # 2: moments per parameter, in the REFERENCE's tensor layout (1 / absent: raw flat vectors)
+
+    def _moment_views(self, flat):
+        for n, p in zip(self.names, self.params):
+            o = self.offsets[n]
+            yield n, flat[o:o + p.numel()].view_as(p)
+
+    def _to_ref(self, name, t):
+        return self.layout.reference_layout(name, t) if self.layout is not None else t
+
+    def _from_ref(self, name, t):
+        return self.layout.storage_layout(name, t) if self.layout is not None else t
+
     def state_dict(self):
-        return {"t": self.t, "lr": self.param_groups[0]["lr"], "betas": self.betas, "eps": self.eps,
-                "names": self.names, "exp_avg": self.exp_avg.detach().cpu(),
-                "exp_avg_sq": self.exp_avg_sq.detach().cpu()}
+        """Moments per parameter in the reference's layout (what torch.optim.Adam would hold for the reference model):
+        independent of the packed conv-weight storage and of the order of the flat buffer."""
+        return {"format": self.STATE_FORMAT, "t": self.t, "lr": self.param_groups[0]["lr"], "betas": self.betas,
+                "eps": self.eps, "names": list(self.names),
+                "exp_avg": {n: self._to_ref(n, v).detach().cpu().contiguous() for n, v in self._moment_views(self.exp_avg)},
+                "exp_avg_sq": {n: self._to_ref(n, v).detach().cpu().contiguous()
+                               for n, v in self._moment_views(self.exp_avg_sq)}}
 
     def load_state_dict(self, sd):
-        if list(sd["names"]) != self.names:
-            raise ValueError("optimizer state was saved for a different parameter layout")
+        if sorted(sd["names"]) != sorted(self.names):
+            raise ValueError("optimizer state was saved for a different set of parameters")
+        fmt = int(sd.get("format", 1))
+        if fmt == 1:
+            # raw flat vectors written before conv weights were stored packed: every slice is in torch's layout and in
+            # the order of ITS `names`
+            if list(sd["names"]) != self.names:
+                raise ValueError("format-1 optimizer state needs the parameter order it was saved with")
+            per = {}
+            for key in ("exp_avg", "exp_avg_sq"):
+                flat, d = sd[key], {}
+                for n, p in zip(self.names, self.params):
+                    o = self.offsets[n]
+                    ref_shape = tuple(self._to_ref(n, p).shape)
+                    d[n] = flat[o:o + p.numel()].view(ref_shape)
+                per[key] = d
+        elif fmt == self.STATE_FORMAT:
+            per = {"exp_avg": sd["exp_avg"], "exp_avg_sq": sd["exp_avg_sq"]}
+        else:
+            raise ValueError(f"optimizer state format {fmt} is newer than this build understands ({self.STATE_FORMAT})")
         self.dev_state.zero_()
         self.dev_state[0] = float(sd["t"])
         self.param_groups[0]["lr"] = float(sd["lr"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        for key, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
+            for n, v in self._moment_views(flat):
+                src = per[key][n]
+                want = tuple(self._to_ref(n, v).shape)
+                if tuple(src.shape) != want:
+                    raise ValueError(f"optimizer state of {n}: shape {tuple(src.shape)}, expected {want}")
+                v.copy_(self._from_ref(n, src.to(v.device)))

@@ -57,8 +57,9 @@ def get_dataset(dataset_fp, batch_size, samples_length=64, seed=None):
 def main(argv=None):
     args = get_parse().parse_args(argv)
     from .model.disentangled_vae import ConvolutionalMulVAE
+    rank = int(os.environ.get("RANK", "0"))
     torch.manual_seed(args.seed)
-    torch.cuda.manual_seed(args.seed)
+    torch.cuda.manual_seed(args.seed + 7919 * rank)      # every rank its own reparameterisation-noise stream
     loader, _ = get_dataset(args.dataset_fp, args.batch_size, args.samples_length, seed=args.seed)
     os.makedirs(args.log_dir, exist_ok=True)
     with open(os.path.join(args.log_dir, "config.json"), "w") as fp:

@@ -65,6 +65,45 @@ def _worker_reducer(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_uneven_order(rank, world, port, q):
+    """World 4: every rank's hooks fire in a DIFFERENT order and some ranks never report some parameters.  Buckets are
+    unequal in size, so a rank that issued its collectives in completion order would pair a bucket with a peer's other
+    bucket (size mismatch: error or hang) — the reducer must issue them in buffer order everywhere."""
+    _init(rank, world, port)
+    import random
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ddp, ops
+    from dvae_amd.optim import FlatAdam
+    sizes = (900, 40, 3000, 8, 2500, 310, 1200, 64, 2048)
+    ps = [(f"p{i}", torch.nn.Parameter(torch.zeros(n))) for i, n in enumerate(sizes)]
+    opt = FlatAdam(ps, lr=1e-3)
+    red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets, bucket_bytes=6000)
+    assert len(red.buckets) >= 4 and len({hi - lo for lo, hi in red.buckets}) > 1
+    for trial in range(4):
+        rng = random.Random(1000 * trial + rank)          # a different order per rank and trial
+        order = list(range(len(ps)))
+        rng.shuffle(order)
+        if trial >= 2:
+            order = order[: len(order) - 1 - rank % 3]    # ... and some parameters never report on some ranks
+        opt.zero_grad()
+        red.begin()
+        for i in range(len(ps)):
+            ps[i][1].grad.add_(float(rank + 1) * (i + 1) + trial)
+        launched_before = red.stats["hook"]
+        for i in order:
+            ops.grad_ready_hook(ps[i][1])
+        red.finish()
+        assert red.next_bucket == len(red.buckets)
+        assert red.stats["hook"] - launched_before <= len(red.buckets)
+        for i, (_, p) in enumerate(ps):
+            want = sum(float(r + 1) * (i + 1) + trial for r in range(world))
+            assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (trial, i, rank)
+    dist.barrier()
+    if rank == 0:
+        q.put("ok")
+    dist.destroy_process_group()
+
+
 def _worker_step_equivalence(rank, world, port, q):
     _init(rank, world, port)
     import dvae_amd  # noqa: F401
@@ -119,6 +158,10 @@ def _run(fn, world=2):
 
 def test_bucketed_reducer_world2_gloo():
     assert _run(_worker_reducer) == "ok"
+
+
+def test_reducer_world4_uneven_ready_order_gloo():
+    assert _run(_worker_uneven_order, world=4) == "ok"
 
 
 def test_two_rank_step_equals_chunked_oracle_step():

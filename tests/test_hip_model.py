@@ -245,6 +245,15 @@ def test_config0_run_training_and_resume(tmp_path):
     assert "DisentangledVAE_VCTK_2.pth" in ck and "DisentangledVAE_VCTK_4.pth" in ck
     sd = torch.load(os.path.join(log_dir, "checkpoints", "DisentangledVAE_VCTK_4.pth"))
     assert "enc_lstm.weight_hh_l1_reverse" in sd and "dec_modules.2.0.weight" in sd     # reference key names
+    # reconstructions of a test batch at every report interval (variational_base_vae.py:196-201); files carry the
+    # value load_last_model returns, i.e. checkpoint epoch + 1, as in the reference (:205-206)
+    est = os.listdir(os.path.join(log_dir, "images", "estimation"))
+    for ep in (3, 5):
+        assert f"{ep}_original_mel_0.npy" in est and f"{ep}_recons_mel_0.npy" in est, est
+    # Adam moments are checkpointed per parameter in the REFERENCE's layout (conv weights [Cout][Cin][5])
+    osd = torch.load(os.path.join(log_dir, "checkpoints", "DisentangledVAE_VCTK_4.opt"))
+    assert osd["format"] == 2 and tuple(osd["exp_avg"]["dec_modules.2.0.weight"].shape) == (512, 512, 5)
+    assert "cuda_rng_offset" in osd
     hist2 = cli.main(argv[:7] + ["--epochs=1"] + argv[8:])                               # resumes at epoch 5
     assert [h["epoch"] for h in hist2] == [5]
 

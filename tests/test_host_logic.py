@@ -264,3 +264,49 @@ def test_frontend_refuses_cpu():
     from dvae_amd.frontend import MelFrontend
     with pytest.raises(RuntimeError):
         MelFrontend(device="cpu")
+
+
+def test_flat_adam_state_is_layout_independent():
+    """The optimizer checkpoint holds the moments per parameter in the REFERENCE's layout: a conv weight stored packed
+    [5][Cout][Cin] round-trips through [Cout][Cin][5], and a format-1 file (raw flat vectors written when conv weights
+    were still stored in torch's layout) is converted instead of being silently permuted."""
+    import dvae_amd  # noqa: F401
+    from dvae_amd.optim import FlatAdam
+
+    class Layout:
+        def reference_layout(self, name, t):
+            return t.permute(1, 2, 0) if name == "conv.weight" else t
+
+        def storage_layout(self, name, t):
+            return t.permute(2, 0, 1) if name == "conv.weight" else t
+
+    def make():
+        conv = torch.nn.Parameter(torch.zeros(5, 3, 2))      # packed [K][Cout][Cin]
+        lin = torch.nn.Parameter(torch.zeros(4, 6))
+        return FlatAdam([("conv.weight", conv), ("lin.weight", lin)], lr=1e-3, layout=Layout())
+
+    a = make()
+    a.exp_avg.copy_(torch.arange(a.numel, dtype=torch.float32))
+    a.exp_avg_sq.copy_(torch.arange(a.numel, dtype=torch.float32) * 2)
+    a.dev_state[0] = 7
+    sd = a.state_dict()
+    assert sd["format"] == 2 and tuple(sd["exp_avg"]["conv.weight"].shape) == (3, 2, 5)
+    assert torch.equal(sd["exp_avg"]["conv.weight"], a.exp_avg[:30].view(5, 3, 2).permute(1, 2, 0))
+    b = make()
+    b.load_state_dict(sd)
+    for (_, va), (_, vb) in zip(a._moment_views(a.exp_avg), b._moment_views(b.exp_avg)):
+        assert torch.equal(va, vb)
+    for (_, va), (_, vb) in zip(a._moment_views(a.exp_avg_sq), b._moment_views(b.exp_avg_sq)):
+        assert torch.equal(va, vb)
+    assert b.t == 7
+    # format 1: the conv slice of the flat vector is [Cout][Cin][5] (torch layout)
+    ref = torch.arange(30, dtype=torch.float32).view(3, 2, 5)
+    flat = torch.zeros(a.numel)
+    flat[:30] = ref.reshape(-1)
+    old = {"t": 3, "lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "names": ["conv.weight", "lin.weight"],
+           "exp_avg": flat, "exp_avg_sq": flat.clone()}
+    c = make()
+    c.load_state_dict(old)
+    assert torch.equal(c.exp_avg[:30].view(5, 3, 2), ref.permute(2, 0, 1))
+    with pytest.raises(ValueError):
+        c.load_state_dict(dict(sd, format=3))
