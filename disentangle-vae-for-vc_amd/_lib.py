@@ -70,6 +70,7 @@ SIGNATURES = {
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_x3": (i32, [vp, vp, vp, i32, vp]),
     "dvae_repack_all": (i32, [C.POINTER(RepackDesc), i32, vp]),
+    "dvae_lstm_pers_supported": (i32, [i32, i32, i32, i32]),
     "dvae_lstm_pers_ws_bytes": (i64, [i32, i32]),
     "dvae_lstm_pers_check": (i32, [vp, C.POINTER(i32), vp]),
     "dvae_lstm_pers_selftest": (i32, [C.POINTER(LstmDir), i32, i32, i32, i64, i32, vp]),

@@ -998,7 +998,7 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
 }  // namespace
 
 // lstm_pers.hip: the W_hh-resident persistent recurrence (one launch per sequence)
-int dvae_pers_usable(int N, int H, int pm);
+int dvae_pers_usable(int N, int H, int pm, int bwd);
 int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, int64_t ldh, int drop_bid, hipStream_t s);
 
 namespace {
@@ -1035,7 +1035,7 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
-  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm))
+  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm, 0))
     return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
@@ -1091,7 +1091,7 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
   ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
-  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm))
+  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm, 1))
     return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;

@@ -40,8 +40,10 @@ typedef unsigned u32x4v __attribute__((__vector_size__(16)));
 // (H = 1024, N = 128, measured): partial-line stores of 32 CUs serialise behind each other.
 constexpr int PERS_FLAG_STRIDE = 32;          // words between the flags of two producers
 constexpr int PERS_FLAG_LD = 32 * PERS_FLAG_STRIDE;   // words per row group (H/32 <= 32 producers)
+constexpr int PERS_FLAG_LD_X3 = 64 * PERS_FLAG_STRIDE;   // fp32x3 forward: H/16 <= 64 producers per row group
 constexpr int PERS_MAX_RB = 16;               // row groups
 constexpr int PERS_FLAG_BYTES = PERS_MAX_RB * PERS_FLAG_LD * 4;   // 64 KiB; a launch zeroes the n_rb groups it uses
+static_assert(4 * PERS_FLAG_LD_X3 * 4 <= PERS_FLAG_BYTES, "fp32x3: at most 4 row groups of 64 producers");
 constexpr int PERS_ERR_OFF = PERS_FLAG_BYTES; // sticky error record: 16 words (never cleared by a launch)
 constexpr int PERS_XCH_OFF = PERS_FLAG_BYTES + 4096;   // exchange ring
 constexpr int PERS_PAD_LDS = 84 * 1024;       // total LDS per workgroup >= this: exactly one workgroup fits a CU
@@ -556,6 +558,236 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   }
 }
 
+// ======================================================================================================================
+// fp32x3 forward (the default arithmetic, BASELINE configs[1]/[3]): fp32 RESULTS on the bf16 pipe.  W_hh lives as THREE bf16
+// planes (w = w0 + w1 + w2 exactly, dvae_lstm_pack_w_x3), h is handed over as three planes too (the PRODUCER splits each
+// value once; 64 consumers read it), six exact partial products per (fragment, column tile) — lstm.hip, PM = 2.
+// 3 x the bytes of the bf16 mode per W_hh element, so a workgroup owns 16 hidden units (64 gate columns) x 32 segments:
+// planes 0 and 1 of its slice in registers (256 at H = 1024), plane 2 (used by one product of six) mostly in LDS.
+// Group = the H/16 workgroups of a row block (64 at H = 1024: one poller lane each).
+// ======================================================================================================================
+template <int KW, int K2L>
+struct X3Lds {
+  bf16x8 w2[K2L > 0 ? NWV : 1][4][K2L > 0 ? K2L : 1][64];   // plane 2 of chunks KW-K2L .. KW-1: [wave][g][k][lane]
+  f32x2 red[NWV][NWV - 1][4][64];        // partial gate sums FOR wave w's elements FROM the three other waves: [w][slot][g][lane]
+  __bf16 hx[3][2][16][24];               // h planes in A-fragment order [plane][mt][row][16 units + pad]
+  int dead;
+};
+
+template <int H, int K2L>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a) {
+  constexpr int MT = 2;
+  constexpr int NCH = H / 32;           // 32-deep k-chunks of h
+  constexpr int NPR = H / 16;           // producers of a row group
+  constexpr int KW = NCH / NWV;         // chunks per wave
+  constexpr int K2R = KW - K2L;         // chunks whose plane 2 stays in registers
+  constexpr int NEL = 2;
+  constexpr int RD = 4;                 // (chunk, row tile) units of h[t-1] in flight: 12 loads per lane
+  const int T = a.T, N = a.N;
+  const int bid = blockIdx.x;
+  const int rb = bid % a.n_rb, jb = bid / a.n_rb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  X3Lds<KW, K2L>& L = *reinterpret_cast<X3Lds<KW, K2L>*>(lds_raw);
+  volatile int* dead = &L.dead;
+  if (tid == 0) *dead = 0;
+
+  // resident W_hh fragments: [(g*(H/16) + jb)][chunk][plane][lane][8]
+  bf16x8 W01[4][KW][2], W2[4][K2R > 0 ? K2R : 1];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(
+            a.wp + (((((int64_t)(g * (H / 16) + jb)) * NCH + wave * KW + k) * 3 + p) * 64 + lane) * 16);
+        if (p < 2) W01[g][k][p < 2 ? p : 0] = w;
+        else if (k < K2R) W2[g][k < K2R ? k : 0] = w;
+        else L.w2[wave][g][k >= K2R ? k - K2R : 0][lane] = w;
+      }
+
+  // this wave owns the elements (row tile emt, accumulator registers e0, e0+1) of every lane: rows emt*16 + q*4 + e0 + {0,1},
+  // unit r.  Its accumulators START from those elements' pre-activations (the other positions from zero), so the sum over
+  // the four waves' partial tiles IS the gate pre-activation and no operand of the epilogue stays live under the MFMAs.
+  const int emt = wave >> 1, e0 = (wave & 1) * 2;
+  const int erow0 = emt * 16 + q * 4 + e0;
+  int el_n[NEL];
+  bool el_ok[NEL];
+  float creg[NEL];
+#pragma unroll
+  for (int i = 0; i < NEL; ++i) {
+    el_ok[i] = rb * 32 + erow0 + i < N;
+    el_n[i] = min(rb * 32 + erow0 + i, N - 1);
+    creg[i] = 0.f;
+  }
+  const int j0 = jb * 16;
+  const int64_t H4 = 4 * (int64_t)H;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, a.xch_bytes, 0x00020000);
+  const int slot_bytes = a.n_rb * NCH * MT * 3 * 1024;          // fragment (chunk, mt, plane) = 1 KiB
+  const int xld = (rb * NCH + wave * KW) * MT * 3 * 1024 + lane * 16;
+  // this workgroup's 16 units are half of chunk jb/2: lanes q' = 2*(jb&1) + {0,1} of its fragments
+  const int xst = ((rb * NCH + (jb >> 1)) * MT * 3) * 1024 + ((jb & 1) * 32 + lane) * 16;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD_X3 + lane * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD_X3 + jb * PERS_FLAG_STRIDE;
+
+  auto fetch = [&](int step_, float (&x)[NEL][4]) {
+    const int t_ = a.reverse ? (T - 1 - step_) : step_;
+    const float* __restrict__ G_ = a.gates + (int64_t)t_ * N * H4 + j0 + r;
+#pragma unroll
+    for (int i = 0; i < NEL; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) x[i][g] = G_[(int64_t)el_n[i] * H4 + g * H];
+  };
+
+  float x[NEL][4];                      // pre-activations of the NEXT frame (fetched under this frame's MFMAs)
+  fetch(0, x);
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = a.reverse ? (T - 1 - step) : step;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 own = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (e0) { own[2] = x[0][g]; own[3] = x[1][g]; } else { own[0] = x[0][g]; own[1] = x[1][g]; }
+      acc[0][g] = emt ? f32x4{0.f, 0.f, 0.f, 0.f} : own;
+      acc[1][g] = emt ? own : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    PERS_STAMP(0);
+    if (step > 0) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
+        pers_give_up(a.err, 1, bid, step, wave);
+        *dead = 1;
+      }
+      __syncthreads();                                             // barrier A
+      PERS_STAMP(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int so = ((step - 1) & 1) * slot_bytes;
+      // unit u = (chunk k, row tile mt) = three 1-KiB fragments (the planes of h); RD units in flight
+      bf16x8 av[RD][3];
+      auto load = [&](int u) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          av[u % RD][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld + (u * 3 + p) * 1024, so, 16));
+      };
+#pragma unroll
+      for (int u = 0; u < RD; ++u) load(u);
+      fetch(min(step + 1, T - 1), x);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < KW * MT; ++u) {
+        const int k = u / MT, mt = u % MT;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const bf16x8 w2 = (k < K2R) ? W2[g][k < K2R ? k : 0] : L.w2[wave][g][k >= K2R ? k - K2R : 0][lane];
+          // the six partial products of weight >= 2^-16: (h plane, W plane)
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W01[g][k][0], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W01[g][k][1], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][1], W01[g][k][0], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][1], W01[g][k][1], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], w2, acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][2], W01[g][k][0], acc[mt][g], 0, 0, 0);
+        }
+        if (u + RD < KW * MT) {
+          __builtin_amdgcn_sched_barrier(0);
+          load(u + RD);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      fetch(min(step + 1, T - 1), x);
+    }
+    // every wave hands the other three owners their part of its partial tiles and keeps its own in registers
+#pragma unroll
+    for (int o = 0; o < NWV; ++o) {
+      if (o == wave) continue;
+      const int slot = (wave - o - 1) & (NWV - 1);               // 0..2
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = acc[o >> 1][g];
+        L.red[o][slot][g][lane] = (o & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+      }
+    }
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
+    if (*dead) break;
+
+    float go_[NEL][4], co_[NEL], ho_[NEL];
+    {
+      f32x2 gs[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 own = acc[0][g];
+        if (emt) own = acc[1][g];
+        f32x2 sacc = e0 ? f32x2{own[2], own[3]} : f32x2{own[0], own[1]};
+#pragma unroll
+        for (int sl = 0; sl < NWV - 1; ++sl) sacc += L.red[wave][sl][g][lane];
+        gs[g] = sacc;
+      }
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const float gi = gate_sigmoid(gs[0][i]);
+        const float gf = gate_sigmoid(gs[1][i]);
+        const float gg = gate_tanh(gs[2][i]);
+        const float go = gate_sigmoid(gs[3][i]);
+        const float c = gf * creg[i] + gi * gg;
+        const float h = go * gate_tanh(c);
+        creg[i] = c;
+        const int row = erow0 + i;
+        // h = h0 + h1 + h2 exactly (two round-to-nearest splits; the last residual is exact in bf16)
+        const __bf16 h0 = (__bf16)h;
+        const float r1 = h - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const __bf16 h2 = (__bf16)(r1 - (float)h1);
+        L.hx[0][row >> 4][row & 15][r] = h0;
+        L.hx[1][row >> 4][row & 15][r] = h1;
+        L.hx[2][row >> 4][row & 15][r] = h2;
+        go_[i][0] = gi; go_[i][1] = gf; go_[i][2] = gg; go_[i][3] = go;
+        co_[i] = c; ho_[i] = h;
+      }
+    }
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
+    if (wave == 0) {
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
+        if (lane < 32) {                // lane (r, q' in {0,1}): units 8q'..8q'+7 of row r
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&L.hx[p][mt][r][(q & 1) * 8]);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + (mt * 3 + p) * 1024, so, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_STAMP(6);
+        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // the frame's outputs (activated gates, c, h), after the hand-off has left
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+      if (el_ok[i]) {
+        float* gp = a.gates + ((int64_t)t * N + el_n[i]) * H4 + j0 + r;
+        gp[0] = go_[i][0];
+        gp[H] = go_[i][1];
+        gp[2 * H] = go_[i][2];
+        gp[3 * H] = go_[i][3];
+        a.c_all[((int64_t)t * N + el_n[i]) * H + j0 + r] = co_[i];
+        reinterpret_cast<float*>(a.h_out)[((int64_t)t * N + el_n[i]) * a.ldh + j0 + r] = ho_[i];
+      }
+    }
+  }
+}
+
 #ifdef DVAE_PERS_TS
 unsigned long long* g_pers_ts = nullptr;
 int g_pers_ts_bid = 0;
@@ -602,27 +834,87 @@ int pers_launch_one(bool bwd, const PersArgs& a, int grid, hipStream_t s) {
 
 }  // namespace
 
-// used by lstm.hip: 1 when (N, H, mode) has a persistent kernel on this device
-int dvae_pers_usable(int N, int H, int pm) {
+// fp32x3 forward: 32-row tiles, 16 units per workgroup
+bool pers_x3_ok(int N, int H, int cus) {
+  if (H != 512 && H != 1024) return false;
+  const int n_rb = (N + 31) / 32;
+  return n_rb <= 4 && (H / 16) * n_rb <= cus;
+}
+
+// used by lstm.hip: 1 when (N, H, mode, pass) has a persistent kernel on this device
+int dvae_pers_usable(int N, int H, int pm, int bwd) {
+  if (pm == DVAE_MODE_F32X3) return !bwd && pers_x3_ok(N, H, pers_cu_count());
   if (pm != DVAE_MODE_BF16) return 0;
   return pers_mt(N, H, pers_cu_count()) != 0;
 }
 
+DVAE_API int dvae_lstm_pers_supported(int N, int H, int mode, int bwd) {
+  if (N < 1) return 0;
+  return dvae_pers_usable(N, H, mode, bwd);
+}
+
 DVAE_API int64_t dvae_lstm_pers_ws_bytes(int N, int H) {
   if (N < 1 || (H != 512 && H != 1024)) return 0;
-  int mt = pers_mt(N, H, 256);
-  if (!mt) return 0;
-  const int64_t n_rb = (N + 16 * mt - 1) / (16 * mt);
-  return PERS_XCH_OFF + 2 * n_rb * (4 * (H / 32)) * mt * 1024;
+  int64_t need = 0;
+  if (int mt = pers_mt(N, H, 256)) {
+    const int64_t n_rb = (N + 16 * mt - 1) / (16 * mt);
+    need = PERS_XCH_OFF + 2 * n_rb * (4 * (H / 32)) * mt * 1024;
+  }
+  if (pers_x3_ok(N, H, 256)) {
+    const int64_t x3 = PERS_XCH_OFF + 2 * (int64_t)((N + 31) / 32) * (H / 32) * 2 * 3 * 1024;
+    need = x3 > need ? x3 : need;
+  }
+  return need;
 }
+
+namespace {
+template <int H, int K2L>
+int pers_launch_x3(const PersArgs& a, int grid, hipStream_t s) {
+  constexpr int KW = H / 32 / NWV;
+  const int need = (int)sizeof(X3Lds<KW, K2L>);
+  const int lds = need > PERS_PAD_LDS ? need : PERS_PAD_LDS;
+  auto kern = lstm_pers_fwd_x3<H, K2L>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, s, a);
+  return dvae_check_launch();
+}
+}  // namespace
 
 // one direction of one layer, all T frames; `bwd` selects the pass.  Returns DVAE_EINVAL when the shape has no persistent
 // kernel (the caller then uses the per-frame launches).
 int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, int64_t ldh, int drop_bid, hipStream_t s) {
   const int cus = pers_cu_count();
+  if (!d.pers_ws || !d.w_packed || (((uintptr_t)d.pers_ws) & 255)) return DVAE_EINVAL;
+  if (d.packed_mode == DVAE_MODE_F32X3) {
+    if (bwd || d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
+    PersArgs a{};
+    a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
+    char* ws = (char*)d.pers_ws;
+    a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
+    a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = 0;
+    a.n_rb = (N + 31) / 32;
+    const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
+    a.timeout = us > 40000000u ? 4000000000u : us * 100u;
+    a.xch_bytes = 2 * a.n_rb * (H / 32) * 2 * 3 * 1024;
+    a.drop_bid = drop_bid;
+#ifdef DVAE_PERS_TS
+    a.ts = g_pers_ts;
+    a.ts_bid = g_pers_ts_bid;
+#endif
+    if (hipMemsetAsync(ws, 0, (size_t)a.n_rb * PERS_FLAG_LD_X3 * 4, s) != hipSuccess) {
+      g_dvae_last_hip_error = (int)hipGetLastError();
+      return DVAE_ELAUNCH;
+    }
+    const int grid = (H / 16) * a.n_rb;
+    if (H == 1024) return pers_launch_x3<1024, 8>(a, grid, s);
+    return pers_launch_x3<512, 0>(a, grid, s);
+  }
   const int mt = pers_mt(N, H, cus);
-  if (!mt || !d.pers_ws || d.packed_mode != DVAE_MODE_BF16 || !d.w_packed) return DVAE_EINVAL;
-  if (((uintptr_t)d.pers_ws) & 255) return DVAE_EINVAL;
+  if (!mt || d.packed_mode != DVAE_MODE_BF16) return DVAE_EINVAL;
   const bool s16 = d.state_bf16 != 0;
   if (s16 && (ldh & 7)) return DVAE_EINVAL;
   PersArgs a{};

@@ -315,8 +315,12 @@ class DisentangledVAE(nn.Module):
         Returns (h, h16) the same way: h16 is None unless the layer keeps its state in bf16 (then h is the placeholder)."""
         mod = getattr(self, mname)
         from ..derived import lstm_pack_modes
-        pers = ops.lstm_persistent_usable(n_seg, mod.hidden_size, lstm_pack_modes(ops.current_mode(), mod.hidden_size)[0],
-                                          2 if mod.bidirectional else 1)
+        # both passes on the W_hh-resident launches (bf16 mode): two plain layers; otherwise (fp32x3: forward only — inside
+        # LstmStack2Fn — or none) two stacked layers of equal width share their per-frame launches
+        mf, mb = lstm_pack_modes(ops.current_mode(), mod.hidden_size)
+        ndir = 2 if mod.bidirectional else 1
+        pers = ops.lstm_persistent_usable(n_seg, mod.hidden_size, mf, ndir) and \
+            ops.lstm_persistent_usable(n_seg, mod.hidden_size, mb, ndir, bwd=True)
         if not pers and LstmStack2Fn.usable(T, mod.hidden_size, mod.num_layers, mod.bidirectional):
             # two stacked layers of equal width share their frame launches (ops.LstmStack2Fn)
             der = self._lstm_der(mname, 0, False) + self._lstm_der(mname, 1, False)

@@ -430,8 +430,9 @@ _PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the largest worksp
 _pers_ws: dict = {}
 
 
-def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1) -> bool:
-    return bool(LSTM_PERSISTENT and ndir == 1 and int(mode) == MODE_BF16 and lib().dvae_lstm_pers_ws_bytes(N, H) > 0)
+def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1, bwd: bool = False) -> bool:
+    """`mode`: precision of the recurrent product of that pass (derived.lstm_pack_modes)."""
+    return bool(LSTM_PERSISTENT and ndir == 1 and lib().dvae_lstm_pers_supported(N, H, int(mode), int(bwd)))
 
 
 def lstm_pers_workspace(dev) -> torch.Tensor:
@@ -566,7 +567,7 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].dc_ws = ptr(dc)
             dirs[d].reverse = d
             dirs[d].state_bf16 = int(s16)
-        if lstm_persistent_usable(N, H, bf, ndir):
+        if lstm_persistent_usable(N, H, bf, ndir, bwd=True):
             dirs[0].pers_ws, dirs[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         dx = None
@@ -650,13 +651,27 @@ class LstmStack2Fn(torch.autograd.Function):
             dirs[d].reverse, dirs[d].packed_mode, dirs[d].step_shift = 0, bf, (Tc if d == 1 else 0)
             dirs[d].state_bf16 = int(s16)
         rows = Tc * N
-        for c0 in range(0, T + Tc, Tc):
-            if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
-                r0 = (c0 - Tc) * N
-                gemm(h1.data_ptr() + esz * r0 * H, w_ih2 if der[1].w_ih16 is None else der[1].w_ih16,
-                     g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias, rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode,
-                     flags=A_BF16 if s16 else 0)
-            check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
+        if lstm_persistent_usable(N, H, bf):
+            # the forward recurrences as two W_hh-resident launches (one per layer), layer 2's whole input projection in
+            # between; the backward pass keeps the stacked per-frame launches below
+            one = (_lib.LstmDir * 1)()
+            for d, (g, wh, h, c) in enumerate(((g1, w_hh1, h1, c1), (g2, w_hh2, h2, c2))):
+                if d == 1:
+                    gemm(h1, w_ih2 if der[1].w_ih16 is None else der[1].w_ih16, g2, der[1].bias, R, 4 * H, H, H, H, 4 * H,
+                         True, True, mode=mode)
+                one[0].gates, one[0].w_hh, one[0].w_packed = ptr(g), ptr(wh), ptr(der[d].pack_f)
+                one[0].h_out, one[0].c_all = ptr(h), ptr(c)
+                one[0].reverse, one[0].packed_mode, one[0].step_shift, one[0].state_bf16 = 0, bf, 0, int(s16)
+                one[0].pers_ws, one[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
+                check(L.dvae_lstm_seq_fwd(one, 1, T, N, H, H, st), "dvae_lstm_seq_fwd")
+        else:
+            for c0 in range(0, T + Tc, Tc):
+                if c0 >= Tc:    # layer 1 finished frames [c0-Tc, c0): their rows go through layer 2's input projection
+                    r0 = (c0 - Tc) * N
+                    gemm(h1.data_ptr() + esz * r0 * H, w_ih2 if der[1].w_ih16 is None else der[1].w_ih16,
+                         g2.data_ptr() + 4 * r0 * 4 * H, der[1].bias, rows, 4 * H, H, H, H, 4 * H, True, True, mode=mode,
+                         flags=A_BF16 if s16 else 0)
+                check(L.dvae_lstm_seq_fwd_range(dirs, 2, T, N, H, H, c0, c0 + Tc, st), "dvae_lstm_seq_fwd_range")
         ctx.save_for_backward(x, h1, h2, g1, g2, c1, c2, w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2)
         ctx.der = der
         ctx.cfg = (T, N, H, bfb, mode, s16)

@@ -170,7 +170,7 @@ typedef struct {
                          element strides */
   void* pers_ws;      /* optional: >= dvae_lstm_pers_ws_bytes(N, H) bytes, 256-byte aligned, zero-initialised ONCE by the
                          caller.  When given to a plain one-direction dvae_lstm_seq_fwd / _bwd call whose shape has a
-                         persistent kernel (bf16 mode, H = 512 / 1024, (H/32) * ceil(N/32) <= CU count), the whole sequence
+                         persistent kernel (dvae_lstm_pers_supported), the whole sequence
                          runs in ONE W_hh-resident launch (csrc/lstm_pers.hip) instead of one launch per frame; same
                          arithmetic, same tensors.  One workspace serves every layer run on one stream */
   unsigned pers_timeout_us; /* bound of every cross-workgroup wait of that launch (0: 2 s); see dvae_lstm_pers_check */
@@ -206,7 +206,12 @@ typedef struct {
 } dvae_repack_desc_t;
 int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
 
-/* ---- W_hh-resident persistent recurrence (nn.LSTM at disentangled_vae.py:172,193; H = 512 / 1024, bf16 mode) ----
+/* ---- W_hh-resident persistent recurrence (nn.LSTM at disentangled_vae.py:172,193; H = 512 / 1024) ----
+ * Exists for: DVAE_MODE_BF16, forward and backward, (H/32) * ceil(N/32) <= CU count; DVAE_MODE_F32X3, FORWARD only (three
+ * bf16 planes of W_hh resident, h handed over as three planes), N <= 128 (the backward recurrence streams the 4H-wide
+ * gate gradients, which no residency shrinks: it stays on the per-frame kernels).
+ * dvae_lstm_pers_supported: 1 when a call with (N, H, packed_mode = mode, pass) would take the persistent launch on the
+ *   current device (given a workspace), else 0.
  * dvae_lstm_pers_ws_bytes: size of the synchronisation workspace (flags + sticky error record + exchange ring) for
  *   (N, H); 0 when the shape has no persistent kernel.
  * dvae_lstm_pers_check: SYNCHRONISES `stream`, then returns DVAE_ELAUNCH if a bounded wait of any persistent launch on
@@ -214,6 +219,7 @@ int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
  *   that launch are garbage), DVAE_OK otherwise.  Not capturable; call it wherever the host synchronises anyway.
  * dvae_lstm_pers_selftest: a forward launch in which workgroup `drop_bid` never publishes — every waiter must give up
  *   within dir->pers_timeout_us and dvae_lstm_pers_check must then report it (tests/test_hip_lstm_pers.py). */
+int dvae_lstm_pers_supported(int N, int H, int mode, int bwd);
 int64_t dvae_lstm_pers_ws_bytes(int N, int H);
 int dvae_lstm_pers_check(void* ws, int* info4, void* stream);
 int dvae_lstm_pers_selftest(const dvae_lstm_dir_t* dir, int T, int N, int H, int64_t ldh, int drop_bid, void* stream);

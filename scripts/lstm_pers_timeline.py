@@ -17,14 +17,16 @@ H, N = int(sys.argv[1]), int(sys.argv[2])
 bid = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 bwd = len(sys.argv) > 4 and sys.argv[4] == "bwd"
 T = 128
+MODE = int(os.environ.get("LSTM_MODE", "1"))      # 1 bf16 (bf16 state), 2 fp32x3 (forward only, fp32 state)
 L = lib()
 L.dvae_lstm_pers_set_ts.argtypes = [C.c_void_p, C.c_int]
 f = dict(device="cuda", dtype=torch.float32)
 w_hh = torch.randn(4 * H, H, **f) / H ** 0.5
-der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), 1)
+der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), MODE)
 gates0 = torch.randn(T * N, 4 * H, **f) * 0.5
-gates, h, c = torch.empty_like(gates0), torch.empty(T * N, H, device="cuda", dtype=torch.bfloat16), torch.empty(T * N, H, **f)
-dh, dg = torch.randn(T * N, H, **f) * 0.1, torch.empty(T * N, 4 * H, device="cuda", dtype=torch.bfloat16)
+sdt = torch.bfloat16 if MODE == 1 else torch.float32
+gates, h, c = torch.empty_like(gates0), torch.empty(T * N, H, device="cuda", dtype=sdt), torch.empty(T * N, H, **f)
+dh, dg = torch.randn(T * N, H, **f) * 0.1, torch.empty(T * N, 4 * H, device="cuda", dtype=sdt)
 dc = torch.empty(N, H, **f)
 ts = torch.zeros(T * 8 * 8, device="cuda", dtype=torch.int64)
 ws = ops.lstm_pers_workspace("cuda")
@@ -35,7 +37,7 @@ def dirs(b):
     d[0].gates, d[0].c_all, d[0].h_out = ptr(gates), ptr(c), ptr(h)
     d[0].w_hh, d[0].w_packed = (ptr(der.w_hh_t), ptr(der.pack_b)) if b else (ptr(w_hh), ptr(der.pack_f))
     d[0].dh_out, d[0].dgates, d[0].dc_ws = ptr(dh), ptr(dg), ptr(dc)
-    d[0].packed_mode, d[0].state_bf16, d[0].pers_ws = 1, 1, ptr(ws)
+    d[0].packed_mode, d[0].state_bf16, d[0].pers_ws = (0 if (b and MODE == 2) else MODE), int(MODE == 1), ptr(ws)
     return d
 
 

@@ -110,6 +110,37 @@ def test_persistent_matches_frame_kernels(env, H, T, N, s16, reverse):
     compare(got, ref, f"H={H} T={T} N={N} s16={s16} rev={reverse}")
 
 
+@pytest.mark.parametrize("H,T,N,reverse", [(1024, 8, 128, 0), (512, 6, 128, 0), (1024, 5, 40, 1), (512, 1, 128, 0),
+                                            (1024, 3, 17, 0)])
+def test_persistent_fp32x3_forward_matches_frame_kernels(env, H, T, N, reverse):
+    """fp32x3 (the default arithmetic): the forward recurrence on three resident bf16 planes of W_hh, h handed over as
+    three planes.  fp32 results: against the per-frame fp32x3 kernels only the fp32 summation order differs."""
+    _lib, ops, lstm_local = env
+    L, st, ptr = _lib.lib(), _lib.stream(), _lib.ptr
+    X3 = _lib.MODE_F32X3
+    assert ops.lstm_persistent_usable(N, H, X3) and not ops.lstm_persistent_usable(N, H, X3, bwd=True)
+    g = torch.Generator(device="cuda").manual_seed(H + T + N)
+    f = dict(device="cuda", dtype=torch.float32)
+    w_hh = (torch.rand(4 * H, H, generator=g, **f) * 2 - 1) / H ** 0.5
+    der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), X3)
+    gates0 = torch.rand(T * N, 4 * H, generator=g, **f) * 2 - 1
+    outs = []
+    for pers in (False, True):
+        gates, h, c = gates0.clone(), torch.full((T * N, H), float("nan"), **f), torch.empty(T * N, H, **f)
+        d = (_lib.LstmDir * 1)()
+        d[0].gates, d[0].c_all, d[0].h_out, d[0].w_hh, d[0].w_packed = ptr(gates), ptr(c), ptr(h), ptr(w_hh), ptr(der.pack_f)
+        d[0].reverse, d[0].packed_mode = reverse, X3
+        if pers:
+            d[0].pers_ws = ptr(ops.lstm_pers_workspace("cuda"))
+        _lib.check(L.dvae_lstm_seq_fwd(d, 1, T, N, H, H, st), "fwd")
+        ops.lstm_pers_check()
+        outs.append((gates, c, h))
+    for name, a, b in zip(("gates", "c", "h"), outs[1], outs[0]):
+        assert torch.isfinite(a).all(), name
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * float(b.abs().max()), f"{name}: max |diff| {err:.3e}"
+
+
 def test_persistent_handoffs_under_uneven_load(env):
     """A second stream streams 1 GiB copies through HBM while the persistent launches run: hand-offs must not depend on
     timing.  Every output word is compared with the per-frame kernels' each round."""
