@@ -107,14 +107,20 @@ SIGNATURES = {
     "dvae_stft_frames": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_stft_magnitude": (i32, [vp, vp, i64, i32, vp]),
     "dvae_mel_db_normalize": (i32, [vp, vp, i32, i32, i64, i64, f32, f32, f32, vp]),
-    "dvae_probe_launches": (i32, [i32, i32, i32, i32, vp, vp]),
-    "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
-    "dvae_probe_mfma_bf16": (i32, [i32, i32, i32, vp, vp, vp]),
-    "dvae_probe_coissue": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "dvae_prof_enable": (i32, [i32]),
     "dvae_prof_collect": (i32, [C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]),
     "dvae_prof_collect_tags": (i32, [C.POINTER(C.c_uint), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), i32]),
+}
+
+
+# include/dvae_hip_dev.h: only in the development build (csrc/build.sh dev -> libdvae_dev.so; DVAE_LIB_PATH selects it)
+DEV_SIGNATURES = {
+    "dvae_probe_launches": (i32, [i32, i32, i32, i32, vp, vp]),
+    "dvae_probe_mfma": (i32, [i32, i32, i32, vp, vp]),
+    "dvae_probe_mfma_bf16": (i32, [i32, i32, i32, vp, vp, vp]),
+    "dvae_probe_coissue": (i32, [i32, i32, i32, i32, vp, vp, vp]),
+    "dvae_lstm_pers_set_ts": (i32, [vp, i32]),
 }
 
 
@@ -142,6 +148,9 @@ def lib():
             fn = getattr(h, name)  # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
+        for name, (res, args) in DEV_SIGNATURES.items():
+            if hasattr(h, name):
+                getattr(h, name).restype, getattr(h, name).argtypes = res, args
         got = h.dvae_version()
         if got != ABI_VERSION:
             raise RuntimeError(f"{LIB_PATH} reports ABI {got}, this binding is for {ABI_VERSION} (include/dvae_hip.h): "

@@ -46,6 +46,18 @@ __device__ __forceinline__ void split3(const f32x4& x, bf16x4 (&p)[3]) {
   }
 }
 
+// Tile-selection experiments (scripts/one_shape.py, wgrad_sweep.py ...) read environment knobs — in the DEV build only
+// (csrc/build.sh dev -> libdvae_dev.so).  The product library has ONE deterministic dispatch: the knobs are constants.
+#ifdef DVAE_DEV
+#include <cstdlib>
+static inline int dvae_dev_knob(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+#else
+#define dvae_dev_knob(name, dflt) (dflt)
+#endif
+
 extern int g_dvae_compute_mode;   // gemm.hip: process default of the contraction arithmetic (DVAE_MODE_*)
 
 extern int g_dvae_last_hip_error;

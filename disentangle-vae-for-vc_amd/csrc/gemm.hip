@@ -1428,9 +1428,9 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   if (p.split_k < 1) p.split_k = 1;
   if (p.split_k > 1 && (p.epi != DVAE_EPI_ATOMIC || p.act != DVAE_ACT_NONE)) return DVAE_EINVAL;
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
-  // tuning knobs for experiments (scripts/one_shape.py); unset in production
-  static const int bk_env = getenv("DVAE_GEMM_BK") ? atoi(getenv("DVAE_GEMM_BK")) : 0;
-  static const int narrow_env = getenv("DVAE_GEMM_NARROW") ? atoi(getenv("DVAE_GEMM_NARROW")) : -1;
+  // tuning knobs for experiments (scripts/one_shape.py): environment variables in the DEV build, constants in the product
+  static const int bk_env = dvae_dev_knob("DVAE_GEMM_BK", 0);
+  static const int narrow_env = dvae_dev_knob("DVAE_GEMM_NARROW", -1);
   int kps = (p.K + p.split_k - 1) / p.split_k;
   // k-tile 32 when the per-split K allows it without padding waste (a long split is simply rounded up to whole
   // 32-deep tiles: the last split takes what is left)
@@ -1445,7 +1445,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   int zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
   // split mode: the 256 x 128 tile (gemm_x3_tall_kernel, one workgroup per CU) when it still fills the chip; an
   // atomically accumulated product (weight gradients) is cut into twice the k-splits for it
-  static const int tall_env = getenv("DVAE_GEMM_TALL") ? atoi(getenv("DVAE_GEMM_TALL")) : -1;
+  static const int tall_env = dvae_dev_knob("DVAE_GEMM_TALL", -1);
   bool tall = false;
   // (its raw-buffer addressing: every k range a multiple of 16, operands below 1 GiB)
   const int64_t a_bytes = (int64_t)(a_kc ? p.M : p.K) * p.lda * 4;
@@ -1463,7 +1463,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     // one workgroup per CU: nothing hides a tile's prologue (cold loads) and epilogue (128 KB of C per CU), so the tile
     // must be long: >= 24 k-steps (measured: 24 and 12 equal, 60 slower by 0.1 ms per step; shorter ones stay
     // on the 128 x 128 kernel, whose two workgroups per CU cover each other's ends)
-    static const int tall_min = getenv("DVAE_GEMM_TALL_MIN") ? atoi(getenv("DVAE_GEMM_TALL_MIN")) : 24;
+    static const int tall_min = dvae_dev_knob("DVAE_GEMM_TALL_MIN", 24);
     const int steps_per_tile = (kps / 16) * (p.tap_mode == 1 ? p.taps : 1);
     tall = (t2 * zdim >= 192 && steps_per_tile >= tall_min) || tall_env == 1;
   }
@@ -1480,7 +1480,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
       sk64 = (p.K + kps64 - 1) / kps64;
     }
     const int z64 = sk64 * (p.tap_mode == 2 ? p.taps : 1);
-    static const int tall16_min = getenv("DVAE_GEMM_TALL16_MIN") ? atoi(getenv("DVAE_GEMM_TALL16_MIN")) : 8;
+    static const int tall16_min = dvae_dev_knob("DVAE_GEMM_TALL16_MIN", 8);
     const int iters = (kps64 / 64) * (p.tap_mode == 1 ? p.taps : 1);
     if (t2 * z64 >= 192 && iters >= tall16_min) {
       tall16 = true;
@@ -1490,7 +1490,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
       zdim = z64;
     }
   }
-  static const int big_env = getenv("DVAE_GEMM_BIG") ? atoi(getenv("DVAE_GEMM_BIG")) : -1;
+  static const int big_env = dvae_dev_knob("DVAE_GEMM_BIG", -1);
   // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
   bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0);
@@ -1503,7 +1503,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   const bool narrow = !big && !tall && !tall16 && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
   const int bn = big ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
-  static const int xcd_env = getenv("DVAE_GEMM_XCDMAP") ? atoi(getenv("DVAE_GEMM_XCDMAP")) : 1;
+  static const int xcd_env = dvae_dev_knob("DVAE_GEMM_XCDMAP", 1);
   p.xcd_map = (xcd_env && (p.tiles_m % 8 == 0) && (xcd_env == 2 || p.tap_mode == 1)) ? 1 : 0;
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)

@@ -1011,6 +1011,36 @@ struct SeqPlan {
   int n_j, mt5, n_m5;
   int64_t frames;   // (entry, step) pairs of this call that carry a recurrent product
 };
+
+// dvae_prof_collect_tags, family 2: tag = kind | H-class << 4 | precision mode << 8
+//   kind 0 / 1: one launch per frame, forward / backward; 2 / 3: the W_hh-resident persistent launch; 4 / 5: H = 64, whole
+//   sequence per launch.  H-class: 0 H = 64, 1 H = 512, 2 H = 1024, 3 other.
+// bytes = ALGORITHMIC L2 -> CU operand bytes of the call at its tiling: per frame, every workgroup pulls its slice of W_hh
+// (per-frame kernels only) and its rows of h[t-1] / dG[t+1]; the persistent launches pull the rows only.
+unsigned lstm_tag(int kind, int H, int pm) {
+  const int hc = H == 64 ? 0 : H == 512 ? 1 : H == 1024 ? 2 : 3;
+  return (unsigned)kind | ((unsigned)hc << 4) | ((unsigned)pm << 8);
+}
+double lstm_bytes(bool bwd, bool pers, const StepArgs& a, const SeqPlan& p, int ndir) {
+  const double H = a.H, K = bwd ? 4.0 * H : H;             // contraction depth
+  const double bw = a.pm == DVAE_MODE_BF16 ? 2.0 : a.pm == DVAE_MODE_F32X3 ? 6.0 : 4.0;
+  double ba = (a.pm == DVAE_MODE_BF16 && a.st16) ? 2.0 : 4.0;   // bytes per element of the streamed rows
+  if (H == 64) return 0.0;
+  if (pers) {
+    if (a.pm == DVAE_MODE_F32X3) {                            // 16 units x 32 rows per workgroup, rows as three bf16 planes
+      const double wgs = (H / 16) * ((a.N + 31) / 32);
+      return (double)p.frames * wgs * 32.0 * K * 6.0;
+    }
+    const int mt = ((int)(H / 32) * ((a.N + 15) / 16) <= 256) ? 1 : 2;
+    const double wgs = (H / 32) * ((a.N + 16 * mt - 1) / (16 * mt));
+    return (double)p.frames * wgs * 16.0 * mt * K * 2.0;     // rows handed over as bf16
+  }
+  // per-frame kernels: a workgroup = 16 hidden units x 16*mt5 rows; its W_hh slice is 64 x H values in both passes
+  const double wgs = (double)p.n_j * p.n_m5;
+  (void)ndir;
+  if (a.pm == DVAE_MODE_F32 || bwd) ba = (a.pm == DVAE_MODE_BF16 && a.st16) ? 2.0 : 4.0;
+  return (double)p.frames * wgs * (64.0 * H * bw + 16.0 * p.mt5 * K * ba);
+}
 int plan_seq(const StepArgs& a, int ndir, int g0, int g1, SeqPlan& p) {
   if (g0 < 0 || g1 < g0) return DVAE_EINVAL;
   p.shifted = a.d[0].shift != 0 || (ndir == 2 && a.d[1].shift != 0);
@@ -1034,9 +1064,10 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   SeqPlan p;
   if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
-  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm, 0))
-    return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
+  const bool pers = ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm, 0);
+  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames, lstm_tag(H == 64 ? 4 : pers ? 2 : 0, H, a.pm),
+                 lstm_bytes(false, pers, a, p, ndir));
+  if (pers) return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_fwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
@@ -1090,9 +1121,10 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   SeqPlan p;
   if ((rc = plan_seq(a, ndir, g0, g1, p))) return rc;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames);
-  if (ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm, 1))
-    return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
+  const bool pers = ndir == 1 && p.whole && dirs[0].pers_ws && dvae_pers_usable(N, H, a.pm, 1);
+  ProfScope prof(2, s, 2.0 * N * 4.0 * H * H * (double)p.frames, lstm_tag(H == 64 ? 5 : pers ? 3 : 1, H, a.pm),
+                 lstm_bytes(true, pers, a, p, ndir));
+  if (pers) return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
     hipLaunchKernelGGL(lstm_seq_bwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);

@@ -84,6 +84,7 @@ DVAE_API int dvae_prof_collect(double* total_ms, int64_t* launches, double* flop
 }
 
 
+#ifdef DVAE_DEV   // probe kernels: experiments only, built into libdvae_dev.so (csrc/build.sh dev), not into the product
 // ---- launch-floor probe (experiments only): n back-to-back launches of a kernel that does nothing / touches LDS
 namespace {
 __global__ void probe_kernel(float* sink, int lds_words) {
@@ -243,3 +244,4 @@ DVAE_API int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void*
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters, shape);
   return dvae_check_launch();
 }
+#endif  // DVAE_DEV

@@ -346,16 +346,6 @@ int dvae_prof_collect(double* total_ms, int64_t* launches, double* flops);
  * of gemm_f32_kernel<A_KC, B_KC, NTW, BK, WG, MODE>; bytes = algorithmic operand bytes (each element once).  Returns the
  * number of distinct tags (<= max_tags written). */
 int dvae_prof_collect_tags(unsigned* tags, double* ms, int64_t* launches, double* flops, double* bytes, int max_tags);
-/* experiments: n back-to-back launches of an empty kernel (launch-floor probe, scripts/launch_floor.py) */
-int dvae_probe_launches(int n, int blocks, int threads, int lds_bytes, float* sink, void* stream);
-/* experiments: register-only MFMA chains (shape 32 -> 32x32x2 f32, else 16x16x4 f32): the matrix-pipe ceiling of THIS chip */
-int dvae_probe_mfma(int blocks, int iters, int shape, float* out, void* stream);
-/* bf16 matrix-pipe ceiling with the split-mode MFMA stream on register operands; pattern 0 zeros, 1 random constant,
- * 2 random changing every k-step; out2[0..1] = shader-clock cycles and 100 MHz reference ticks of block 0's loop */
-/* do the split arithmetic (VALU) of one wave and the MFMAs of another wave of the same SIMD overlap?  which: 1 MFMA waves,
- * 2 VALU waves, 3 both; out2[0] / out2[1] = cycles of an MFMA / a VALU wave of block 0 */
-int dvae_probe_coissue(int blocks, int iters, int which, int prio, float* out, unsigned long long* out2, void* stream);
-int dvae_probe_mfma_bf16(int blocks, int iters, int pattern, float* out, unsigned long long* out2, void* stream);
 #ifdef __cplusplus
 }
 #endif

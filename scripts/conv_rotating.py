@@ -1,5 +1,9 @@
 """GPU-box: the 512->512 conv forward launch, sustained, over ONE operand set (everything stays in the 256 MB Infinity
 Cache) vs rotating over S sets (S x 72 MB: operands come from HBM, as inside the train step).  usage: conv_rotating.py [S]"""
+import os as _os
+# needs the DEVELOPMENT build of the library (csrc/build.sh dev): probes / environment knobs / timelines are not in the product
+_os.environ.setdefault("DVAE_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                                                       "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -2,6 +2,10 @@
 usage: lstm_pers_timeline.py H N [bid] [fwd|bwd]  — median ns between stamps per wave over the frames of one workgroup:
 0 frame start, 1 poll matched + barrier A, 2 MFMAs done / partial tiles written, 3 after barrier B, 4 epilogue done,
 5 after barrier C, 6 (wave 0) payload drained."""
+import os as _os
+# needs the DEVELOPMENT build of the library (csrc/build.sh dev): probes / environment knobs / timelines are not in the product
+_os.environ.setdefault("DVAE_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                                                       "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
 import ctypes as C
 import os
 import sys

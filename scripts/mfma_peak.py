@@ -1,4 +1,8 @@
 """GPU-box: register-only fp32 MFMA chains -> the matrix-pipe ceiling of this chip at the clock it holds."""
+import os as _os
+# needs the DEVELOPMENT build of the library (csrc/build.sh dev): probes / environment knobs / timelines are not in the product
+_os.environ.setdefault("DVAE_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                                                       "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,8 @@
 """GPU-box microbench: conv wgrad (tap mode 2) time against the split-K count."""
+import os as _os
+# needs the DEVELOPMENT build of the library (csrc/build.sh dev): probes / environment knobs / timelines are not in the product
+_os.environ.setdefault("DVAE_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
+                                                       "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
 import os
 import sys
 
