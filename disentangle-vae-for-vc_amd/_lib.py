@@ -22,7 +22,7 @@ class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
                 ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_mode", i32),
-                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint)]
+                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint), ("dbias_ih", vp), ("dbias_hh", vp)]
 
 
 class RepackDesc(C.Structure):
@@ -47,7 +47,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 300     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 301     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {

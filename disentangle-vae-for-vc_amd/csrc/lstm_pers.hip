@@ -55,6 +55,8 @@ struct PersArgs {
   float* c_all;          // [T,N,H]
   const float* dh_out;   // backward: [T,N,ldh]
   char* dgates;          // backward: [T,N,4H] bf16 (s16) or fp32
+  float* db1;            // backward, optional: += column sums of dG over all frames and rows (bias gradients)
+  float* db2;
   unsigned* flags;       // ws + 0
   unsigned* err;         // ws + PERS_ERR_OFF
   char* xch;             // ws + PERS_XCH_OFF
@@ -340,6 +342,7 @@ struct BwdLds {
   f32x4 red[NWV][MT * 2][64];            // partial dH tiles [wave][mt*2+u][lane]
   float stage[16 * MT][4 * 32 + 4];      // fp32 dG (state kept in fp32 only)
   __bf16 gx[4 * MT][16][40];             // dG in A-fragment order [(g, mt)][row][32 units + pad]
+  float bsum[4][32];                     // bias gradient of this workgroup's 128 gate columns (summed at the end)
   int dead;
 };
 
@@ -364,6 +367,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   BwdLds<MT, KL>& L = *reinterpret_cast<BwdLds<MT, KL>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  if (tid < 128) L.bsum[tid >> 5][tid & 31] = 0.f;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the bias gradient: its elements' dG over all frames
 
   // resident W_hh fragments (rows g*H + k-quarter of this wave, columns = the 32 units of this workgroup)
   bf16x8 W[4][2][KR];
@@ -382,9 +387,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   const int tile = (wave * NEL) >> 2, e0 = (wave * NEL) & 3, emt = tile >> 1, eu = tile & 1;
   const int erow0 = emt * 16 + q * 4 + e0, eunit = eu * 16 + r;
   int el_n[NEL];
+  bool el_ok[NEL];
   float dcreg[NEL], ccreg[NEL];
 #pragma unroll
   for (int i = 0; i < NEL; ++i) {
+    el_ok[i] = rb * 16 * MT + erow0 + i < N;
     el_n[i] = min(rb * 16 * MT + erow0 + i, N - 1);
     dcreg[i] = 0.f;
   }
@@ -496,7 +503,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
         ccreg[i] = cp;                      // c[t-1] is the cell state of the next (earlier) frame
         const int row = erow0 + i;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) L.gx[g * MT + (row >> 4)][row & 15][eunit] = (__bf16)o[g];
+        for (int g = 0; g < 4; ++g) {
+          const __bf16 ob = (__bf16)o[g];
+          L.gx[g * MT + (row >> 4)][row & 15][eunit] = ob;
+          // the bias gradient sums dG as STORED (bf16 when the gate gradients are kept in bf16: oracle/bf16_ref.py)
+          if (el_ok[i]) bs[g] += s16 ? (float)ob : o[g];
+        }
         if (!s16) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) L.stage[row][g * 32 + eunit] = o[g];
@@ -555,6 +567,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   for (int step = 0; step < T; step += 2) {
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
+  }
+  if (a.db1 || a.db2) {
+    // db_ih = db_hh = sum over frames and rows of dG (replaces a colsum pass over [T*N, 4H])
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][eunit], bs[g]);
+    __syncthreads();
+    if (tid < 128) {
+      const int g = tid >> 5, u = tid & 31;
+      const float v = L.bsum[g][u];
+      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
+      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
+    }
   }
 }
 
@@ -920,6 +944,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   PersArgs a{};
   a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
   a.dh_out = d.dh_out; a.dgates = (char*)d.dgates;
+  a.db1 = bwd ? d.dbias_ih : nullptr; a.db2 = bwd ? d.dbias_hh : nullptr;
   char* ws = (char*)d.pers_ws;
   a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
   a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = s16 ? 1 : 0;

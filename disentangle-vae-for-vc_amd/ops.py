@@ -567,8 +567,11 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].dc_ws = ptr(dc)
             dirs[d].reverse = d
             dirs[d].state_bf16 = int(s16)
-        if lstm_persistent_usable(N, H, bf, ndir, bwd=True):
+        pers = lstm_persistent_usable(N, H, bf, ndir, bwd=True)
+        if pers:
+            # the persistent launch also leaves the bias gradients (column sums of dG): no colsum pass below
             dirs[0].pers_ws, dirs[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
+            dirs[0].dbias_ih, dirs[0].dbias_hh = ptr(_grad_buf(params[0][2])), ptr(_grad_buf(params[0][3]))
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
@@ -592,7 +595,8 @@ class LstmLayerFn(torch.autograd.Function):
                     sk = _split_k(_tiles(4 * H, H), rows)
                     gemm(a_ptr, b_ptr, gw, None, 4 * H, H, rows, 4 * H, ldh, H, False, False, ACT_NONE, EPI_ATOMIC, sk, mode,
                          flags=(A_BF16 | B_BF16) if s16 else 0)
-                colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
+                if not pers:
+                    colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         for (wi, wh, bi, bh) in params:
             _ready(wi, wh, bi, bh)
         del keep

@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 300
+#define DVAE_ABI_VERSION 301
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -174,6 +174,10 @@ typedef struct {
                          runs in ONE W_hh-resident launch (csrc/lstm_pers.hip) instead of one launch per frame; same
                          arithmetic, same tensors.  One workspace serves every layer run on one stream */
   unsigned pers_timeout_us; /* bound of every cross-workgroup wait of that launch (0: 2 s); see dvae_lstm_pers_check */
+  float* dbias_ih;    /* optional, used by the PERSISTENT backward launch only (dvae_lstm_pers_supported(.., bwd = 1)): the */
+  float* dbias_hh;    /* column sums of dgates over all frames and rows are ADDED to these [4H] vectors (the gradients of
+                         b_ih and b_hh, nn.LSTM keeps two): the caller then skips its dvae_colsum_add pass over dgates.
+                         Ignored (and the caller must run dvae_colsum_add) when the per-frame kernels are used */
 } dvae_lstm_dir_t;
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);

@@ -16,7 +16,7 @@ root, steps = sys.argv[1], float(sys.argv[2])
 tag = sys.argv[3] if len(sys.argv) > 3 else "pmc"
 traffic_json = sys.argv[4] if len(sys.argv) > 4 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-fam = lambda n: ("gemm_f32_kernel" if ("gemm_f32" in n or "gemm_x3" in n) else "lstm_step_* (H>=512)" if "lstm_step" in n else
+fam = lambda n: ("gemm_f32_kernel" if ("gemm_f32" in n or "gemm_x3" in n) else "lstm_step_* (H>=512, per frame)" if "lstm_step" in n else "lstm_pers_* (persistent)" if "lstm_pers" in n else
                  "lstm_seq_*_h64" if "lstm_seq" in n else "adam" if "adam" in n else "bn_*" if "bn_" in n else
                  "colsum" if "colsum" in n else "repack_all" if "repack" in n else "other")
 acc = collections.defaultdict(lambda: collections.defaultdict(float))

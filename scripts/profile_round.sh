@@ -19,6 +19,12 @@ CSV=$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)
 if [ -n "$DB" ]; then python3 scripts/rocpd_stats.py "$DB" "$SUM/${TAG}_kernel_stats.csv" 40 > "$SUM/${TAG}_last_step.txt" 2>&1;
 elif [ -n "$CSV" ]; then cp "$CSV" "$SUM/${TAG}_kernel_stats.csv"; fi
 tail -1 "$OUT/kt.json" > "$SUM/${TAG}_bench_under_profiler.json"
+# 1b. the same for BASELINE configs[2] (bf16, B=128, T=256)
+BENCH16="bench.py --dtype bf16 --batch 128 --frames 256 --steps 6 --warmup 3 --no-cpu-baseline --no-other-configs --no-roofline"
+rocprofv3 --kernel-trace --stats -f csv rocpd -d "$OUT/kt16" -o kt16 -- python3 $BENCH16 > "$OUT/kt16.json" 2> "$OUT/kt16.err"
+DB16=$(find "$OUT/kt16" -name '*results.db' | head -1)
+if [ -n "$DB16" ]; then python3 scripts/rocpd_stats.py "$DB16" "$SUM/${TAG}_bf16_kernel_stats.csv" 40 > "$SUM/${TAG}_bf16_last_step.txt" 2>&1; fi
+tail -1 "$OUT/kt16.json" > "$SUM/${TAG}_bf16_bench_under_profiler.json"
 EAGER="bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-other-configs --no-roofline"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   D="$OUT/pmc_$(echo $C | tr ' ' '_')"
