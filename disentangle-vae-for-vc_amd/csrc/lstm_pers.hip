@@ -109,6 +109,13 @@ __device__ __forceinline__ void pers_give_up(unsigned* err, int code, int bid, i
 //   leaves in HBM goes to an LDS staging tile                                                                     barrier C
 //   wave 0: payload (sc1) -> drain -> flag;   meanwhile waves 1..3 (wave 0 joins): whole-line stores of the staging tile
 constexpr int NWV = 4;
+// fragments in flight at 32-row tiles and H = 1024 (measured)
+#ifndef PERS_PD_FWD2
+#define PERS_PD_FWD2 8
+#endif
+#ifndef PERS_PD_BWD2
+#define PERS_PD_BWD2 6
+#endif
 
 // ======================================================================================================================
 // forward:  G = Xproj[t] + h[t-1] W_hh^T ; i,f,o = sigmoid, g = tanh ; c = f c' + i g ; h = o tanh(c)
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
   constexpr int KW = NCH / NWV;         // chunks per wave
   constexpr int KR = KW - KL;           // ... of which in registers
   constexpr int NEL = 2 * MT;           // (segment, unit) elements per thread: e = e0 .. e0 + NEL - 1 of ONE (mt, u) tile
-  constexpr int PD = (KW * MT > 8) ? KW / 2 : KW;   // chunks of h[t-1] in flight (registers: 256 hold W_hh)
+  constexpr int PD = (KW * MT > 8) ? PERS_PD_FWD2 : KW;   // chunks of h[t-1] in flight (registers: most hold W_hh)
   typedef float fvec __attribute__((ext_vector_type(NEL)));
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   constexpr int KR = KW - KL;
   constexpr int NEL = 2 * MT;
   constexpr int NC = 4 * KW;            // chunks a wave contracts per frame (its unit quarter of all four gates)
-  constexpr int PD = (NC * MT > 32) ? 4 : (NC > 8 ? 8 : NC);   // chunks of dG in flight (registers: 256 hold W_hh)
+  constexpr int PD = (NC * MT > 32) ? PERS_PD_BWD2 : (NC > 8 ? 8 : NC);   // chunks of dG in flight (registers: most hold W_hh)
   typedef float fvec __attribute__((ext_vector_type(NEL)));
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;

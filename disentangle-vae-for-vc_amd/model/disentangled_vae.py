@@ -444,6 +444,18 @@ class DisentangledVAE(nn.Module):
             return mod.torch_layout(tensor)
         return tensor
 
+    def store_first_params(self, batch_size):
+        """The two [2048 x T*128] weights (enc_linear, dec_pre_linear2; 134 MB each at T = 128, 70 % of all parameters):
+        their gradient is ONE outer product over the 2*batch rows of a step, written by an unsplit launch — stored, not
+        accumulated (FlatAdam.set_store_first).  Only while that launch stays unsplit (a small contraction depth)."""
+        from ..ops import _split_k, _tiles
+        out = []
+        for name, w in (("enc_linear.linear_layer.weight", self.enc_linear.linear_layer.weight),
+                        ("dec_pre_linear2.weight", self.dec_pre_linear2.weight)):
+            if _split_k(_tiles(w.shape[0], w.shape[1]), 2 * int(batch_size)) == 1:
+                out.append(name)
+        return out
+
     def storage_layout(self, name, tensor):
         """Inverse of reference_layout: a tensor in the reference's layout -> how parameter `name` is stored here."""
         mod = self.get_submodule(name.rsplit(".", 1)[0])
@@ -474,6 +486,7 @@ class ConvolutionalMulVAE(VariationalBaseModelVAE):
         self.model = DisentangledVAE(latent_dim=self.latent_dim, beta=0.1, batch_size=batch_size,
                                      speaker_size=speaker_size, n_frames=n_frames).to(device)
         self.optimizer = FlatAdam(self.model.backward_param_order(), lr=self.lr, layout=self.model)
+        self.optimizer.set_store_first(self.model.store_first_params(self.batch_size))
         self.train_losses, self.test_losses = [], []
 
     def loss_functionGVAE2(self, x1, x2, x_recon1, x_recon2, recons_x1_hat, recons_x2_hat, q_z1_mu, q_z1_logvar,

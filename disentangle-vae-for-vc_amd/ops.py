@@ -248,13 +248,21 @@ def linear_dgrad(dy, w, mode=None, w16=None):
     return dx
 
 
-def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None, mode=None):
-    """wgrad[Nout,K] += dy[rows,Nout]^T @ x[rows,K] (atomic accumulation, split over rows)"""
+def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None, mode=None, store=False):
+    """wgrad[Nout,K] += dy[rows,Nout]^T @ x[rows,K] (atomic accumulation, split over rows).
+    store: the caller guarantees this launch is the ONLY contribution to `wgrad` this step and that nothing zeroed it
+    (FlatAdam.zero_grad skips such parameters): an unsplit launch then STORES instead of read-modify-writing — for the two
+    134 MB outer products (enc_linear, dec_pre_linear2: K = 2B rows only) that halves an HBM-bound launch."""
     Nout, K = wgrad.shape
     rows = dy.shape[0] if rows is None else rows
     lda = Nout if lda is None else lda
     ldb = K if ldb is None else ldb
     sk = _split_k(_tiles(Nout, K), rows)
+    if store:
+        if sk != 1:
+            raise ValueError("store-first weight gradient needs an unsplit launch")
+        gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, EPI_STORE, 1, mode)
+        return
     # one split: every element has one writer, a plain read-modify-write (coalesced 128-B rows) replaces the atomics
     epi = EPI_ATOMIC if (sk > 1 or os.environ.get("DVAE_WGRAD_ATOMIC") == "1") else EPI_ACCUM
     gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, epi, sk, mode)
@@ -310,7 +318,13 @@ class LinearFn(torch.autograd.Function):
             dy = du
         dx = linear_dgrad(dy, weight, ctx.mode, ctx.w16) if ctx.needs_input_grad[0] else None
         with side_work(dy, x):
-            linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode)
+            # a parameter FlatAdam.zero_grad leaves alone because exactly one unsplit launch writes its gradient per step
+            store = bool(getattr(weight, "_dvae_grad_store_first", False)) and \
+                _split_k(_tiles(weight.shape[0], weight.shape[1]), dy.shape[0]) == 1
+            if getattr(weight, "_dvae_grad_store_first", False) and not store:
+                raise RuntimeError("store-first weight gradient: the launch would be split; clear the flag "
+                                   "(FlatAdam.set_store_first) for this shape")
+            linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode, store=store)
             colsum_add(dy, _grad_buf(bias))
         _ready(weight, bias)
         return dx, None, None, None, None, None

@@ -51,6 +51,7 @@ class FlatAdam:
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
             p._dvae_flat_owned = True      # ops._grad_buf refuses to re-allocate a gradient for such a parameter
         self.lr, self.betas, self.eps = lr, betas, eps
+        self._zero_ranges = [(0, off)]     # what zero_grad clears: everything, minus store-first parameters
         self.dev_state = torch.zeros(4, device=dev, dtype=torch.float32)   # [t, 1-b1^t, sqrt(1-b2^t), -]
         # torch.optim-compatible surface used by callers of the reference wrapper
         self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps}]
@@ -64,9 +65,28 @@ class FlatAdam:
                 return False
         return True
 
+    def set_store_first(self, names):
+        """Parameters whose gradient is WRITTEN (not accumulated) by exactly one launch per step
+        (ops.linear_wgrad_acc(store=True)): zero_grad leaves their slices alone — the zero-fill and the read half of the
+        read-modify-write of a 134 MB gradient are pure HBM traffic.  Only for parameters that get a gradient EVERY step."""
+        names = set(names)
+        for n, p in zip(self.names, self.params):
+            p._dvae_grad_store_first = n in names
+        spans = sorted((self.offsets[n], self.offsets[n] + (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN)
+                       for n, p in zip(self.names, self.params) if n in names)
+        out, lo = [], 0
+        for a, b in spans:
+            if a > lo:
+                out.append((lo, a))
+            lo = max(lo, b)
+        if lo < self.numel:
+            out.append((lo, self.numel))
+        self._zero_ranges = out
+
     def zero_grad(self, set_to_none: bool = False):
         # gradients are accumulated by the HIP backward kernels directly into flat_g
-        self.flat_g.zero_()
+        for lo, hi in self._zero_ranges:
+            self.flat_g[lo:hi].zero_()
 
     def step(self, grad_scale: float = 1.0):
         if not self.flat_p.is_cuda:
