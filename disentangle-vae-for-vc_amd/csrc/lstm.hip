@@ -1142,7 +1142,9 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
         if (p.mt5 == 2) BWD5(2, 64, 1); else BWD5(1, 64, 1);
       } else if (a.pm == DVAE_MODE_F32X3) {
         if (p.mt5 == 2) BWD5(2, 32, 2); else BWD5(1, 64, 2);
-      } else if (p.mt5 == 2) BWD5(2, 64, 0);
+      } else if (p.mt5 == 2) {
+        if (dvae_dev_knob("DVAE_LSTM_BWD_KR", 64) == 32) BWD5(2, 32, 0); else BWD5(2, 64, 0);
+      } else if (dvae_dev_knob("DVAE_LSTM_BWD_KR", 64) == 32) BWD5(1, 32, 0);
       else BWD5(1, 64, 0);
 #undef BWD5
     }

@@ -110,6 +110,9 @@ __device__ __forceinline__ void pers_give_up(unsigned* err, int code, int bid, i
 //   wave 0: payload (sc1) -> drain -> flag;   meanwhile waves 1..3 (wave 0 joins): whole-line stores of the staging tile
 constexpr int NWV = 4;
 // fragments in flight at 32-row tiles and H = 1024 (measured)
+#ifndef PERS_RD_F32
+#define PERS_RD_F32 8
+#endif
 #ifndef PERS_PD_FWD2
 #define PERS_PD_FWD2 8
 #endif
@@ -819,6 +822,231 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
   }
 }
 
+// ======================================================================================================================
+// fp32 backward (the default arithmetic keeps the backward recurrence on the fp32 MFMA: it streams the 4H-wide gate
+// gradients, which no operand split shrinks — lstm.hip).  Persistent form: a workgroup owns 16 hidden units
+// x 32 segments; its 16 columns of W_hh over K = 4H are 64 K fp32 values per wave = 256 VGPRs per lane (fragments of
+// v_mfma_f32_16x16x4_f32, dvae_lstm_pack_w), resident for the whole sequence.  dG[t] is handed over in fp32, one 1-KiB
+// fragment (16 rows x 16 units) per (gate, row tile) and producer: a frame pulls 512 KB per CU from the exchange ring
+// instead of 768 KB per workgroup (W_hh slice + rows) from L2 in the per-frame kernel.  Group = the H/16 workgroups of a row block.
+// ======================================================================================================================
+template <int KL>
+struct F32BwdLds {
+  f32x4 wl[KL > 0 ? NWV : 1][4][KL > 0 ? KL : 1][64];   // W_hh fragments kept in LDS: [wave][g][k - KR][lane]
+  f32x4 red[NWV][2][64];                 // partial dH tiles [wave][mt][lane]
+  float gx[4 * 2][16][20];               // dG[t] in fragment order [(g, mt)][row][16 units + pad]
+  float bsum[4][16];
+  int dead;
+};
+
+template <int H, int KL>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs a) {
+  constexpr int MT = 2, NEL = 2;
+  constexpr int NPR = H / 16;           // producers of a row group = 16-deep k-chunks per gate
+  constexpr int KW = NPR / NWV;         // chunks per gate and wave (its unit quarter)
+  constexpr int KR = KW - KL;           // ... of which in registers (the fp32 fragments of H = 1024 are 256 registers per lane:
+                                        // half of them live in LDS, 128 KB per workgroup)
+  constexpr int NC = 4 * KW;            // chunks a wave contracts per frame
+  constexpr int RD = PERS_RD_F32;       // chunks in flight (x 2 row tiles of 1 KiB each per lane-instruction)
+  const int T = a.T, N = a.N;
+  const int bid = blockIdx.x;
+  const int rb = bid % a.n_rb, jb = bid / a.n_rb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  F32BwdLds<KL>& L = *reinterpret_cast<F32BwdLds<KL>*>(lds_raw);
+  volatile int* dead = &L.dead;
+  if (tid == 0) *dead = 0;
+  if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // resident W_hh fragments: packed_bwd [(jb*4 + g)][chunk][lane][4] <- W[g*H + 16*chunk + 4q + e][jb*16 + r]
+  f32x4 W[4][KR];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(a.wp + ((((int64_t)(jb * 4 + g)) * NPR + wave * KW + k) * 64 + lane) * 16);
+      if (k < KR) W[g][k < KR ? k : 0] = w;
+      else L.wl[wave][g][k >= KR ? k - KR : 0][lane] = w;
+    }
+
+  // this wave owns (row tile emt, accumulator registers e0, e0+1) of every lane: rows emt*16 + q*4 + e0 + {0,1}, unit r
+  const int emt = wave >> 1, e0 = (wave & 1) * 2;
+  const int erow0 = emt * 16 + q * 4 + e0;
+  int el_n[NEL];
+  bool el_ok[NEL];
+  float dcreg[NEL], ccreg[NEL];
+#pragma unroll
+  for (int i = 0; i < NEL; ++i) {
+    el_ok[i] = rb * 32 + erow0 + i < N;
+    el_n[i] = min(rb * 32 + erow0 + i, N - 1);
+    dcreg[i] = 0.f;
+  }
+  const int j0 = jb * 16;
+  const int64_t H4 = 4 * (int64_t)H;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, a.xch_bytes, 0x00020000);
+  const int slot_bytes = a.n_rb * 4 * NPR * MT * 1024;                    // fragment (g, producer, mt) = 1 KiB
+  const int xld = (rb * 4 * NPR + wave * KW) * MT * 1024 + lane * 16;     // + g*NPR*MT*1024 per gate
+  const int xst = (rb * 4 * NPR + jb) * MT * 1024 + lane * 16;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD_X3 + (lane < NPR ? lane : 0) * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD_X3 + jb * PERS_FLAG_STRIDE;
+
+  struct Ops {
+    float gt[NEL][4], cp[NEL], dho[NEL];
+  };
+  auto frame_t = [&](int step_) { const int fs = T - 1 - step_; return a.reverse ? (T - 1 - fs) : fs; };
+  auto fetch = [&](int step_, Ops& o) {
+    const int t_ = frame_t(step_);
+    const int tp_ = min(max(a.reverse ? t_ + 1 : t_ - 1, 0), T - 1);
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o.gt[i][g] = a.gates[((int64_t)t_ * N + el_n[i]) * H4 + g * H + j0 + r];
+      o.cp[i] = a.c_all[((int64_t)tp_ * N + el_n[i]) * H + j0 + r];
+      o.dho[i] = a.dh_out[((int64_t)t_ * N + el_n[i]) * a.ldh + j0 + r];
+    }
+  };
+
+  auto frame = [&](int step, Ops& cur, Ops& nxt) -> bool {
+    const int fstep = T - 1 - step;
+    const int t = frame_t(step);
+    f32x4 acc[MT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+    PERS_STAMP(0);
+    if (step > 0) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
+        pers_give_up(a.err, 2, bid, step, wave);
+        *dead = 1;
+      }
+      __syncthreads();                                             // barrier A
+      PERS_STAMP(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int so = ((step - 1) & 1) * slot_bytes;
+      // chunk c of this wave: gate g = c / KW, producer k = c % KW of its unit quarter; RD chunks in flight
+      f32x4 av[RD][MT];
+      auto load = [&](int c) {
+        const int g = c / KW, k = c % KW;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          av[c % RD][mt] = __builtin_bit_cast(
+              f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld + ((g * NPR + k) * MT + mt) * 1024, so, 16));
+      };
+#pragma unroll
+      for (int c = 0; c < RD; ++c) load(c);
+      fetch(min(step + 1, T - 1), nxt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int g = c / KW, k = c % KW;
+        const f32x4 w = (k < KR) ? W[g][k < KR ? k : 0] : L.wl[wave][g][k >= KR ? k - KR : 0][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c % RD][mt][e], w[e], acc[mt], 0, 0, 0);
+        if (c + RD < NC) {
+          __builtin_amdgcn_sched_barrier(0);
+          load(c + RD);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      fetch(min(step + 1, T - 1), nxt);
+    }
+    L.red[wave][0][lane] = acc[0];
+    L.red[wave][1][lane] = acc[1];
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
+    if (*dead) return false;
+
+    float o_[NEL][4];
+    {
+      f32x2 rec = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.red[0][emt][lane]) + e0);
+#pragma unroll
+      for (int w = 1; w < NWV; ++w)
+        rec += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.red[w][emt][lane]) + e0);
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const float dh = cur.dho[i] + rec[i];
+        const float gi = cur.gt[i][0], gf = cur.gt[i][1], gg = cur.gt[i][2], go = cur.gt[i][3];
+        const float cp = fstep > 0 ? cur.cp[i] : 0.f;
+        const float tc = gate_tanh(ccreg[i]);
+        const float dc = dcreg[i] + dh * go * (1.f - tc * tc);
+        o_[i][0] = dc * gg * gi * (1.f - gi);
+        o_[i][1] = dc * cp * gf * (1.f - gf);
+        o_[i][2] = dc * gi * (1.f - gg * gg);
+        o_[i][3] = dh * tc * go * (1.f - go);
+        dcreg[i] = dc * gf;
+        ccreg[i] = cp;
+        const int row = erow0 + i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          L.gx[g * MT + (row >> 4)][row & 15][r] = o_[i][g];
+          if (el_ok[i]) bs[g] += o_[i][g];
+        }
+      }
+    }
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
+    if (wave == 0) {
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
+        // lane (r, q): units 4q..4q+3 of row r = the 16 bytes of the fragment
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&L.gx[g * MT + mt][r][q * 4]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + (g * NPR * MT + mt) * 1024, so, 16);
+          }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_STAMP(6);
+        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      // waves 1..3 archive dG[t] (fp32, 64-byte row pieces) for the weight-gradient / dx contractions
+      for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
+        const int g = f / MT, mt = f - g * MT;
+        const int n = rb * 32 + mt * 16 + r;
+        if (n < N)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dgates) + ((int64_t)t * N + n) * H4 + g * H + j0 + q * 4) =
+              *reinterpret_cast<const f32x4*>(&L.gx[f][r][q * 4]);
+      }
+    }
+    return true;
+  };
+
+  {
+    const int t0 = frame_t(0);
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) ccreg[i] = a.c_all[((int64_t)t0 * N + el_n[i]) * H + j0 + r];
+  }
+  Ops oa, ob;
+  fetch(0, oa);
+  __syncthreads();
+  for (int step = 0; step < T; step += 2) {
+    if (!frame(step, oa, ob)) break;
+    if (step + 1 < T && !frame(step + 1, ob, oa)) break;
+  }
+  if (a.db1 || a.db2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][r], bs[g]);
+    __syncthreads();
+    if (tid < 64) {
+      const int g = tid >> 4, u = tid & 15;
+      const float v = L.bsum[g][u];
+      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
+      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
+    }
+  }
+}
+
 #ifdef DVAE_PERS_TS
 unsigned long long* g_pers_ts = nullptr;
 int g_pers_ts_bid = 0;
@@ -875,6 +1103,7 @@ bool pers_x3_ok(int N, int H, int cus) {
 // used by lstm.hip: 1 when (N, H, mode, pass) has a persistent kernel on this device
 int dvae_pers_usable(int N, int H, int pm, int bwd) {
   if (pm == DVAE_MODE_F32X3) return !bwd && pers_x3_ok(N, H, pers_cu_count());
+  if (pm == DVAE_MODE_F32) return bwd && pers_x3_ok(N, H, pers_cu_count());      // fp32 backward: the same 16 x 32 tiling
   if (pm != DVAE_MODE_BF16) return 0;
   return pers_mt(N, H, pers_cu_count()) != 0;
 }
@@ -893,7 +1122,9 @@ DVAE_API int64_t dvae_lstm_pers_ws_bytes(int N, int H) {
   }
   if (pers_x3_ok(N, H, 256)) {
     const int64_t x3 = PERS_XCH_OFF + 2 * (int64_t)((N + 31) / 32) * (H / 32) * 2 * 3 * 1024;
+    const int64_t f32b = PERS_XCH_OFF + 2 * (int64_t)((N + 31) / 32) * 4 * (H / 16) * 2 * 1024;
     need = x3 > need ? x3 : need;
+    need = f32b > need ? f32b : need;
   }
   return need;
 }
@@ -943,6 +1174,42 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     const int grid = (H / 16) * a.n_rb;
     if (H == 1024) return pers_launch_x3<1024, 8>(a, grid, s);
     return pers_launch_x3<512, 0>(a, grid, s);
+  }
+  if (d.packed_mode == DVAE_MODE_F32) {
+    if (!bwd || d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
+    PersArgs a{};
+    a.gates = d.gates; a.wp = (const char*)d.w_packed; a.c_all = d.c_all; a.dh_out = d.dh_out; a.dgates = (char*)d.dgates;
+    a.db1 = d.dbias_ih; a.db2 = d.dbias_hh;
+    char* ws = (char*)d.pers_ws;
+    a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
+    a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = 0;
+    a.n_rb = (N + 31) / 32;
+    const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
+    a.timeout = us > 40000000u ? 4000000000u : us * 100u;
+    a.xch_bytes = 2 * a.n_rb * 4 * (H / 16) * 2 * 1024;
+    a.drop_bid = drop_bid;
+#ifdef DVAE_PERS_TS
+    a.ts = g_pers_ts;
+    a.ts_bid = g_pers_ts_bid;
+#endif
+    if (hipMemsetAsync(ws, 0, (size_t)a.n_rb * PERS_FLAG_LD_X3 * 4, s) != hipSuccess) {
+      g_dvae_last_hip_error = (int)hipGetLastError();
+      return DVAE_ELAUNCH;
+    }
+    const int grid = (H / 16) * a.n_rb;
+    if (H == 1024) {
+      constexpr int KL = 8;
+      const int lds = (int)sizeof(F32BwdLds<KL>) > PERS_PAD_LDS ? (int)sizeof(F32BwdLds<KL>) : PERS_PAD_LDS;
+      static bool set = false;
+      if (!set) { (void)hipFuncSetAttribute((const void*)lstm_pers_bwd_f32<1024, KL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL((lstm_pers_bwd_f32<1024, KL>), dim3(grid), dim3(64 * NWV), lds, s, a);
+    } else {
+      const int lds = (int)sizeof(F32BwdLds<0>) > PERS_PAD_LDS ? (int)sizeof(F32BwdLds<0>) : PERS_PAD_LDS;
+      static bool set = false;
+      if (!set) { (void)hipFuncSetAttribute((const void*)lstm_pers_bwd_f32<512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
+      hipLaunchKernelGGL((lstm_pers_bwd_f32<512, 0>), dim3(grid), dim3(64 * NWV), lds, s, a);
+    }
+    return dvae_check_launch();
   }
   const int mt = pers_mt(N, H, cus);
   if (!mt || d.packed_mode != DVAE_MODE_BF16) return DVAE_EINVAL;

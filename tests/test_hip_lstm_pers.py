@@ -112,33 +112,48 @@ def test_persistent_matches_frame_kernels(env, H, T, N, s16, reverse):
 
 @pytest.mark.parametrize("H,T,N,reverse", [(1024, 8, 128, 0), (512, 6, 128, 0), (1024, 5, 40, 1), (512, 1, 128, 0),
                                             (1024, 3, 17, 0)])
-def test_persistent_fp32x3_forward_matches_frame_kernels(env, H, T, N, reverse):
-    """fp32x3 (the default arithmetic): the forward recurrence on three resident bf16 planes of W_hh, h handed over as
-    three planes.  fp32 results: against the per-frame fp32x3 kernels only the fp32 summation order differs."""
+def test_persistent_fp32x3_forward_fp32_backward_match_frame_kernels(env, H, T, N, reverse):
+    """The default arithmetic: the forward recurrence on three resident bf16 planes of W_hh (h handed over as three
+    planes, fp32 results), the backward one on resident fp32 fragments (dG handed over in fp32).  Against the per-frame
+    kernels of the same arithmetic only the fp32 summation order differs; the persistent backward also leaves the bias
+    gradient (column sums of dG)."""
     _lib, ops, lstm_local = env
     L, st, ptr = _lib.lib(), _lib.stream(), _lib.ptr
-    X3 = _lib.MODE_F32X3
+    X3, F32 = _lib.MODE_F32X3, _lib.MODE_F32
     assert ops.lstm_persistent_usable(N, H, X3) and not ops.lstm_persistent_usable(N, H, X3, bwd=True)
+    assert ops.lstm_persistent_usable(N, H, F32, bwd=True) and not ops.lstm_persistent_usable(N, H, F32)
     g = torch.Generator(device="cuda").manual_seed(H + T + N)
     f = dict(device="cuda", dtype=torch.float32)
     w_hh = (torch.rand(4 * H, H, generator=g, **f) * 2 - 1) / H ** 0.5
     der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), X3)
     gates0 = torch.rand(T * N, 4 * H, generator=g, **f) * 2 - 1
+    dh = (torch.rand(T * N, H, generator=g, **f) * 2 - 1) * 0.1
     outs = []
     for pers in (False, True):
         gates, h, c = gates0.clone(), torch.full((T * N, H), float("nan"), **f), torch.empty(T * N, H, **f)
+        dg, dc, db = torch.full((T * N, 4 * H), float("nan"), **f), torch.empty(N, H, **f), torch.zeros(2, 4 * H, **f)
         d = (_lib.LstmDir * 1)()
         d[0].gates, d[0].c_all, d[0].h_out, d[0].w_hh, d[0].w_packed = ptr(gates), ptr(c), ptr(h), ptr(w_hh), ptr(der.pack_f)
         d[0].reverse, d[0].packed_mode = reverse, X3
         if pers:
             d[0].pers_ws = ptr(ops.lstm_pers_workspace("cuda"))
         _lib.check(L.dvae_lstm_seq_fwd(d, 1, T, N, H, H, st), "fwd")
+        b = (_lib.LstmDir * 1)()
+        b[0].gates, b[0].c_all, b[0].w_hh, b[0].w_packed = ptr(gates), ptr(c), ptr(der.w_hh_t), ptr(der.pack_b)
+        b[0].dh_out, b[0].dgates, b[0].dc_ws, b[0].reverse, b[0].packed_mode = ptr(dh), ptr(dg), ptr(dc), reverse, F32
+        if pers:
+            b[0].pers_ws, b[0].dbias_ih, b[0].dbias_hh = ptr(ops.lstm_pers_workspace("cuda")), ptr(db[0]), ptr(db[1])
+        _lib.check(L.dvae_lstm_seq_bwd(b, 1, T, N, H, H, st), "bwd")
         ops.lstm_pers_check()
-        outs.append((gates, c, h))
-    for name, a, b in zip(("gates", "c", "h"), outs[1], outs[0]):
+        outs.append((gates, c, h, dg, db))
+    for name, a, b in zip(("gates", "c", "h", "dgates"), outs[1], outs[0]):
         assert torch.isfinite(a).all(), name
         err = float((a - b).abs().max())
         assert err <= 2e-5 * float(b.abs().max()), f"{name}: max |diff| {err:.3e}"
+    want = outs[0][3].double().sum(0)
+    for k in range(2):
+        err = float((outs[1][4][k].double() - want).abs().max())
+        assert err <= 1e-4 * float(want.abs().max()), f"bias gradient {k}: {err:.3e}"
 
 
 def test_persistent_handoffs_under_uneven_load(env):
