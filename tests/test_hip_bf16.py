@@ -134,8 +134,20 @@ def test_conv5(ops, N, T, Cin, Cout):
 
 
 # ------------------------------------------------------------------ LSTM frame kernels (H = 512, 1024) in bf16 mode
-@pytest.mark.parametrize("H,In,T,N", [(512, 128, 6, 20), (1024, 512, 5, 32), (1024, 1024, 3, 128)])
-def test_lstm_layer_bf16(ops, H, In, T, N):
+@pytest.mark.parametrize("persistent", [True, False])
+@pytest.mark.parametrize("H,In,T,N", [(512, 128, 6, 20), (1024, 512, 5, 32), (1024, 1024, 3, 128), (1024, 512, 4, 256)])
+def test_lstm_layer_bf16(ops, H, In, T, N, persistent):
+    """persistent: the W_hh-resident one-launch-per-sequence recurrence (csrc/lstm_pers.hip) / the per-frame kernels."""
+    prev = ops.LSTM_PERSISTENT
+    ops.LSTM_PERSISTENT = persistent
+    try:
+        _lstm_layer_bf16(ops, H, In, T, N)
+        ops.lstm_pers_check()
+    finally:
+        ops.LSTM_PERSISTENT = prev
+
+
+def _lstm_layer_bf16(ops, H, In, T, N):
     """Forward and backward of one LSTM layer against oracle/bf16_ref.lstm_dir (rounded operands, fp32 accumulation)."""
     from oracle.bf16_ref import lstm_dir
     s = 1.0 / np.sqrt(H)

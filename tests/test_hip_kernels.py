@@ -26,6 +26,22 @@ def dev(t):
     return t.cuda().contiguous()
 
 
+class persistent_lstm:
+    """`with persistent_lstm(ops, flag):` — the W_hh-resident one-launch-per-sequence recurrence on / off (off: the
+    one-launch-per-frame kernels, which stay the fallback for shapes without a persistent kernel)."""
+
+    def __init__(self, ops, flag):
+        self.ops, self.flag = ops, flag
+
+    def __enter__(self):
+        self.prev = self.ops.LSTM_PERSISTENT
+        self.ops.LSTM_PERSISTENT = self.flag
+
+    def __exit__(self, *exc):
+        self.ops.LSTM_PERSISTENT = self.prev
+        self.ops.lstm_pers_check()
+
+
 def close(got, ref, rel=2e-4, name=""):
     got = got.detach().cpu().double()
     ref = ref.detach().cpu().double()
@@ -205,7 +221,13 @@ def test_bn_residual(ops):
 @pytest.mark.parametrize("N,T,In,H,bidir", [(8, 12, 512, 64, True), (128, 6, 128, 512, False), (6, 5, 512, 1024, False),
                                             (20, 9, 128, 64, True), (128, 4, 512, 1024, False), (128, 4, 128, 512, True),
                                             (20, 5, 64, 128, False), (20, 5, 96, 256, True), (33, 3, 512, 1024, False)])
-def test_lstm_layer(ops, N, T, In, H, bidir):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_lstm_layer(ops, N, T, In, H, bidir, persistent):
+    with persistent_lstm(ops, persistent):
+        _lstm_layer(ops, N, T, In, H, bidir)
+
+
+def _lstm_layer(ops, N, T, In, H, bidir):
     ref = torch.nn.LSTM(In, H, 1, batch_first=True, bidirectional=bidir)
     x = rnd(N, T, In, seed=1)
     xr = x.clone().requires_grad_()
@@ -229,7 +251,13 @@ def test_lstm_layer(ops, N, T, In, H, bidir):
 
 
 @pytest.mark.parametrize("N,T,In,H", [(128, 8, 512, 1024), (6, 4, 512, 1024), (128, 4, 128, 512), (40, 6, 64, 512)])
-def test_lstm_stack2(ops, N, T, In, H):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_lstm_stack2(ops, N, T, In, H, persistent):
+    with persistent_lstm(ops, persistent):
+        _lstm_stack2(ops, N, T, In, H)
+
+
+def _lstm_stack2(ops, N, T, In, H):
     """ops.LstmStack2Fn (two stacked layers sharing frame launches, the dec_lstm2 schedule of the benchmark) against a
     2-layer nn.LSTM.  N = 128 at H = 1024 is the benchmarked instantiation (32-row tiles, 64-deep stacked forward)."""
     assert ops.LstmStack2Fn.usable(T, H, 2, False)
@@ -357,6 +385,14 @@ def test_layouts(ops):
     acc = torch.zeros(260, device="cuda")
     ops.colsum_add(dev(t), acc)
     close(acc, t.sum(0), rel=1e-5, name="colsum")
+    # bf16 input (the storage of conv / LSTM gradients in the bf16 compute mode): 8 columns per 16-byte load, ragged
+    # column counts (80 = the mel width, 520) and row counts that are not a multiple of the block's rows
+    for R_, C_ in ((300, 80), (1000, 512), (131, 520)):
+        tb = rnd(R_, C_, seed=5).bfloat16()
+        acc1, acc2 = torch.zeros(C_, device="cuda"), torch.ones(C_, device="cuda")
+        ops.colsum_add(tb.cuda(), acc1, acc2)
+        close(acc1, tb.float().sum(0), rel=1e-5, name=f"colsum bf16 {R_}x{C_}")
+        close(acc2, tb.float().sum(0) + 1.0, rel=1e-5, name=f"colsum bf16 second output {R_}x{C_}")
 
 
 def test_prof_hooks(ops):
