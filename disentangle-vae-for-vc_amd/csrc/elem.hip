@@ -395,53 +395,40 @@ __global__ __launch_bounds__(256) void permute_102_kernel(const float* __restric
   }
 }
 
-constexpr int CS_ROWS = 128;
 // out[c] += sum_r X[r][c]: 64 column-quads x 4 row lanes per workgroup, 16-byte loads (1 KiB per wave per row)
 template <bool XB16>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ Xv, float* __restrict__ o1,
                                                      float* __restrict__ o2, int R, int C, int64_t ld, int rows_pb) {
-  // a thread owns VEC consecutive columns = one 16-byte load per row (4 fp32 / 8 bf16): a wave covers 256 / 512 columns
-  constexpr int VEC = XB16 ? 8 : 4;
   using elem_t = typename std::conditional<XB16, __bf16, float>::type;
-  using vec_t = typename std::conditional<XB16, bf16x8, f32x4>::type;
   const elem_t* __restrict__ X = reinterpret_cast<const elem_t*>(Xv);
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + cl) * VEC;
+  const int c = (blockIdx.x * 64 + cl) * 4;
   const int r0 = blockIdx.y * rows_pb, r1 = min(R, r0 + rows_pb);
-  float s[VEC];
-#pragma unroll
-  for (int k = 0; k < VEC; ++k) s[k] = 0.f;
-  if (c + VEC - 1 < C) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c + 3 < C) {
     // eight independent 16-byte loads in flight per thread (one dependent load per iteration left the kernel at
     // ~2 TB/s: too little memory-level parallelism for HBM latency)
     const elem_t* __restrict__ px = X + (int64_t)(r0 + rl) * ld + c;
     const int n = (r1 - r0 - rl + 3) >> 2;          // rows of this thread
     int i = 0;
     for (; i + 8 <= n; i += 8) {
-      vec_t v[8];
+      f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const vec_t*>(px + (int64_t)(i + u) * 4 * ld);
+      for (int u = 0; u < 8; ++u) v[u] = ld4<XB16>(px + (int64_t)(i + u) * 4 * ld, 0);
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int k = 0; k < VEC; ++k) s[k] += (float)v[u][k];
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; i < n; ++i) {
-      const vec_t v = *reinterpret_cast<const vec_t*>(px + (int64_t)i * 4 * ld);
-#pragma unroll
-      for (int k = 0; k < VEC; ++k) s[k] += (float)v[k];
-    }
+    for (; i < n; ++i) s += ld4<XB16>(px + (int64_t)i * 4 * ld, 0);
   } else if (c < C) {
     for (int r = r0 + rl; r < r1; r += 4)
-      for (int k = 0; k < VEC && c + k < C; ++k) s[k] += (float)X[(int64_t)r * ld + c + k];
+      for (int k = 0; k < 4 && c + k < C; ++k) s[k] += (float)X[(int64_t)r * ld + c + k];
   }
-  __shared__ float red[4][64][VEC + 1];
-#pragma unroll
-  for (int k = 0; k < VEC; ++k) red[rl][cl][k] = s[k];
+  __shared__ f32x4 red[4][64];
+  red[rl][cl] = s;
   __syncthreads();
   if (rl == 0 && c < C) {
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
+    for (int k = 0; k < 4; ++k) {
       if (c + k >= C) break;
       const float tot = red[0][cl][k] + red[1][cl][k] + red[2][cl][k] + red[3][cl][k];
       atomicAdd(o1 + c + k, tot);
@@ -788,11 +775,15 @@ DVAE_API int dvae_permute_102(const float* in, float* out, int A, int B, int C, 
 
 DVAE_API int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int C, int64_t ld, int x_bf16, void* stream) {
   if (!X || !out1 || R < 1 || C < 1) return DVAE_EINVAL;
-  if ((ld & (x_bf16 ? 7 : 3)) || (((uintptr_t)X) & 15)) return DVAE_EINVAL;
+  if ((ld & 3) || (((uintptr_t)X) & (x_bf16 ? 7 : 15))) return DVAE_EINVAL;
   // (fewer rows per workgroup for narrow matrices -- more workgroups -- was tried: the extra same-address atomics
   // cost more than the parallelism gains, 0.43 -> 1.0 ms per step)
-  const int cb = x_bf16 ? (C + 511) / 512 : (C + 255) / 256;
-  const int rows_pb = CS_ROWS;
+  const int cb = (C + 255) / 256;
+  // Rows per workgroup: every workgroup ends in one atomic per column, so few, long workgroups win (measured, us at
+  // 128 / 256 / 512 / 1024 rows: [16384 x 512] fp32 18.0 / 9.6 / 8.3 / 10.6; [65536 x 512] bf16 57 / 35 / 23 / 22;
+  // [16384 x 4096] fp32 54 / 52 / 48 / 41): 512, and 1024 once there are >= 512 workgroups even so
+  int rows_pb = ((int64_t)R * cb >= (int64_t)512 * 1024) ? 1024 : 512;
+  if (dvae_dev_knob("DVAE_COLSUM_ROWS", 0) > 0) rows_pb = dvae_dev_knob("DVAE_COLSUM_ROWS", 0);
   dim3 grid(cb, (R + rows_pb - 1) / rows_pb);
   if (x_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
   else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
