@@ -28,6 +28,7 @@
 // error record (dvae_lstm_pers_check turns it into DVAE_ELAUNCH) and the whole workgroup leaves the frame loop; its
 // neighbours then time out on it in turn.  All workgroups are co-resident by construction: grid <= CU count (checked on
 // the host), one workgroup per CU (>= 84 KB of LDS each), so a hand-off can only stall behind foreign work on the GPU.
+#include <algorithm>
 #include <type_traits>
 #include "common.h"
 
@@ -110,6 +111,12 @@ __device__ __forceinline__ void pers_give_up(unsigned* err, int code, int bid, i
 //   wave 0: payload (sc1) -> drain -> flag;   meanwhile waves 1..3 (wave 0 joins): whole-line stores of the staging tile
 constexpr int NWV = 4;
 // fragments in flight at 32-row tiles and H = 1024 (measured)
+#ifndef PERS_SPLIT3
+#define PERS_SPLIT3 split3      // (a variant with plain, v_pk_add_f32-packed subtractions measured the same: 11.7 vs 11.8 us)
+#endif
+#ifndef PERS_RD_X3
+#define PERS_RD_X3 4
+#endif
 #ifndef PERS_RD_F32
 #define PERS_RD_F32 8
 #endif
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
   constexpr int KW = NCH / NWV;         // chunks per wave
   constexpr int K2R = KW - K2L;         // chunks whose plane 2 stays in registers
   constexpr int NEL = 2;
-  constexpr int RD = 4;                 // (chunk, row tile) units of h[t-1] in flight: 12 loads per lane
+  constexpr int RD = PERS_RD_X3;        // (chunk, row tile) units of h[t-1] in flight, three 1-KiB loads per lane each
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;
   const int rb = bid % a.n_rb, jb = bid / a.n_rb;
@@ -713,18 +720,23 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
       for (int u = 0; u < RD; ++u) load(u);
       fetch(min(step + 1, T - 1), x);
       __builtin_amdgcn_sched_barrier(0);
+      bf16x8 w2[4];                           // plane 2 of chunk k: read from LDS ONCE per chunk, used by both row tiles
 #pragma unroll
       for (int u = 0; u < KW * MT; ++u) {
         const int k = u / MT, mt = u % MT;
+        if (mt == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            w2[g] = (k < K2R) ? W2[g][k < K2R ? k : 0] : L.w2[wave][g][k >= K2R ? k - K2R : 0][lane];
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const bf16x8 w2 = (k < K2R) ? W2[g][k < K2R ? k : 0] : L.w2[wave][g][k >= K2R ? k - K2R : 0][lane];
           // the six partial products of weight >= 2^-16: (h plane, W plane)
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W01[g][k][0], acc[mt][g], 0, 0, 0);
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W01[g][k][1], acc[mt][g], 0, 0, 0);
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][1], W01[g][k][0], acc[mt][g], 0, 0, 0);
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][1], W01[g][k][1], acc[mt][g], 0, 0, 0);
-          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], w2, acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], w2[g], acc[mt][g], 0, 0, 0);
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][2], W01[g][k][0], acc[mt][g], 0, 0, 0);
         }
         if (u + RD < KW * MT) {
@@ -1047,6 +1059,253 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
   }
 }
 
+// ======================================================================================================================
+// fp32x3 backward (experiment → see DESIGN.md §4.2b): as lstm_pers_bwd_f32, but the recurrent product runs on the bf16 pipe
+// — W_hh as three resident bf16 planes (planes 0, 1 in registers, plane 2 in LDS), dG[t+1] handed over in fp32 and split
+// into three planes BY THE CONSUMER (each value is split by the 64 workgroups that read it: the split is VALU work in the
+// shadow of the MFMAs, 44 operations per 8 values against six 16-cycle MFMAs).  fp32 results, 6/16 of the fp32-MFMA cycles.
+// ======================================================================================================================
+template <int K2L>
+struct X3BwdLds {
+  bf16x8 w2[K2L > 0 ? NWV : 1][4][K2L > 0 ? K2L : 1][64];   // plane 2: [wave][g][k - K2R][lane]
+  f32x4 red[NWV][2][64];
+  float gx[4 * 2][16][20];               // dG[t] (fp32) [(g, mt)][row][16 units + pad]
+  float bsum[4][16];
+  int dead;
+};
+
+template <int H, int K2L>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a) {
+  constexpr int MT = 2, NEL = 2;
+  constexpr int NCH = H / 32;           // 32-deep k-chunks per gate
+  constexpr int NPR = H / 16;           // producers of a row group
+  constexpr int KW = NCH / NWV;         // chunks per gate and wave
+  constexpr int K2R = KW - K2L;
+  constexpr int NU = 4 * KW * MT;       // (gate, chunk, row tile) units a wave contracts per frame
+  constexpr int RD = 8;                 // units in flight (two 1-KiB loads per lane each)
+  const int T = a.T, N = a.N;
+  const int bid = blockIdx.x;
+  const int rb = bid % a.n_rb, jb = bid / a.n_rb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  X3BwdLds<K2L>& L = *reinterpret_cast<X3BwdLds<K2L>*>(lds_raw);
+  volatile int* dead = &L.dead;
+  if (tid == 0) *dead = 0;
+  if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // packed_bwd (three planes): [(jb*4 + g)][chunk][plane][lane][8] <- W[g*H + 32*chunk + 8q + j][jb*16 + r]
+  bf16x8 W01[4][KW][2], W2[4][K2R > 0 ? K2R : 1];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(
+            a.wp + (((((int64_t)(jb * 4 + g)) * NCH + wave * KW + k) * 3 + p) * 64 + lane) * 16);
+        if (p < 2) W01[g][k][p < 2 ? p : 0] = w;
+        else if (k < K2R) W2[g][k < K2R ? k : 0] = w;
+        else L.w2[wave][g][k >= K2R ? k - K2R : 0][lane] = w;
+      }
+
+  const int emt = wave >> 1, e0 = (wave & 1) * 2;
+  const int erow0 = emt * 16 + q * 4 + e0;
+  int el_n[NEL];
+  bool el_ok[NEL];
+  float dcreg[NEL], ccreg[NEL];
+#pragma unroll
+  for (int i = 0; i < NEL; ++i) {
+    el_ok[i] = rb * 32 + erow0 + i < N;
+    el_n[i] = min(rb * 32 + erow0 + i, N - 1);
+    dcreg[i] = 0.f;
+  }
+  const int j0 = jb * 16;
+  const int64_t H4 = 4 * (int64_t)H;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, a.xch_bytes, 0x00020000);
+  const int slot_bytes = a.n_rb * 4 * NCH * MT * 2048;                    // fragment (g, chunk, mt) = two 1-KiB halves
+  const int xld = (rb * 4 * NCH + wave * KW) * MT * 2048 + lane * 16;     // + ((g*NCH + k)*MT + mt)*2048 + half*1024
+  // this workgroup's 16 units are half of chunk jb/2: lanes 32*(jb&1) + (r + 16 q'), q' in {0,1}
+  const int xst = (rb * 4 * NCH + (jb >> 1)) * MT * 2048 + ((jb & 1) * 32 + lane) * 16;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD_X3 + (lane < NPR ? lane : 0) * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD_X3 + jb * PERS_FLAG_STRIDE;
+
+  struct Ops {
+    float gt[NEL][4], cp[NEL], dho[NEL];
+  };
+  auto frame_t = [&](int step_) { const int fs = T - 1 - step_; return a.reverse ? (T - 1 - fs) : fs; };
+  auto fetch = [&](int step_, Ops& o) __attribute__((always_inline)) {
+    const int t_ = frame_t(step_);
+    const int tp_ = min(max(a.reverse ? t_ + 1 : t_ - 1, 0), T - 1);
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o.gt[i][g] = a.gates[((int64_t)t_ * N + el_n[i]) * H4 + g * H + j0 + r];
+      o.cp[i] = a.c_all[((int64_t)tp_ * N + el_n[i]) * H + j0 + r];
+      o.dho[i] = a.dh_out[((int64_t)t_ * N + el_n[i]) * a.ldh + j0 + r];
+    }
+  };
+
+  auto frame = [&](int step, Ops& cur, Ops& nxt) __attribute__((always_inline)) -> bool {
+    const int fstep = T - 1 - step;
+    const int t = frame_t(step);
+    f32x4 acc[MT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+    PERS_STAMP(0);
+    if (step > 0) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
+        pers_give_up(a.err, 2, bid, step, wave);
+        *dead = 1;
+      }
+      __syncthreads();                                             // barrier A
+      PERS_STAMP(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int so = ((step - 1) & 1) * slot_bytes;
+      // unit u: gate g = u / (KW*MT), chunk k = (u / MT) % KW, row tile mt = u % MT; RD units in flight
+      f32x4 av[RD][2];
+      auto load = [&](int u) __attribute__((always_inline)) {
+        const int g = u / (KW * MT), k = (u / MT) % KW, mt = u % MT;
+        // the per-lane part of the address is ONE register (xld); everything else rides in the scalar offset
+        const int off = so + ((g * NCH + k) * MT + mt) * 2048;
+        av[u % RD][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld, off, 16));
+        av[u % RD][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld, off + 1024, 16));
+      };
+      auto split = [&](int u, bf16x8 (&pl)[3]) __attribute__((always_inline)) {
+        bf16x4 lo[3], hi[3];
+        PERS_SPLIT3(av[u % RD][0], lo);
+        PERS_SPLIT3(av[u % RD][1], hi);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pl[p] = __builtin_shufflevector(lo[p], hi[p], 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+#pragma unroll
+      for (int u = 0; u < RD; ++u) load(u);
+      fetch(min(step + 1, T - 1), nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 pl[2][3];                         // planes of the unit being multiplied / of the next one (split under its MFMAs)
+      split(0, pl[0]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < KW; ++k) {
+          const bf16x8 w2 = (k < K2R) ? W2[g][k < K2R ? k : 0] : L.w2[wave][g][k >= K2R ? k - K2R : 0][lane];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int u = (g * KW + k) * MT + mt;
+            if (u + 1 < NU) split(u + 1, pl[(u + 1) & 1]);
+            const bf16x8 (&pc)[3] = pl[u & 1];
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[0], W01[g][k][0], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[0], W01[g][k][1], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[1], W01[g][k][0], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[1], W01[g][k][1], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[0], w2, acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[2], W01[g][k][0], acc[mt], 0, 0, 0);
+            if (u + RD < NU) {
+              __builtin_amdgcn_sched_barrier(0);
+              load(u + RD);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+        }
+    } else {
+      fetch(min(step + 1, T - 1), nxt);
+    }
+    L.red[wave][0][lane] = acc[0];
+    L.red[wave][1][lane] = acc[1];
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
+    if (*dead) return false;
+
+    {
+      f32x2 rec = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.red[0][emt][lane]) + e0);
+#pragma unroll
+      for (int w = 1; w < NWV; ++w)
+        rec += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.red[w][emt][lane]) + e0);
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const float dh = cur.dho[i] + rec[i];
+        const float gi = cur.gt[i][0], gf = cur.gt[i][1], gg = cur.gt[i][2], go = cur.gt[i][3];
+        const float cp = fstep > 0 ? cur.cp[i] : 0.f;
+        const float tc = gate_tanh(ccreg[i]);
+        const float dc = dcreg[i] + dh * go * (1.f - tc * tc);
+        float o[4];
+        o[0] = dc * gg * gi * (1.f - gi);
+        o[1] = dc * cp * gf * (1.f - gf);
+        o[2] = dc * gi * (1.f - gg * gg);
+        o[3] = dh * tc * go * (1.f - go);
+        dcreg[i] = dc * gf;
+        ccreg[i] = cp;
+        const int row = erow0 + i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          L.gx[g * MT + (row >> 4)][row & 15][r] = o[g];
+          if (el_ok[i]) bs[g] += o[g];
+        }
+      }
+    }
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
+    if (wave == 0) {
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
+        if (lane < 32) {               // lane (r, q' in {0,1}): units 8q' + 4h .. + 3 of row r go to half h
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&L.gx[g * MT + mt][r][(q & 1) * 8 + 4 * h]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst,
+                                                       so + ((g * NCH * MT) + mt) * 2048 + h * 1024, 16);
+              }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_STAMP(6);
+        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
+        const int g = f / MT, mt = f - g * MT;
+        const int n = rb * 32 + mt * 16 + r;
+        if (n < N)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dgates) + ((int64_t)t * N + n) * H4 + g * H + j0 + q * 4) =
+              *reinterpret_cast<const f32x4*>(&L.gx[f][r][q * 4]);
+      }
+    }
+    return true;
+  };
+
+  {
+    const int t0 = frame_t(0);
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) ccreg[i] = a.c_all[((int64_t)t0 * N + el_n[i]) * H + j0 + r];
+  }
+  Ops oa, ob;
+  fetch(0, oa);
+  __syncthreads();
+  for (int step = 0; step < T; step += 2) {
+    if (!frame(step, oa, ob)) break;
+    if (step + 1 < T && !frame(step + 1, ob, oa)) break;
+  }
+  if (a.db1 || a.db2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][r], bs[g]);
+    __syncthreads();
+    if (tid < 64) {
+      const int g = tid >> 4, u = tid & 15;
+      const float v = L.bsum[g][u];
+      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
+      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
+    }
+  }
+}
+
 #ifdef DVAE_PERS_TS
 unsigned long long* g_pers_ts = nullptr;
 int g_pers_ts_bid = 0;
@@ -1075,34 +1334,65 @@ int pers_mt(int N, int H, int cus) {
 #ifndef PERS_KL
 #define PERS_KL 2
 #endif
-template <int H, int MT>
-int pers_launch_one(bool bwd, const PersArgs& a, int grid, hipStream_t s) {
-  // LDS: partial tiles + staging + fragment-ordered state (+ part of W_hh); padded so that exactly one workgroup fits a CU
-  constexpr int KL = (H == 1024 && MT == 2) ? PERS_KL : 0;
-  const int need = bwd ? (int)sizeof(BwdLds<MT, KL>) : (int)sizeof(FwdLds<MT, KL>);
-  const int lds = need > PERS_PAD_LDS ? need : PERS_PAD_LDS;
-  auto kern = bwd ? lstm_pers_bwd_bf16<H, MT, KL> : lstm_pers_fwd_bf16<H, MT, KL>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[bwd]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set[bwd] = true;
-  }
+
+// one launch: LDS padded so that exactly one workgroup fits a CU
+template <class K>
+int pers_go(K kern, int need_lds, const PersArgs& a, int grid, hipStream_t s) {
+  const int lds = need_lds > PERS_PAD_LDS ? need_lds : PERS_PAD_LDS;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);   // idempotent, host-side only
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, s, a);
   return dvae_check_launch();
 }
 
-}  // namespace
+// kind: 0 bf16 forward, 1 bf16 backward, 2 fp32x3 forward, 3 fp32 backward, 4 fp32x3 backward
+int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStream_t s) {
+  constexpr int KL = PERS_KL;
+  switch (kind) {
+    case 0:
+      if (H == 1024 && mt == 1) return pers_go(lstm_pers_fwd_bf16<1024, 1, 0>, (int)sizeof(FwdLds<1, 0>), a, grid, s);
+      if (H == 1024) return pers_go(lstm_pers_fwd_bf16<1024, 2, KL>, (int)sizeof(FwdLds<2, KL>), a, grid, s);
+      if (mt == 1) return pers_go(lstm_pers_fwd_bf16<512, 1, 0>, (int)sizeof(FwdLds<1, 0>), a, grid, s);
+      return pers_go(lstm_pers_fwd_bf16<512, 2, 0>, (int)sizeof(FwdLds<2, 0>), a, grid, s);
+    case 1:
+      if (H == 1024 && mt == 1) return pers_go(lstm_pers_bwd_bf16<1024, 1, 0>, (int)sizeof(BwdLds<1, 0>), a, grid, s);
+      if (H == 1024) return pers_go(lstm_pers_bwd_bf16<1024, 2, KL>, (int)sizeof(BwdLds<2, KL>), a, grid, s);
+      if (mt == 1) return pers_go(lstm_pers_bwd_bf16<512, 1, 0>, (int)sizeof(BwdLds<1, 0>), a, grid, s);
+      return pers_go(lstm_pers_bwd_bf16<512, 2, 0>, (int)sizeof(BwdLds<2, 0>), a, grid, s);
+    case 2:
+      if (H == 1024) return pers_go(lstm_pers_fwd_x3<1024, 8>, (int)sizeof(X3Lds<8, 8>), a, grid, s);
+      return pers_go(lstm_pers_fwd_x3<512, 0>, (int)sizeof(X3Lds<4, 0>), a, grid, s);
+    case 3:
+      if (H == 1024) return pers_go(lstm_pers_bwd_f32<1024, 8>, (int)sizeof(F32BwdLds<8>), a, grid, s);
+      return pers_go(lstm_pers_bwd_f32<512, 0>, (int)sizeof(F32BwdLds<0>), a, grid, s);
+    default:
+      if (H == 1024) return pers_go(lstm_pers_bwd_x3<1024, 8>, (int)sizeof(X3BwdLds<8>), a, grid, s);
+      return pers_go(lstm_pers_bwd_x3<512, 0>, (int)sizeof(X3BwdLds<0>), a, grid, s);
+  }
+}
 
-// fp32x3 forward: 32-row tiles, 16 units per workgroup
+// fp32x3 / fp32 kernels: 32-row tiles, 16 units per workgroup
 bool pers_x3_ok(int N, int H, int cus) {
   if (H != 512 && H != 1024) return false;
   const int n_rb = (N + 31) / 32;
   return n_rb <= 4 && (H / 16) * n_rb <= cus;
 }
 
+// bytes of ONE exchange slot (the fragments all workgroups publish in one frame) of kernel `kind`
+int64_t pers_slot_bytes(int kind, int N, int H, int mt) {
+  switch (kind) {
+    case 0: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * (H / 32) * mt * 1024;
+    case 1: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * 4 * (H / 32) * mt * 1024;
+    case 2: return (int64_t)((N + 31) / 32) * (H / 32) * 2 * 3 * 1024;
+    case 3: return (int64_t)((N + 31) / 32) * 4 * (H / 16) * 2 * 1024;
+    default: return (int64_t)((N + 31) / 32) * 4 * (H / 32) * 2 * 2048;
+  }
+}
+
+}  // namespace
+
 // used by lstm.hip: 1 when (N, H, mode, pass) has a persistent kernel on this device
 int dvae_pers_usable(int N, int H, int pm, int bwd) {
-  if (pm == DVAE_MODE_F32X3) return !bwd && pers_x3_ok(N, H, pers_cu_count());
+  if (pm == DVAE_MODE_F32X3) return pers_x3_ok(N, H, pers_cu_count());      // forward, and backward with consumer-side split
   if (pm == DVAE_MODE_F32) return bwd && pers_x3_ok(N, H, pers_cu_count());      // fp32 backward: the same 16 x 32 tiling
   if (pm != DVAE_MODE_BF16) return 0;
   return pers_mt(N, H, pers_cu_count()) != 0;
@@ -1113,133 +1403,59 @@ DVAE_API int dvae_lstm_pers_supported(int N, int H, int mode, int bwd) {
   return dvae_pers_usable(N, H, mode, bwd);
 }
 
-DVAE_API int64_t dvae_lstm_pers_ws_bytes(int N, int H) {
+static int64_t pers_ws_need(int T, int N, int H) {
   if (N < 1 || (H != 512 && H != 1024)) return 0;
-  int64_t need = 0;
-  if (int mt = pers_mt(N, H, 256)) {
-    const int64_t n_rb = (N + 16 * mt - 1) / (16 * mt);
-    need = PERS_XCH_OFF + 2 * n_rb * (4 * (H / 32)) * mt * 1024;
-  }
-  if (pers_x3_ok(N, H, 256)) {
-    const int64_t x3 = PERS_XCH_OFF + 2 * (int64_t)((N + 31) / 32) * (H / 32) * 2 * 3 * 1024;
-    const int64_t f32b = PERS_XCH_OFF + 2 * (int64_t)((N + 31) / 32) * 4 * (H / 16) * 2 * 1024;
-    need = x3 > need ? x3 : need;
-    need = f32b > need ? f32b : need;
-  }
-  return need;
+  int64_t slot = 0;
+  if (int mt = pers_mt(N, H, 256))
+    for (int kind = 0; kind < 2; ++kind) slot = std::max(slot, pers_slot_bytes(kind, N, H, mt));
+  if (pers_x3_ok(N, H, 256))
+    for (int kind = 2; kind < 5; ++kind) slot = std::max(slot, pers_slot_bytes(kind, N, H, 2));
+  if (!slot) return 0;
+  return PERS_XCH_OFF + (T > 0 ? (int64_t)T : 2) * slot;
 }
-
-namespace {
-template <int H, int K2L>
-int pers_launch_x3(const PersArgs& a, int grid, hipStream_t s) {
-  constexpr int KW = H / 32 / NWV;
-  const int need = (int)sizeof(X3Lds<KW, K2L>);
-  const int lds = need > PERS_PAD_LDS ? need : PERS_PAD_LDS;
-  auto kern = lstm_pers_fwd_x3<H, K2L>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NWV), lds, s, a);
-  return dvae_check_launch();
-}
-}  // namespace
+DVAE_API int64_t dvae_lstm_pers_ws_bytes(int N, int H) { return pers_ws_need(0, N, H); }
 
 // one direction of one layer, all T frames; `bwd` selects the pass.  Returns DVAE_EINVAL when the shape has no persistent
 // kernel (the caller then uses the per-frame launches).
 int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, int64_t ldh, int drop_bid, hipStream_t s) {
   const int cus = pers_cu_count();
   if (!d.pers_ws || !d.w_packed || (((uintptr_t)d.pers_ws) & 255)) return DVAE_EINVAL;
-  if (d.packed_mode == DVAE_MODE_F32X3) {
-    if (bwd || d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
-    PersArgs a{};
-    a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
-    char* ws = (char*)d.pers_ws;
-    a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
-    a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = 0;
-    a.n_rb = (N + 31) / 32;
-    const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
-    a.timeout = us > 40000000u ? 4000000000u : us * 100u;
-    a.xch_bytes = 2 * a.n_rb * (H / 32) * 2 * 3 * 1024;
-    a.drop_bid = drop_bid;
-#ifdef DVAE_PERS_TS
-    a.ts = g_pers_ts;
-    a.ts_bid = g_pers_ts_bid;
-#endif
-    if (hipMemsetAsync(ws, 0, (size_t)a.n_rb * PERS_FLAG_LD_X3 * 4, s) != hipSuccess) {
-      g_dvae_last_hip_error = (int)hipGetLastError();
-      return DVAE_ELAUNCH;
-    }
-    const int grid = (H / 16) * a.n_rb;
-    if (H == 1024) return pers_launch_x3<1024, 8>(a, grid, s);
-    return pers_launch_x3<512, 0>(a, grid, s);
+  int kind, mt = 2;
+  if (d.packed_mode == DVAE_MODE_BF16) {
+    mt = pers_mt(N, H, cus);
+    if (!mt) return DVAE_EINVAL;
+    if (d.state_bf16 && (ldh & 7)) return DVAE_EINVAL;
+    kind = bwd ? 1 : 0;
+  } else {
+    if (d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
+    if (d.packed_mode == DVAE_MODE_F32X3) kind = bwd ? 4 : 2;
+    else if (d.packed_mode == DVAE_MODE_F32 && bwd) kind = 3;
+    else return DVAE_EINVAL;
   }
-  if (d.packed_mode == DVAE_MODE_F32) {
-    if (!bwd || d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
-    PersArgs a{};
-    a.gates = d.gates; a.wp = (const char*)d.w_packed; a.c_all = d.c_all; a.dh_out = d.dh_out; a.dgates = (char*)d.dgates;
-    a.db1 = d.dbias_ih; a.db2 = d.dbias_hh;
-    char* ws = (char*)d.pers_ws;
-    a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
-    a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = 0;
-    a.n_rb = (N + 31) / 32;
-    const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
-    a.timeout = us > 40000000u ? 4000000000u : us * 100u;
-    a.xch_bytes = 2 * a.n_rb * 4 * (H / 16) * 2 * 1024;
-    a.drop_bid = drop_bid;
-#ifdef DVAE_PERS_TS
-    a.ts = g_pers_ts;
-    a.ts_bid = g_pers_ts_bid;
-#endif
-    if (hipMemsetAsync(ws, 0, (size_t)a.n_rb * PERS_FLAG_LD_X3 * 4, s) != hipSuccess) {
-      g_dvae_last_hip_error = (int)hipGetLastError();
-      return DVAE_ELAUNCH;
-    }
-    const int grid = (H / 16) * a.n_rb;
-    if (H == 1024) {
-      constexpr int KL = 8;
-      const int lds = (int)sizeof(F32BwdLds<KL>) > PERS_PAD_LDS ? (int)sizeof(F32BwdLds<KL>) : PERS_PAD_LDS;
-      static bool set = false;
-      if (!set) { (void)hipFuncSetAttribute((const void*)lstm_pers_bwd_f32<1024, KL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL((lstm_pers_bwd_f32<1024, KL>), dim3(grid), dim3(64 * NWV), lds, s, a);
-    } else {
-      const int lds = (int)sizeof(F32BwdLds<0>) > PERS_PAD_LDS ? (int)sizeof(F32BwdLds<0>) : PERS_PAD_LDS;
-      static bool set = false;
-      if (!set) { (void)hipFuncSetAttribute((const void*)lstm_pers_bwd_f32<512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); set = true; }
-      hipLaunchKernelGGL((lstm_pers_bwd_f32<512, 0>), dim3(grid), dim3(64 * NWV), lds, s, a);
-    }
-    return dvae_check_launch();
-  }
-  const int mt = pers_mt(N, H, cus);
-  if (!mt || d.packed_mode != DVAE_MODE_BF16) return DVAE_EINVAL;
-  const bool s16 = d.state_bf16 != 0;
-  if (s16 && (ldh & 7)) return DVAE_EINVAL;
   PersArgs a{};
   a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
   a.dh_out = d.dh_out; a.dgates = (char*)d.dgates;
   a.db1 = bwd ? d.dbias_ih : nullptr; a.db2 = bwd ? d.dbias_hh : nullptr;
   char* ws = (char*)d.pers_ws;
   a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
-  a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = s16 ? 1 : 0;
-  a.n_rb = (N + 16 * mt - 1) / (16 * mt);
+  a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = d.state_bf16 ? 1 : 0;
+  a.n_rb = kind < 2 ? (N + 16 * mt - 1) / (16 * mt) : (N + 31) / 32;
   const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
   a.timeout = us > 40000000u ? 4000000000u : us * 100u;
-  a.xch_bytes = 2 * a.n_rb * (bwd ? 4 : 1) * (H / 32) * mt * 1024;
+  const int64_t slot = pers_slot_bytes(kind, N, H, mt);
+  a.xch_bytes = (int)(2 * slot);
   a.drop_bid = drop_bid;
 #ifdef DVAE_PERS_TS
   a.ts = g_pers_ts;
   a.ts_bid = g_pers_ts_bid;
 #endif
-  const int grid = (H / 32) * a.n_rb;
-  if (hipMemsetAsync(ws, 0, (size_t)a.n_rb * PERS_FLAG_LD * 4, s) != hipSuccess) {
+  const int grid = (kind < 2 ? H / 32 : H / 16) * a.n_rb;
+  const size_t flag_bytes = (size_t)a.n_rb * (kind < 2 ? PERS_FLAG_LD : PERS_FLAG_LD_X3) * 4;
+  if (hipMemsetAsync(ws, 0, flag_bytes, s) != hipSuccess) {
     g_dvae_last_hip_error = (int)hipGetLastError();
     return DVAE_ELAUNCH;
   }
-  if (H == 1024 && mt == 1) return pers_launch_one<1024, 1>(bwd, a, grid, s);
-  if (H == 1024) return pers_launch_one<1024, 2>(bwd, a, grid, s);
-  if (mt == 1) return pers_launch_one<512, 1>(bwd, a, grid, s);
-  return pers_launch_one<512, 2>(bwd, a, grid, s);
+  return pers_dispatch(kind, H, mt, a, grid, s);
 }
 
 DVAE_API int dvae_lstm_pers_check(void* ws, int* info4, void* stream) {

@@ -27,16 +27,17 @@ LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b w_ih16
 
 
 def lstm_pack_modes(mode: int, H: int):
-    """(forward pack mode, backward pack mode) of an LSTM layer under compute mode `mode`: bf16 mode runs both
-    recurrences on bf16 fragments; fp32x3 runs the FORWARD recurrence on three-plane fragments (measured 12.5 vs 14.6 us
-    per H = 1024 layer-frame) and keeps the backward one on the fp32 MFMA (17.6 vs 18.1 at H = 1024, slower at H = 512:
-    it is bound by the dG[t+1] rows it streams, which the split does not shrink).  H not a multiple of 512: fp32."""
+    """(forward pack mode, backward pack mode) of an LSTM layer under compute mode `mode`: the bf16 mode runs both
+    recurrences on bf16 fragments; fp32x3 runs both on three-plane fragments — fp32 results at 6/16 of the fp32-MFMA
+    cycles: the W_hh-resident persistent kernels (csrc/lstm_pers.hip) are matrix-pipe bound, forward 7.1 us per H = 1024
+    frame against 13.8 on the per-frame kernels, backward (dG split into planes by the consumer) 12.2 against 13.4 on
+    resident fp32 fragments and 16.8-18.9 on the per-frame fp32 kernels.  H not a multiple of 512: fp32."""
     if H % 512:
         return _lib.MODE_F32, _lib.MODE_F32
     if mode == _lib.MODE_BF16:
         return _lib.MODE_BF16, _lib.MODE_BF16
     if mode == _lib.MODE_F32X3:
-        return _lib.MODE_F32X3, _lib.MODE_F32
+        return _lib.MODE_F32X3, _lib.MODE_F32X3
     return _lib.MODE_F32, _lib.MODE_F32
 
 

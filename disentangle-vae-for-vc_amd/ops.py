@@ -440,7 +440,7 @@ class ConvBnActFn(torch.autograd.Function):
 # (bf16 compute mode, H = 512 / 1024, (H/32) * ceil(N/32) <= CU count); DVAE_LSTM_PERSISTENT=0 keeps one launch per frame.
 LSTM_PERSISTENT = os.environ.get("DVAE_LSTM_PERSISTENT", "1") != "0"
 LSTM_PERS_TIMEOUT_US = 0                    # 0: the library's default bound (2 s) on every cross-workgroup wait
-_PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the largest workspace any supported (N, H) needs
+_PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the workspace any supported (N, H) needs
 _pers_ws: dict = {}
 
 
@@ -450,14 +450,22 @@ def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1, bwd: bool =
 
 
 def lstm_pers_workspace(dev) -> torch.Tensor:
-    """Flags + sticky error record + exchange ring of the persistent LSTM launches of one device (zeroed once; every
-    launch re-zeroes its flags with a memset node of its own; launches of one stream share it)."""
+    """Flags + sticky error record + two-slot exchange ring of the persistent LSTM launches of one device (zeroed once;
+    every launch re-zeroes its flags with a memset node of its own; launches of one stream share it).
+    (One exchange slot PER FRAME read with plain, L2-cached loads was tried and REMOVED: under hipGraph replay an XCD's L2
+    can still hold a slot's lines from the previous launch — the write-through-coherent loads of the ring are what makes
+    the hand-off independent of cache state)"""
     key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     ws = _pers_ws.get(key)
     if ws is None:
         ws = _pers_ws[key] = torch.zeros(_PERS_WS_BYTES, device=f"cuda:{key}", dtype=torch.uint8)
         assert ws.data_ptr() % 256 == 0
     return ws
+
+
+def _pers_fill(d, dev):
+    """pers_ws / pers_timeout_us of a dvae_lstm_dir_t"""
+    d.pers_ws, d.pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
 
 
 def lstm_pers_check():
@@ -530,7 +538,7 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].state_bf16 = int(s16)
         pers = lstm_persistent_usable(N, H, bf, ndir)
         if pers:
-            dirs[0].pers_ws, dirs[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
+            _pers_fill(dirs[0], dev)
         check(L.dvae_lstm_seq_fwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_fwd")
         ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
         ctx.der = der
@@ -584,7 +592,7 @@ class LstmLayerFn(torch.autograd.Function):
         pers = lstm_persistent_usable(N, H, bf, ndir, bwd=True)
         if pers:
             # the persistent launch also leaves the bias gradients (column sums of dG): no colsum pass below
-            dirs[0].pers_ws, dirs[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
+            _pers_fill(dirs[0], dev)
             dirs[0].dbias_ih, dirs[0].dbias_hh = ptr(_grad_buf(params[0][2])), ptr(_grad_buf(params[0][3]))
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         dx = None
@@ -680,7 +688,7 @@ class LstmStack2Fn(torch.autograd.Function):
                 one[0].gates, one[0].w_hh, one[0].w_packed = ptr(g), ptr(wh), ptr(der[d].pack_f)
                 one[0].h_out, one[0].c_all = ptr(h), ptr(c)
                 one[0].reverse, one[0].packed_mode, one[0].step_shift, one[0].state_bf16 = 0, bf, 0, int(s16)
-                one[0].pers_ws, one[0].pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
+                _pers_fill(one[0], dev)
                 check(L.dvae_lstm_seq_fwd(one, 1, T, N, H, H, st), "dvae_lstm_seq_fwd")
         else:
             for c0 in range(0, T + Tc, Tc):

@@ -216,8 +216,8 @@ int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
  * gate gradients, which no residency shrinks: it stays on the per-frame kernels).
  * dvae_lstm_pers_supported: 1 when a call with (N, H, packed_mode = mode, pass) would take the persistent launch on the
  *   current device (given a workspace), else 0.
- * dvae_lstm_pers_ws_bytes: size of the synchronisation workspace (flags + sticky error record + exchange ring) for
- *   (N, H); 0 when the shape has no persistent kernel.
+ * dvae_lstm_pers_ws_bytes: size of the synchronisation workspace (flags + sticky error record + two-slot exchange ring)
+ *   for (N, H); 0 when the shape has no persistent kernel.
  * dvae_lstm_pers_check: SYNCHRONISES `stream`, then returns DVAE_ELAUNCH if a bounded wait of any persistent launch on
  *   this workspace gave up since the last check (info4 = {code 1 fwd / 2 bwd, workgroup, step, wave}; the outputs of
  *   that launch are garbage), DVAE_OK otherwise.  Not capturable; call it wherever the host synchronises anyway.

@@ -41,7 +41,7 @@ def dirs(b):
     d[0].gates, d[0].c_all, d[0].h_out = ptr(gates), ptr(c), ptr(h)
     d[0].w_hh, d[0].w_packed = (ptr(der.w_hh_t), ptr(der.pack_b)) if b else (ptr(w_hh), ptr(der.pack_f))
     d[0].dh_out, d[0].dgates, d[0].dc_ws = ptr(dh), ptr(dg), ptr(dc)
-    d[0].packed_mode, d[0].state_bf16, d[0].pers_ws = (0 if (b and MODE == 2) else MODE), int(MODE == 1), ptr(ws)
+    d[0].packed_mode, d[0].state_bf16, d[0].pers_ws = MODE, int(MODE == 1), ptr(ws)
     return d
 
 

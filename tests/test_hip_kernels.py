@@ -408,9 +408,11 @@ def test_prof_hooks(ops):
 
 # ------------------------------------------------------------------ edge cases / error behaviour
 @pytest.mark.parametrize("N,T,In,H,bidir", [(1, 1, 128, 64, True), (17, 3, 128, 512, False), (33, 2, 512, 1024, False)])
-def test_lstm_ragged_sizes(ops, N, T, In, H, bidir):
+@pytest.mark.parametrize("persistent", [True, False])
+def test_lstm_ragged_sizes(ops, N, T, In, H, bidir, persistent):
     """Segment counts that are not multiples of the 16-row MFMA tile, single frame, single segment."""
-    test_lstm_layer(ops, N, T, In, H, bidir)
+    with persistent_lstm(ops, persistent):
+        _lstm_layer(ops, N, T, In, H, bidir)
 
 
 @pytest.mark.parametrize("N,T", [(1, 1), (1, 3), (2, 2), (5, 7)])

@@ -108,19 +108,27 @@ def test_persistent_matches_frame_kernels(env, H, T, N, s16, reverse):
     ref = lay.run(pers=False)
     got = lay.run(pers=True)
     compare(got, ref, f"H={H} T={T} N={N} s16={s16} rev={reverse}")
+    # the same exchange slots again with OTHER data (another layer, the next training step): nothing of the previous
+    # launches may be read back from a cache
+    lay.gates0.neg_().mul_(0.7)
+    lay.dh.mul_(-1.3)
+    ref = lay.run(pers=False)
+    got = lay.run(pers=True)
+    compare(got, ref, f"second launch with other data, H={H} T={T} N={N}")
 
 
 @pytest.mark.parametrize("H,T,N,reverse", [(1024, 8, 128, 0), (512, 6, 128, 0), (1024, 5, 40, 1), (512, 1, 128, 0),
                                             (1024, 3, 17, 0)])
 def test_persistent_fp32x3_forward_fp32_backward_match_frame_kernels(env, H, T, N, reverse):
     """The default arithmetic: the forward recurrence on three resident bf16 planes of W_hh (h handed over as three
-    planes, fp32 results), the backward one on resident fp32 fragments (dG handed over in fp32).  Against the per-frame
+    planes, fp32 results); the backward one on three resident planes too (dG handed over in fp32, split by the consumer)
+    or on resident fp32 fragments.  Against the per-frame
     kernels of the same arithmetic only the fp32 summation order differs; the persistent backward also leaves the bias
     gradient (column sums of dG)."""
     _lib, ops, lstm_local = env
     L, st, ptr = _lib.lib(), _lib.stream(), _lib.ptr
     X3, F32 = _lib.MODE_F32X3, _lib.MODE_F32
-    assert ops.lstm_persistent_usable(N, H, X3) and not ops.lstm_persistent_usable(N, H, X3, bwd=True)
+    assert ops.lstm_persistent_usable(N, H, X3) and ops.lstm_persistent_usable(N, H, X3, bwd=True)
     assert ops.lstm_persistent_usable(N, H, F32, bwd=True) and not ops.lstm_persistent_usable(N, H, F32)
     g = torch.Generator(device="cuda").manual_seed(H + T + N)
     f = dict(device="cuda", dtype=torch.float32)
@@ -128,32 +136,37 @@ def test_persistent_fp32x3_forward_fp32_backward_match_frame_kernels(env, H, T, 
     der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), X3)
     gates0 = torch.rand(T * N, 4 * H, generator=g, **f) * 2 - 1
     dh = (torch.rand(T * N, H, generator=g, **f) * 2 - 1) * 0.1
+    pack_b32 = torch.empty(4 * H * H, **f)          # fp32 fragments of W_hh for the backward pass (der.pack_b: three planes)
+    _lib.check(L.dvae_lstm_pack_w(ptr(w_hh), None, ptr(pack_b32), H, st), "pack")
     outs = []
-    for pers in (False, True):
+    for pers, bmode in ((False, F32), (True, F32), (True, X3)):
         gates, h, c = gates0.clone(), torch.full((T * N, H), float("nan"), **f), torch.empty(T * N, H, **f)
         dg, dc, db = torch.full((T * N, 4 * H), float("nan"), **f), torch.empty(N, H, **f), torch.zeros(2, 4 * H, **f)
         d = (_lib.LstmDir * 1)()
         d[0].gates, d[0].c_all, d[0].h_out, d[0].w_hh, d[0].w_packed = ptr(gates), ptr(c), ptr(h), ptr(w_hh), ptr(der.pack_f)
         d[0].reverse, d[0].packed_mode = reverse, X3
+        ws = ops.lstm_pers_workspace("cuda")
         if pers:
-            d[0].pers_ws = ptr(ops.lstm_pers_workspace("cuda"))
+            d[0].pers_ws = ptr(ws)
         _lib.check(L.dvae_lstm_seq_fwd(d, 1, T, N, H, H, st), "fwd")
         b = (_lib.LstmDir * 1)()
-        b[0].gates, b[0].c_all, b[0].w_hh, b[0].w_packed = ptr(gates), ptr(c), ptr(der.w_hh_t), ptr(der.pack_b)
-        b[0].dh_out, b[0].dgates, b[0].dc_ws, b[0].reverse, b[0].packed_mode = ptr(dh), ptr(dg), ptr(dc), reverse, F32
+        b[0].gates, b[0].c_all, b[0].w_hh = ptr(gates), ptr(c), ptr(der.w_hh_t)
+        b[0].w_packed = ptr(der.pack_b if bmode == X3 else pack_b32)
+        b[0].dh_out, b[0].dgates, b[0].dc_ws, b[0].reverse, b[0].packed_mode = ptr(dh), ptr(dg), ptr(dc), reverse, bmode
         if pers:
-            b[0].pers_ws, b[0].dbias_ih, b[0].dbias_hh = ptr(ops.lstm_pers_workspace("cuda")), ptr(db[0]), ptr(db[1])
+            b[0].pers_ws, b[0].dbias_ih, b[0].dbias_hh = ptr(ws), ptr(db[0]), ptr(db[1])
         _lib.check(L.dvae_lstm_seq_bwd(b, 1, T, N, H, H, st), "bwd")
         ops.lstm_pers_check()
         outs.append((gates, c, h, dg, db))
-    for name, a, b in zip(("gates", "c", "h", "dgates"), outs[1], outs[0]):
-        assert torch.isfinite(a).all(), name
-        err = float((a - b).abs().max())
-        assert err <= 2e-5 * float(b.abs().max()), f"{name}: max |diff| {err:.3e}"
     want = outs[0][3].double().sum(0)
-    for k in range(2):
-        err = float((outs[1][4][k].double() - want).abs().max())
-        assert err <= 1e-4 * float(want.abs().max()), f"bias gradient {k}: {err:.3e}"
+    for which in (1, 2):          # persistent fp32 backward, persistent fp32x3 backward (dG split by the consumer)
+        for name, a, b in zip(("gates", "c", "h", "dgates"), outs[which], outs[0]):
+            assert torch.isfinite(a).all(), name
+            err = float((a - b).abs().max())
+            assert err <= 2e-5 * float(b.abs().max()), f"{name} ({which}): max |diff| {err:.3e}"
+        for k in range(2):
+            err = float((outs[which][4][k].double() - want).abs().max())
+            assert err <= 1e-4 * float(want.abs().max()), f"bias gradient {k} ({which}): {err:.3e}"
 
 
 def test_persistent_handoffs_under_uneven_load(env):
@@ -217,3 +230,4 @@ def test_workspace_size_contract(env):
     assert L.dvae_lstm_pers_ws_bytes(600, 1024) == 0           # would need more workgroups than CUs
     for N, H in ((128, 512), (256, 512), (512, 512), (128, 1024), (256, 1024), (17, 1024)):
         assert L.dvae_lstm_pers_ws_bytes(N, H) <= ops.lstm_pers_workspace("cuda").numel()
+

@@ -62,7 +62,13 @@ def test_against_reference_golden(golden_dir, name):
     gn = np.array([float(p.grad.double().norm()) for _, p in w.model.named_parameters()])
     ref = g["grad_norm"]
     big = np.array([not is_prebn_conv_bias(n) for n in g["param_names"]])
-    np.testing.assert_allclose(gn[big], ref[big], rtol=5e-3)
+    # The style head's gradient (norm 32-170 against 1e2-1e4 elsewhere) is the end of the longest cancellation chain of
+    # the backward pass: run to run (atomic split-K accumulation order + ReLU-gate flips) its norm moves between 1.2e-3
+    # and 4.3e-3 of the reference's at B = 64, T = 128 — with the backward recurrence on fp32 fragments and on three-plane
+    # fragments alike (scripts/diag_gradnorm.py) — and was seen at 5.2e-3 once; everything else stays below 2e-3.
+    style = np.array([n.startswith("style.linear_layer.") for n in g["param_names"]])
+    np.testing.assert_allclose(gn[big & ~style], ref[big & ~style], rtol=5e-3)
+    np.testing.assert_allclose(gn[style], ref[style], rtol=1e-2)
     assert np.all(gn[~big] < 0.2) and np.all(ref[~big] < 0.2)   # round-off only; real gradient norms are >= 50
     for k in g.files:
         if k.startswith("g_"):
