@@ -393,6 +393,7 @@ class ConvBnActFn(torch.autograd.Function):
             return z
         if as16:
             ctx.mark_non_differentiable(zd)
+            ctx.set_materialize_grads(False)      # no zero-fill for the bf16 twin's (never used) gradient
         return z, (zd if as16 else None)
 
     @staticmethod
@@ -547,6 +548,7 @@ class LstmLayerFn(torch.autograd.Function):
             return (h_out, None) if emit16 else h_out
         if emit16:
             ctx.mark_non_differentiable(h_out)
+            ctx.set_materialize_grads(False)
             return _placeholder(R, ldh, dev), h_out
         return h_out.float()          # stand-alone use in the bf16 mode: a real fp32 copy for the caller
 
@@ -705,6 +707,7 @@ class LstmStack2Fn(torch.autograd.Function):
             return (h2, None) if emit16 else h2
         if emit16:
             ctx.mark_non_differentiable(h2)
+            ctx.set_materialize_grads(False)
             return _placeholder(R, H, dev), h2
         return h2.float()
 

@@ -37,6 +37,25 @@ for k in sorted(acc, key=lambda k: -acc[k].get("GRBM_GUI_ACTIVE", 0)):
     n = max(cnt[k].values()) / steps
     busy = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1.0, a.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024)
     print(f"| {k} | {n:.0f} | {busy:.2f} | {2 * a.get('FETCH_SIZE', 0) / 1024 / steps:.0f} | {a.get('WRITE_SIZE', 0) / 1024 / steps:.0f} |")
+# per instantiation of the contraction family (template arguments as rocprofv3 prints them)
+import re
+inst = collections.defaultdict(lambda: collections.defaultdict(float))
+icnt = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        if "gemm_f32" in n or "gemm_x3" in n:
+            k = re.sub(r"\(anonymous namespace\)::|^void |\(.*$", "", n)[:70]
+            inst[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            icnt[k][r["Counter_Name"]] += 1
+if inst:
+    print("\nContraction family by instantiation (fabric-side MB per LAUNCH: 2 x FETCH_SIZE + WRITE_SIZE):\n")
+    print("| instantiation | launches/step | read MB/launch | write MB/launch |")
+    print("|---|---|---|---|")
+    for k in sorted(inst, key=lambda k: -(2 * inst[k].get("FETCH_SIZE", 0) + inst[k].get("WRITE_SIZE", 0))):
+        n = max(1, icnt[k].get("FETCH_SIZE", 0))
+        print(f"| {k} | {n / steps:.0f} | {2 * inst[k].get('FETCH_SIZE', 0) / 1024 / n:.1f} | "
+              f"{inst[k].get('WRITE_SIZE', 0) / 1024 / max(1, icnt[k].get('WRITE_SIZE', 0)):.1f} |")
 g = acc.get("gemm_f32_kernel")
 if g and g.get("FETCH_SIZE") and g.get("WRITE_SIZE"):
     launches = cnt["gemm_f32_kernel"]["FETCH_SIZE"] / steps
