@@ -68,7 +68,9 @@ struct GemmParams {
   int k_per_split;       // multiple of the k-tile
   int act, epi;
   int tiles_m;
-  int xcd_map;           // contiguous m-tile ranges per XCD (see the kernel)
+  int xcd_map;           // XCD-aware workgroup -> tile map (gemm_tile_of)
+  int map_gm, map_gn;    // ... its block of tiles that run on one XCD at a time: map_gm m-tiles x map_gn n-tiles
+  int map_nstr;          // ... n-strips of map_gn tiles (tiles_n / map_gn)
   // conv forward feeding a training-mode BatchNorm: per-column partial sums of the stored outputs, one fp64 pair per
   // (64-row chunk, group, column) in the layout bn.hip's finalize kernels read — drops bn_partial's pass over Y
   double* bn_part;
@@ -94,6 +96,28 @@ struct GemmParams {
 // that read it and the VALU stream sits in front of each MFMA burst.
 // A16 / B16M (bf16 mode only): the operand is ALREADY bf16 in memory (activations written as bf16 by their producers,
 // bf16 weight copies from the repack launch): half the bytes per element and no conversion on the way into LDS.
+// Workgroup -> tile.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2; the workgroups that are
+// resident on an XCD at the same time are consecutive in q = blockIdx.x / 8.  With xcd_map, XCD x owns the CONTIGUOUS
+// m-tiles [x * tiles_m / 8, (x + 1) * tiles_m / 8) (the +-2-row shifts of the conv taps stay in one L2), and walks its
+// part of the tile grid in BLOCKS of map_gm x map_gn tiles — the set that is resident at once — n fastest inside a
+// block, the n-strips of one m-group before the next m-group.  The block reads map_gm A tiles + map_gn B tiles from the
+// fabric and shares them through the L2 (with one n-tile per round, as before, every A tile went over the fabric once
+// per n-tile: 4 GB for the M = 65536, N = 1024, K = 4096 bf16 product, which ran AT the 4 TB/s that allows).
+__device__ __forceinline__ void gemm_tile_of(const GemmParams& p, int& tile_m, int& tile_n) {
+  if (p.xcd_map) {
+    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int blk = p.map_gm * p.map_gn;
+    const int round = q / blk, r = q - round * blk;
+    const int mg = round / p.map_nstr, st = round - mg * p.map_nstr;
+    const int rm = r / p.map_gn;
+    tile_m = x * per + mg * p.map_gm + rm;
+    tile_n = st * p.map_gn + (r - rm * p.map_gn);
+  } else {
+    tile_m = blockIdx.x % p.tiles_m;
+    tile_n = blockIdx.x / p.tiles_m;
+  }
+}
+
 template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0, bool BNS = false, bool A16 = false, bool B16M = false>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
   constexpr bool BF = (MODE == 1), X3 = (MODE == 2);
@@ -124,18 +148,8 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   const int wm = wave / WG, wn = wave % WG;
   const int l31 = lane & 31, kh = lane >> 5;
 
-  // Workgroup -> tile.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2): with xcd_map the
-  // m-tiles an XCD works on are CONTIGUOUS (XCD x owns m-tiles [x*tiles_m/8, (x+1)*tiles_m/8) of every n-tile), so the
-  // +-2-tile row shifts of the conv taps stay in the same L2 instead of being fetched by five different XCDs.
   int tile_m, tile_n;
-  if (WG == 2 && p.xcd_map) {   // (the 16-wave variant never runs tap modes and has no registers to spare)
-    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    tile_m = x * per + q % per;
-    tile_n = q / per;
-  } else {
-    tile_m = blockIdx.x % p.tiles_m;
-    tile_n = blockIdx.x / p.tiles_m;
-  }
+  gemm_tile_of(p, tile_m, tile_n);     // (the 16-wave variant never runs with xcd_map: no registers to spare)
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   int tap_fixed = 0, ks = blockIdx.z;
@@ -646,14 +660,7 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   const int l31 = lane & 31, kh = lane >> 5;
 
   int tile_m, tile_n;
-  if (p.xcd_map) {
-    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    tile_m = x * per + q % per;
-    tile_n = q / per;
-  } else {
-    tile_m = blockIdx.x % p.tiles_m;
-    tile_n = blockIdx.x / p.tiles_m;
-  }
+  gemm_tile_of(p, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   int tap_fixed = 0, ks = blockIdx.z;
   if (p.tap_mode == 2) {
@@ -1075,14 +1082,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p)
   const int l31 = lane & 31, kh = lane >> 5;
 
   int tile_m, tile_n;
-  if (p.xcd_map) {
-    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    tile_m = x * per + q % per;
-    tile_n = q / per;
-  } else {
-    tile_m = blockIdx.x % p.tiles_m;
-    tile_n = blockIdx.x / p.tiles_m;
-  }
+  gemm_tile_of(p, tile_m, tile_n);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   int tap_fixed = 0, ks = blockIdx.z;
   if (p.tap_mode == 2) {
@@ -1504,7 +1504,22 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   const int bn = big ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
   static const int xcd_env = dvae_dev_knob("DVAE_GEMM_XCDMAP", 1);
-  p.xcd_map = (xcd_env && (p.tiles_m % 8 == 0) && (xcd_env == 2 || p.tap_mode == 1)) ? 1 : 0;
+  static const int strip_env = dvae_dev_knob("DVAE_GEMM_STRIP", 8);    // n-tiles per block (0: one, the round-2 map)
+  p.xcd_map = (xcd_env && (p.tiles_m % 8 == 0) && !big && (xcd_env == 2 || p.tap_mode == 1 || strip_env > 0)) ? 1 : 0;
+  {
+    // the block resident on one XCD: 32 CUs x (1 tall | 2 square) workgroups; fabric bytes per block ~ gm * BM + gn * BN
+    const int per = p.tiles_m >> 3, conc = (tall || tall16) ? 32 : 64;
+    int gn = 1;
+    for (int d = 1; d <= (strip_env > 0 ? strip_env : 1); ++d)
+      if (tiles_n % d == 0) gn = d;
+    int gm = 1;
+    for (int d = 1; d <= conc / gn && d <= per; ++d)
+      if (per % d == 0) gm = d;
+    if (strip_env <= 0) gm = per > 0 ? per : 1;
+    p.map_gm = gm;
+    p.map_gn = gn;
+    p.map_nstr = tiles_n / gn;
+  }
   dim3 grid(p.tiles_m * tiles_n, 1, zdim);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
   const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
