@@ -47,7 +47,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 301     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 302     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
@@ -90,6 +90,8 @@ SIGNATURES = {
     "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "dvae_sum_f32": (i32, [vp, vp, vp, vp, i64, vp]),
+    "dvae_zero_f32": (i32, [vp, i64, vp]),
     "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_frames_to_mel": (i32, [vp, vp, i32, i32, i32, vp]),
     "dvae_permute_102": (i32, [vp, vp, i32, i32, i32, vp]),

@@ -713,6 +713,37 @@ DVAE_API int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, in
   return dvae_check_launch();
 }
 
+// x[0, n) = 0 with plain stores, in a launch of its own right in front of the launches that accumulate into x atomically
+// (gradients: FlatAdam.zero_grad; split-k outputs of the Linear layers)
+__global__ __launch_bounds__(256) void zero_kernel(float* __restrict__ x, int64_t n) {
+  const int64_t n4 = n >> 2;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    *reinterpret_cast<f32x4*>(x + 4 * i) = z;
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[(n4 << 2) + threadIdx.x] = 0.f;
+}
+DVAE_API int dvae_zero_f32(float* x, int64_t n, void* stream) {
+  if (!x || n < 1 || (((uintptr_t)x) & 15)) return DVAE_EINVAL;
+  hipLaunchKernelGGL(zero_kernel, dim3(nblk(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, n);
+  return dvae_check_launch();
+}
+
+// out = a + b (+ c): the sum of the gradients that reach a tensor with several consumers (ops.FanoutFn)
+__global__ __launch_bounds__(256) void sum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  const float* __restrict__ c, float* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(a + 4 * i) + *reinterpret_cast<const f32x4*>(b + 4 * i);
+    if (c) v += *reinterpret_cast<const f32x4*>(c + 4 * i);
+    *reinterpret_cast<f32x4*>(out + 4 * i) = v;
+  }
+}
+DVAE_API int dvae_sum_f32(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n < 4 || (n & 3)) return DVAE_EINVAL;
+  if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)out)) & 15) return DVAE_EINVAL;
+  hipLaunchKernelGGL(sum_kernel, dim3(nblk(n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n >> 2);
+  return dvae_check_launch();
+}
+
 DVAE_API int dvae_gather_crop(const float* mels, const int* lens, const int* utt, const int* off, float* out, int n,
                               int C, int T, int Lmax, void* stream) {
   if (!mels || !lens || !utt || !off || !out || n < 1 || C < 1 || T < 1 || Lmax < 1) return DVAE_EINVAL;

@@ -30,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..ops import (ACT_NONE, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, LatentFn, LinearFn, LstmLayerFn,
+from ..ops import (ACT_NONE, fanout, ACT_RELU, ACT_TANH, ConvBnActFn, FramesToMelFn, LatentFn, LinearFn, LstmLayerFn,
                    LstmStack2Fn, Permute102Fn, mel_to_frames)
 from ..derived import DerivedWeights
 from ..optim import FlatAdam
@@ -342,8 +342,9 @@ class DisentangledVAE(nn.Module):
         lin = self.enc_linear.linear_layer
         feat = LinearFn.apply(flat, lin.weight, lin.bias, ACT_RELU, self._w16("enc_linear"))
         st, ct = self.style.linear_layer, self.content.linear_layer
-        return (LinearFn.apply(feat, st.weight, st.bias, ACT_NONE, self._w16("style")),
-                LinearFn.apply(feat, ct.weight, ct.bias, ACT_NONE, self._w16("content")))
+        f_s, f_c = fanout(feat, 2)          # two consumers: their gradients are summed by one launch (ops.FanoutFn)
+        return (LinearFn.apply(f_s, st.weight, st.bias, ACT_NONE, self._w16("style")),
+                LinearFn.apply(f_c, ct.weight, ct.bias, ACT_NONE, self._w16("content")))
 
     def _decode_frames(self, z, T, n_seg, groups):
         p1, p2 = self.dec_pre_linear1, self.dec_pre_linear2
@@ -399,7 +400,14 @@ class DisentangledVAE(nn.Module):
         S, Cn = self.speaker_size, self.latent_dim - self.speaker_size
         if self.eps_override is not None:
             e1, e2, es = (e.to(dev, torch.float32) for e in self.eps_override)
-            eps_c = torch.cat((e1, e2), 0).contiguous() if train else None
+            if not train:
+                eps_c = None
+            elif (e1.is_contiguous() and e2.is_contiguous() and e1.shape == e2.shape and
+                  e1.untyped_storage().data_ptr() == e2.untyped_storage().data_ptr() and
+                  e2.storage_offset() == e1.storage_offset() + e1.numel()):
+                eps_c = e1.as_strided((2 * e1.shape[0], e1.shape[1]), (e1.shape[1], 1))   # adjacent halves of one buffer
+            else:
+                eps_c = torch.cat((e1, e2), 0).contiguous()
             return eps_c, es.contiguous()
         eps_c = torch.randn((2 * Bh, Cn), device=dev, dtype=torch.float32) if train else None
         return eps_c, torch.randn((Bh, S), device=dev, dtype=torch.float32)
@@ -421,7 +429,8 @@ class DisentangledVAE(nn.Module):
         eps_c, eps_s = self._eps(Bh, x1.device, train)
         z, q_mu, q_lv, s_mu, s_lv = LatentFn.apply(style, content, eps_c, eps_s, Bh, S, Cn)
         y = self._decode_frames(z, T, N, 2)                              # [T*N, 80]
-        y_hat = self.postnet.forward_frames(y, N, 2, residual=y,         # y + postnet(y)
+        y, y_res, y_in = fanout(y, 3)       # loss, residual and postnet input: one gradient sum (ops.FanoutFn)
+        y_hat = self.postnet.forward_frames(y_in, N, 2, residual=y_res,  # y + postnet(y)
                                             wpt=[self._wpt(f"postnet.{i}") for i in range(5)],
                                             w16=[self._w16(f"postnet.{i}") for i in range(5)])
         rec = FramesToMelFn.apply(y, N, N_MEL, T)

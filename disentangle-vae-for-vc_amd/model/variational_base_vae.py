@@ -132,13 +132,19 @@ class VariationalBaseModelVAE:
         if self._graph is None:
             self._graph_sig = sig
             self._g_x1, self._g_x2 = torch.empty_like(data1), torch.empty_like(data2)
-            self._g_eps = (torch.empty((Bh, Cn), device=dev), torch.empty((Bh, Cn), device=dev),
-                           torch.empty((Bh, S), device=dev))
+            # the two content-noise halves are views of ONE buffer: the model uses it as is (no concatenation launch)
+            eps_c = torch.empty((2 * Bh, Cn), device=dev)
+            self._g_eps_c = eps_c
+            self._g_eps = (eps_c[:Bh], eps_c[Bh:], torch.empty((Bh, S), device=dev))
         self._g_x1.copy_(data1)
         self._g_x2.copy_(data2)
         user_eps = m.eps_override
-        for dst, src in zip(self._g_eps, user_eps if user_eps is not None else (None, None, None)):
-            dst.copy_(src.to(dev)) if src is not None else dst.normal_()
+        if user_eps is None:               # the eager step's two draws (content [2*Bh, Cn], style [Bh, S]), same order
+            self._g_eps_c.normal_()
+            self._g_eps[2].normal_()
+        else:
+            for dst, src in zip(self._g_eps, user_eps):
+                dst.copy_(src.to(dev))
         m.eps_override = self._g_eps
         try:
             if self._graph is None:

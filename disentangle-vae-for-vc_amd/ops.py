@@ -216,19 +216,29 @@ def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi
                               act, epi, split_k, _mflags(_mode(mode), A, B, Cout) | flags, stream()), "dvae_gemm_f32")
 
 
+def zeros(shape, dev):
+    """fp32 zeros written by dvae_zero_f32 (a launch of its own right in front of the atomic accumulation into it).
+    (One arena for all split-k outputs of a step, cleared by the step's Adam launch, was tried and dropped: with two
+    trainers in one process — an eager one and a graph-replayed one using the same arena addresses back to back — the
+    replayed step's decoder outputs came out 1e-5 off every other run; DESIGN.md, tried and dropped.)"""
+    t = torch.empty(shape, device=dev, dtype=torch.float32)
+    check(lib().dvae_zero_f32(ptr(t), t.numel(), stream()), "dvae_zero_f32")
+    return t
+
+
 def linear_fwd(x, w, b, act=ACT_NONE, mode=None, w16=None):
     """y[M,Nout] = act(x[M,K] @ w[Nout,K]^T + b).  w16: bf16 copy of w (bf16 compute mode), used as the operand."""
     M, K = x.shape
     w = w if w16 is None else w16
     Nout = w.shape[0]
-    y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
     sk = _split_k(_tiles(M, Nout), K)
     if sk > 1:
-        y.zero_()
+        y = zeros((M, Nout), x.device)
         gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, ACT_NONE, EPI_ATOMIC, sk, mode)
         if act != ACT_NONE:
             check(lib().dvae_act_fwd(ptr(y), y.numel(), act, stream()), "dvae_act_fwd")
     else:
+        y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
         gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, act, EPI_STORE, 1, mode)
     return y
 
@@ -240,7 +250,7 @@ def linear_dgrad(dy, w, mode=None, w16=None):
     K = w.shape[1]
     sk = _split_k(_tiles(M, K), Nout)
     if sk > 1:
-        dx = torch.zeros((M, K), device=dy.device, dtype=torch.float32)
+        dx = zeros((M, K), dy.device)
         gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, ACT_NONE, EPI_ATOMIC, sk, mode)
     else:
         dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
@@ -798,6 +808,36 @@ class Permute102Fn(torch.autograd.Function):
 
 
 # ----------------------------------------------------------------------------- latent / losses
+class FanoutFn(torch.autograd.Function):
+    """x -> n aliases of x, one per consumer: the gradients of the consumers are summed by ONE launch of dvae_sum_f32
+    instead of n - 1 element-wise additions issued by the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g.contiguous() for g in gs if g is not None]
+        if not gs:
+            return None, None
+        while len(gs) > 1:
+            a, b = gs.pop(), gs.pop()
+            c = gs.pop() if gs else None
+            if a.numel() % 4 or a.dtype != torch.float32:
+                gs.append(a + b if c is None else a + b + c)
+                continue
+            out = torch.empty_like(a)
+            check(lib().dvae_sum_f32(ptr(a), ptr(b), ptr(c), ptr(out), a.numel(), stream()), "dvae_sum_f32")
+            gs.append(out)
+        return gs[0], None
+
+
+def fanout(x, n):
+    return FanoutFn.apply(x, n) if (x.requires_grad and torch.is_grad_enabled()) else (x,) * n
+
+
 class LatentFn(torch.autograd.Function):
     """Style averaging (x2 head detached), three reparameterisations and the q_z concatenations
     (disentangled_vae.py:222-228, 252-272) in one kernel."""

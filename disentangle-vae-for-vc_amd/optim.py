@@ -86,7 +86,10 @@ class FlatAdam:
     def zero_grad(self, set_to_none: bool = False):
         # gradients are accumulated by the HIP backward kernels directly into flat_g
         for lo, hi in self._zero_ranges:
-            self.flat_g[lo:hi].zero_()
+            if self.flat_g.is_cuda:
+                check(lib().dvae_zero_f32(self.flat_g.data_ptr() + 4 * lo, hi - lo, stream()), "dvae_zero_f32")
+            else:
+                self.flat_g[lo:hi].zero_()
 
     def step(self, grad_scale: float = 1.0):
         if not self.flat_p.is_cuda:

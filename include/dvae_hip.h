@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 301
+#define DVAE_ABI_VERSION 302
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -293,6 +293,15 @@ int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, floa
  * state[2]=sqrt(1-beta2^t); zero-initialised by the caller): replayable from a captured hipGraph.  n % 4 == 0. */
 int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, float grad_scale, float* state, void* stream);
+
+/* x[0, n) = 0 (16-byte aligned): optimizer.zero_grad() (variational_base_vae.py:86) and the outputs that split-k
+ * contractions accumulate into atomically, zeroed by a launch of their own right in front of the accumulation. */
+int dvae_zero_f32(float* x, int64_t n, void* stream);
+
+/* out = a + b (+ c when non-null): the sum of the gradients of a tensor with several consumers — x feeding both
+ * latent heads (disentangled_vae.py:212-215), the decoder output feeding the postnet, its residual and the loss
+ * (variational_base_vae.py:292-293).  n % 4 == 0, 16-byte aligned. */
+int dvae_sum_f32(const float* a, const float* b, const float* c, float* out, int64_t n, void* stream);
 
 /* ---- layout plumbing ----
  * dvae_mel_to_frames: x1,x2 [Bh,C,T] (torch layout, variational_base_vae.py:81-82) -> X[T, 2*Bh, C]; x2 may be

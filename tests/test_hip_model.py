@@ -225,6 +225,19 @@ def test_graph_replay_matches_eager():
             assert int(v1) == int(v2) == 8
         else:
             assert float((v1 - v2).abs().max()) <= 1e-4 * max(1.0, float(v1.abs().max())), n1
+    # a manual zero_grad + backward in between (gradients left behind, other launches in the same buffers) does not leak into
+    # the replayed step
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 150))
+    eps = synthetic_eps(B, seed=250)
+    b.model.eps_override = eps
+    b.optimizer.zero_grad()
+    b.loss_functionGVAE2(x1, x2, *b.model(x1, x2), train=True)[0].backward()
+    assert float(b.optimizer.flat_g.abs().max()) > 0.0
+    a.model.eps_override = eps
+    la, lb = a.step(x1, x2, None, train=True), b.step(x1, x2, None, train=True)
+    for k in range(8):
+        assert rel(lb[k], la[k]) <= 1e-5, (k, la[k], lb[k])
+    assert float((a.optimizer.exp_avg - b.optimizer.exp_avg).norm()) <= 1e-2 * float(a.optimizer.exp_avg.norm())
     # and with a real learning rate the replayed steps train: loss goes down
     c = make(B, T)
     c.enable_graph(True)
