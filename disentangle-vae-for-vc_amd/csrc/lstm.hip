@@ -761,6 +761,10 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
 // no grid barrier, 2 launches per layer instead of 2*T.  (At H >= 512 a row-split would stream all of W_hh per
 // workgroup per frame, so those sizes keep the one-launch-per-frame kernels above.)
 // =====================================================================================================
+// B16 (bf16 compute mode): the recurrent product on v_mfma_f32_16x16x32_bf16 — W_hh rounded to bf16 once (RNE, in
+// registers), h[t-1] rounded as it is written to LDS; everything else (gates, cell state, the stored h) stays fp32.  On the
+// fp32 MFMA the 32 dependent-issue MFMAs of a wave are 2 048 of a frame's ~3 500 cycles per SIMD; here they are 4.
+template <bool B16>
 __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   constexpr int H = 64;
   const StepDir& d = a.d[blockIdx.y];
@@ -770,15 +774,31 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   const int gate = wave & 3, half = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) float hs[16][68];     // h[t-1] rows, k-contiguous
+  __shared__ __attribute__((aligned(16))) float hs[B16 ? 1 : 16][68];     // h[t-1] rows, k-contiguous
+  __shared__ __attribute__((aligned(16))) __bf16 hs16[B16 ? 16 : 1][72];  // ... rounded (144-byte rows: conflict-free b128 reads)
   __shared__ float gs[4][16][65];                                // recurrent pre-activation [gate][row][unit]
 
   f32x4 wf[2][4];   // this wave's W_hh fragments: 2 n-tiles x 4 k-chunks, resident for the whole sequence
+  bf16x8 wb[2][2];  // B16: 2 n-tiles x 2 k-chunks of 32 (lane (r, kq) holds k = 32 kc + 8 kq .. + 7 of unit row r)
 #pragma unroll
-  for (int ntl = 0; ntl < 2; ++ntl)
+  for (int ntl = 0; ntl < 2; ++ntl) {
+    const float* wrow = d.w + ((int64_t)(gate * H + (half * 2 + ntl) * 16 + r)) * H;
+    if constexpr (B16) {
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc)
-      wf[ntl][kc] = *reinterpret_cast<const f32x4*>(d.w + ((int64_t)(gate * H + (half * 2 + ntl) * 16 + r)) * H + kc * 16 + 4 * kq);
+      for (int kc = 0; kc < 2; ++kc) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          wb[ntl][kc][e] = (__bf16)lo[e];
+          wb[ntl][kc][4 + e] = (__bf16)hi[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) wf[ntl][kc] = *reinterpret_cast<const f32x4*>(wrow + kc * 16 + 4 * kq);
+    }
+  }
 
   int erow[2], ej[2];
   bool eok[2];
@@ -789,7 +809,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
     erow[e] = idx >> 6;
     ej[e] = idx & 63;
     eok[e] = (m0 + erow[e]) < N;
-    hs[erow[e]][ej[e]] = 0.f;
+    if constexpr (B16) hs16[erow[e]][ej[e]] = (__bf16)0.f; else hs[erow[e]][ej[e]] = 0.f;
   }
   __syncthreads();
 
@@ -814,13 +834,22 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
     fetch(min(step + 1, T - 1), xn);
 
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if constexpr (B16) {
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&hs[r][kc * 16 + 4 * kq]);
+      for (int kc = 0; kc < 2; ++kc) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(&hs16[r][kc * 32 + 8 * kq]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wb[0][kc], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wb[1][kc], acc[1], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[0][kc][e], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[1][kc][e], acc[1], 0, 0, 0);
+      for (int kc = 0; kc < 4; ++kc) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&hs[r][kc * 16 + 4 * kq]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[0][kc][e], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[1][kc][e], acc[1], 0, 0, 0);
+        }
       }
     }
 #pragma unroll
@@ -838,7 +867,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
       const float c = gf * creg[e] + gi * gg;
       const float h = go * gate_tanh(c);
       creg[e] = c;
-      hs[row][j] = eok[e] ? h : 0.f;
+      if constexpr (B16) hs16[row][j] = (__bf16)(eok[e] ? h : 0.f); else hs[row][j] = eok[e] ? h : 0.f;
       if (eok[e]) {
         const int64_t n = m0 + row;
         float* g = G + n * 4 * H + j;
@@ -860,6 +889,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   }
 }
 
+template <bool B16>      // B16: dG[t+1] and W_hh rounded to bf16 for the recurrent product (see lstm_seq_fwd_h64)
 __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   constexpr int H = 64;
   const StepDir& d = a.d[blockIdx.y];   // d.w = W_hh^T [H][4H]
@@ -869,13 +899,30 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   const int nt = wave & 3, khalf = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
 
-  __shared__ __attribute__((aligned(16))) float dgs[16][260];   // dG[t+1] rows (k = gate*64 + unit)
+  __shared__ __attribute__((aligned(16))) float dgs[B16 ? 1 : 16][260];     // dG[t+1] rows (k = gate*64 + unit)
+  __shared__ __attribute__((aligned(16))) __bf16 dgs16[B16 ? 16 : 1][264];  // ... rounded (528-byte rows)
   __shared__ float rs[2][16][65];                               // partial dHrec per k-half
 
   f32x4 wf[8];
+  bf16x8 wb[4];     // B16: 4 k-chunks of 32 of this wave's k-half
+  {
+    const float* wrow = d.w + (int64_t)(nt * 16 + r) * 4 * H + khalf * 128;
+    if constexpr (B16) {
 #pragma unroll
-  for (int kc = 0; kc < 8; ++kc)
-    wf[kc] = *reinterpret_cast<const f32x4*>(d.w + (int64_t)(nt * 16 + r) * 4 * H + khalf * 128 + kc * 16 + 4 * kq);
+      for (int kc = 0; kc < 4; ++kc) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          wb[kc][e] = (__bf16)lo[e];
+          wb[kc][4 + e] = (__bf16)hi[e];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kc = 0; kc < 8; ++kc) wf[kc] = *reinterpret_cast<const f32x4*>(wrow + kc * 16 + 4 * kq);
+    }
+  }
 
   int erow[2], ej[2];
   bool eok[2];
@@ -887,7 +934,9 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     ej[e] = idx & 63;
     eok[e] = (m0 + erow[e]) < N;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) dgs[erow[e]][g * H + ej[e]] = 0.f;
+    for (int g = 0; g < 4; ++g) {
+      if constexpr (B16) dgs16[erow[e]][g * H + ej[e]] = (__bf16)0.f; else dgs[erow[e]][g * H + ej[e]] = 0.f;
+    }
   }
   __syncthreads();
 
@@ -924,11 +973,19 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     auto& dho = cur.dho;
     fetch(min(step + 1, T - 1), nxt);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (B16) {
 #pragma unroll
-    for (int kc = 0; kc < 8; ++kc) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&dgs[r][khalf * 128 + kc * 16 + 4 * kq]);
+      for (int kc = 0; kc < 4; ++kc) {
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(&dgs16[r][khalf * 128 + kc * 32 + 8 * kq]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wb[kc], acc, 0, 0, 0);
+      }
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[kc][e], acc, 0, 0, 0);
+      for (int kc = 0; kc < 8; ++kc) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&dgs[r][khalf * 128 + kc * 16 + 4 * kq]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[kc][e], acc, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) rs[khalf][kq * 4 + q][nt * 16 + r] = acc[q];
@@ -945,10 +1002,17 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
       const float o2 = dc * gi * (1.f - gg * gg);
       const float o3 = dh * tc * go * (1.f - go);
       dcreg[e] = dc * gf;
-      dgs[row][j] = eok[e] ? o0 : 0.f;
-      dgs[row][H + j] = eok[e] ? o1 : 0.f;
-      dgs[row][2 * H + j] = eok[e] ? o2 : 0.f;
-      dgs[row][3 * H + j] = eok[e] ? o3 : 0.f;
+      if constexpr (B16) {
+        dgs16[row][j] = (__bf16)(eok[e] ? o0 : 0.f);
+        dgs16[row][H + j] = (__bf16)(eok[e] ? o1 : 0.f);
+        dgs16[row][2 * H + j] = (__bf16)(eok[e] ? o2 : 0.f);
+        dgs16[row][3 * H + j] = (__bf16)(eok[e] ? o3 : 0.f);
+      } else {
+        dgs[row][j] = eok[e] ? o0 : 0.f;
+        dgs[row][H + j] = eok[e] ? o1 : 0.f;
+        dgs[row][2 * H + j] = eok[e] ? o2 : 0.f;
+        dgs[row][3 * H + j] = eok[e] ? o3 : 0.f;
+      }
       if (eok[e]) {
         float* o = d.dgates + ((int64_t)t * N + m0 + row) * 4 * H + j;
         o[0] = o0;
@@ -985,8 +1049,9 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
   a.pm = dirs[0].packed_mode;
   if (a.pm != DVAE_MODE_F32 && a.pm != DVAE_MODE_BF16 && a.pm != DVAE_MODE_F32X3) return DVAE_EINVAL;
   for (int i = 0; i < ndir; ++i)
-    if (dirs[i].packed_mode != a.pm || (a.pm && !dirs[i].w_packed)) return DVAE_EINVAL;
-  if (a.pm && (H % 512)) return DVAE_EINVAL;          // bf16 / fp32x3 frame kernels exist for H = 512, 1024, ...
+    if (dirs[i].packed_mode != a.pm || (a.pm && H != 64 && !dirs[i].w_packed)) return DVAE_EINVAL;
+  // bf16 / fp32x3 frame kernels exist for H = 512, 1024, ...; H = 64 has a bf16 form (it rounds W_hh itself: no pack)
+  if (a.pm && (H % 512) && !(H == 64 && a.pm == DVAE_MODE_BF16)) return DVAE_EINVAL;
   a.st16 = dirs[0].state_bf16 ? 1 : 0;
   for (int i = 0; i < ndir; ++i)
     if ((dirs[i].state_bf16 ? 1 : 0) != a.st16) return DVAE_EINVAL;
@@ -1070,7 +1135,8 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    hipLaunchKernelGGL(lstm_seq_fwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_fwd_h64<true>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(lstm_seq_fwd_h64<false>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
   if (H % 512 == 0) {
@@ -1127,7 +1193,8 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    hipLaunchKernelGGL(lstm_seq_bwd_h64, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_bwd_h64<true>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(lstm_seq_bwd_h64<false>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
   if (H % 512 == 0) {

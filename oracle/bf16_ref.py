@@ -9,8 +9,7 @@ vectors) with ONE change, stated operation by operation, that defines what "bf16
 
       Linear / LSTM input projection   y  = r(x) r(W)^T + b        dx = r(dy) r(W)     dW = r(dy)^T r(x)
       Conv1d (k5)                      y  = conv(r(x), r(w)) + b   dx = conv^T(r(dy), r(w))   dw = corr(r(dy), r(x))
-      LSTM recurrence, H % 512 == 0    g_t = pre_t + r(h_{t-1}) r(W_hh)^T      dh_{t-1} = r(dg_t) r(W_hh)
-      LSTM recurrence, H == 64         fp32 (the HIP path keeps W_hh of the small encoder LSTM in registers in fp32)
+      LSTM recurrence (every H)        g_t = pre_t + r(h_{t-1}) r(W_hh)^T      dh_{t-1} = r(dg_t) r(W_hh)
       dW_hh (every H)                  r(dg)^T r(h)
 
 Tensors between operations (activations, gates, BatchNorm, losses, gradients, master weights, Adam) are fp32, with one
@@ -116,7 +115,7 @@ def lstm_dir(x, w_ih, w_hh, b_ih, b_hh, reverse=False, state_bf16=None):
     for t in order:
         g = pre[:, t]
         if not first:
-            g = g + _MatmulNT.apply(h, w_hh, H % 512 == 0)
+            g = g + _MatmulNT.apply(h, w_hh, True)
         first = False
         if state_bf16:
             g = _RoundBwd.apply(g)

@@ -184,6 +184,43 @@ def _lstm_layer_bf16(ops, H, In, T, N):
     assert 1e-5 < float((h32 - h.detach()).abs().max()) < 5e-2
 
 
+@pytest.mark.parametrize("In,T,N,bidir", [(512, 7, 20, True), (128, 5, 33, False), (64, 3, 128, True)])
+def test_lstm_h64_bf16(ops, In, T, N, bidir):
+    """The H = 64 whole-sequence kernels in the bf16 mode: recurrent product on rounded operands (W_hh and h[t-1] / dG[t+1]
+    rounded to bf16, fp32 accumulation), state and gate gradients stored in fp32 — oracle/bf16_ref.lstm_dir."""
+    from oracle.bf16_ref import lstm_dir
+    H = 64
+    s = 1.0 / np.sqrt(H)
+    x = rnd(N, T, In, seed=1)
+    nd = 2 if bidir else 1
+    ps = [[rnd(4 * H, In, seed=10 * d + 2) * s, rnd(4 * H, H, seed=10 * d + 3) * s, rnd(4 * H, seed=10 * d + 4) * s,
+           rnd(4 * H, seed=10 * d + 5) * s] for d in range(nd)]
+    xr = x.clone().requires_grad_()
+    pr = [[p.clone().requires_grad_() for p in pd] for pd in ps]
+    h_ref = torch.cat([lstm_dir(xr, *pr[d], reverse=bool(d)) for d in range(nd)], dim=-1)      # [N, T, nd*H]
+    gh = rnd(N, T, nd * H, seed=6)
+    h_ref.backward(gh)
+    xf = dev(x.permute(1, 0, 2).reshape(T * N, In)).requires_grad_()
+    pg = [[torch.nn.Parameter(dev(p)) for p in pd] for pd in ps]
+    args = pg[0] + (pg[1] if bidir else [None] * 4)
+    h = ops.LstmLayerFn.apply(xf, T, N, *args)
+    hg = h.detach().cpu().reshape(T, N, nd * H).permute(1, 0, 2)
+    assert not torch.equal(hg, hg.bfloat16().float())                   # the state itself is not rounded
+    close(hg, h_ref, rel=1e-3, name="bf16 h64 lstm h")   # (an operand pushed across a bf16 rounding boundary moves h by ~1e-4)
+    for pd in pg:
+        for p in pd:
+            p.grad = torch.zeros_like(p)
+    h.backward(dev(gh.permute(1, 0, 2).reshape(T * N, nd * H)))
+    close(xf.grad.reshape(T, N, In).permute(1, 0, 2), xr.grad, rel=2e-3, name="bf16 h64 lstm dx")
+    for d in range(nd):
+        for nm, p, q in zip(("w_ih", "w_hh", "b_ih", "b_hh"), pg[d], pr[d]):
+            close(p.grad, q.grad, rel=2e-3, name=f"bf16 h64 lstm d{nm}[{d}]")
+    # the recurrence really runs on rounded operands: the fp32 mode gives a measurably different h
+    with ops.compute_dtype("fp32"):
+        h32 = ops.LstmLayerFn.apply(xf.detach(), T, N, *[None if a is None else a.detach() for a in args])
+    assert 1e-6 < float((h32 - h.detach()).abs().max()) < 5e-2
+
+
 # ------------------------------------------------------------------ whole model, bf16 mode
 def _real(pair):
     """(h, h16) of model._lstm -> the values: h16 (bf16 state storage) when present, else h"""
@@ -315,7 +352,12 @@ def test_model_bf16_losses_and_gradients(ops, B, T):
             continue
         g16, g32, gh = grads["bf16"][k], grads["fp32"][k], w.model.reference_layout(k, p.grad).cpu()
         noise = _dist(g16, g32)                                  # what bf16 rounding does to this gradient
-        assert _dist(gh, g16) <= max(3e-2, 1.6 * noise), (k, _dist(gh, g16), noise)
+        # two bf16 realisations whose roundings have decorrelated over the 256-frame recurrences sit ~sqrt(2) x noise apart:
+        # measured (6 runs, scripts history) 1.16-1.37 for most tensors, 1.59-1.61 for the first encoder layer's reverse
+        # biases, 1.70-1.76 / 2.18-2.26 for the style head's weight / bias — the smallest gradient at the end of the
+        # longest chain — since the H = 64 encoder recurrence runs on rounded operands too
+        lim = 2.4 if k.startswith("style.") else 1.75
+        assert _dist(gh, g16) <= max(3e-2, lim * noise), (k, _dist(gh, g16), noise)
         cos = float((gh.double() * g16.double()).sum() / (gh.double().norm() * g16.double().norm()))
         assert cos >= 0.9, (k, cos)
 
