@@ -761,12 +761,23 @@ __global__ __launch_bounds__(512) void lstm_step_bwd_v5(const StepArgs a, int gs
 // no grid barrier, 2 launches per layer instead of 2*T.  (At H >= 512 a row-split would stream all of W_hh per
 // workgroup per frame, so those sizes keep the one-launch-per-frame kernels above.)
 // =====================================================================================================
-// B16 (bf16 compute mode): the recurrent product on v_mfma_f32_16x16x32_bf16 — W_hh rounded to bf16 once (RNE, in
-// registers), h[t-1] rounded as it is written to LDS; everything else (gates, cell state, the stored h) stays fp32.  On the
-// fp32 MFMA the 32 dependent-issue MFMAs of a wave are 2 048 of a frame's ~3 500 cycles per SIMD; here they are 4.
-template <bool B16>
+// PM = 1 (bf16 compute mode): the recurrent product on v_mfma_f32_16x16x32_bf16 — W_hh rounded to bf16 once (RNE, in
+// registers), h[t-1] rounded as it is written to LDS; everything else (gates, cell state, the stored h) stays fp32.
+// PM = 2 (fp32x3, the default arithmetic): both operands split exactly into three bf16 planes (W_hh once, h[t-1] as it
+// is written), six partial products per product: fp32 results.  On the fp32 MFMA (PM = 0) the 32 MFMAs of a wave are
+// 2 048 of a frame's ~3 500 cycles per SIMD; with PM = 1 they are 4 of 16 cycles, with PM = 2 24.
+__device__ __forceinline__ void split3s(float x, __bf16 (&p)[3]) {
+  p[0] = (__bf16)x;
+  float r = x - (float)p[0];
+  p[1] = (__bf16)r;
+  r -= (float)p[1];
+  p[2] = (__bf16)r;       // exact: what is left has at most 8 significant bits
+}
+template <int PM>
 __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   constexpr int H = 64;
+  constexpr bool B16 = PM != 0;
+  constexpr int NP = PM == 2 ? 3 : 1;
   const StepDir& d = a.d[blockIdx.y];
   const int N = a.N, T = a.T;
   const int m0 = blockIdx.x * 16;
@@ -775,11 +786,11 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   const int r = lane & 15, kq = lane >> 4;
 
   __shared__ __attribute__((aligned(16))) float hs[B16 ? 1 : 16][68];     // h[t-1] rows, k-contiguous
-  __shared__ __attribute__((aligned(16))) __bf16 hs16[B16 ? 16 : 1][72];  // ... rounded (144-byte rows: conflict-free b128 reads)
+  __shared__ __attribute__((aligned(16))) __bf16 hs16[NP][B16 ? 16 : 1][72];  // ... as bf16 plane(s) (144-byte rows: conflict-free b128 reads)
   __shared__ float gs[4][16][65];                                // recurrent pre-activation [gate][row][unit]
 
   f32x4 wf[2][4];   // this wave's W_hh fragments: 2 n-tiles x 4 k-chunks, resident for the whole sequence
-  bf16x8 wb[2][2];  // B16: 2 n-tiles x 2 k-chunks of 32 (lane (r, kq) holds k = 32 kc + 8 kq .. + 7 of unit row r)
+  bf16x8 wb[NP][2][2];  // B16: plane x 2 n-tiles x 2 k-chunks of 32 (lane (r, kq) holds k = 32 kc + 8 kq .. + 7 of unit row r)
 #pragma unroll
   for (int ntl = 0; ntl < 2; ++ntl) {
     const float* wrow = d.w + ((int64_t)(gate * H + (half * 2 + ntl) * 16 + r)) * H;
@@ -789,9 +800,16 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          wb[ntl][kc][e] = (__bf16)lo[e];
-          wb[ntl][kc][4 + e] = (__bf16)hi[e];
+        for (int e = 0; e < 8; ++e) {
+          const float wv = e < 4 ? lo[e & 3] : hi[e & 3];
+          if constexpr (PM == 2) {
+            __bf16 pl[3];
+            split3s(wv, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wb[q][ntl][kc][e] = pl[q];
+          } else {
+            wb[0][ntl][kc][e] = (__bf16)wv;
+          }
         }
       }
     } else {
@@ -809,7 +827,12 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
     erow[e] = idx >> 6;
     ej[e] = idx & 63;
     eok[e] = (m0 + erow[e]) < N;
-    if constexpr (B16) hs16[erow[e]][ej[e]] = (__bf16)0.f; else hs[erow[e]][ej[e]] = 0.f;
+    if constexpr (B16) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) hs16[q][erow[e]][ej[e]] = (__bf16)0.f;
+    } else {
+      hs[erow[e]][ej[e]] = 0.f;
+    }
   }
   __syncthreads();
 
@@ -837,9 +860,16 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
     if constexpr (B16) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
-        const bf16x8 av = *reinterpret_cast<const bf16x8*>(&hs16[r][kc * 32 + 8 * kq]);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wb[0][kc], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wb[1][kc], acc[1], 0, 0, 0);
+        bf16x8 av[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) av[q] = *reinterpret_cast<const bf16x8*>(&hs16[q][r][kc * 32 + 8 * kq]);
+        // partial products, small ones first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
+        constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int term = (NP == 3 ? 0 : 5); term < 6; ++term) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], wb[ib[term]][0][kc], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], wb[ib[term]][1][kc], acc[1], 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -867,7 +897,16 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
       const float c = gf * creg[e] + gi * gg;
       const float h = go * gate_tanh(c);
       creg[e] = c;
-      if constexpr (B16) hs16[row][j] = (__bf16)(eok[e] ? h : 0.f); else hs[row][j] = eok[e] ? h : 0.f;
+      if constexpr (PM == 2) {
+        __bf16 pl[3];
+        split3s(eok[e] ? h : 0.f, pl);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) hs16[q][row][j] = pl[q];
+      } else if constexpr (PM == 1) {
+        hs16[0][row][j] = (__bf16)(eok[e] ? h : 0.f);
+      } else {
+        hs[row][j] = eok[e] ? h : 0.f;
+      }
       if (eok[e]) {
         const int64_t n = m0 + row;
         float* g = G + n * 4 * H + j;
@@ -889,9 +928,11 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   }
 }
 
-template <bool B16>      // B16: dG[t+1] and W_hh rounded to bf16 for the recurrent product (see lstm_seq_fwd_h64)
+template <int PM>      // PM = 1 / 2: dG[t+1] and W_hh as one / three bf16 planes for the recurrent product (see lstm_seq_fwd_h64)
 __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   constexpr int H = 64;
+  constexpr bool B16 = PM != 0;
+  constexpr int NP = PM == 2 ? 3 : 1;
   const StepDir& d = a.d[blockIdx.y];   // d.w = W_hh^T [H][4H]
   const int N = a.N, T = a.T;
   const int m0 = blockIdx.x * 16;
@@ -900,11 +941,11 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   const int r = lane & 15, kq = lane >> 4;
 
   __shared__ __attribute__((aligned(16))) float dgs[B16 ? 1 : 16][260];     // dG[t+1] rows (k = gate*64 + unit)
-  __shared__ __attribute__((aligned(16))) __bf16 dgs16[B16 ? 16 : 1][264];  // ... rounded (528-byte rows)
+  __shared__ __attribute__((aligned(16))) __bf16 dgs16[NP][B16 ? 16 : 1][264];  // ... as bf16 plane(s) (528-byte rows)
   __shared__ float rs[2][16][65];                               // partial dHrec per k-half
 
   f32x4 wf[8];
-  bf16x8 wb[4];     // B16: 4 k-chunks of 32 of this wave's k-half
+  bf16x8 wb[NP][4];     // B16: plane x 4 k-chunks of 32 of this wave's k-half
   {
     const float* wrow = d.w + (int64_t)(nt * 16 + r) * 4 * H + khalf * 128;
     if constexpr (B16) {
@@ -913,9 +954,16 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          wb[kc][e] = (__bf16)lo[e];
-          wb[kc][4 + e] = (__bf16)hi[e];
+        for (int e = 0; e < 8; ++e) {
+          const float wv = e < 4 ? lo[e & 3] : hi[e & 3];
+          if constexpr (PM == 2) {
+            __bf16 pl[3];
+            split3s(wv, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) wb[q][kc][e] = pl[q];
+          } else {
+            wb[0][kc][e] = (__bf16)wv;
+          }
         }
       }
     } else {
@@ -935,7 +983,12 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     eok[e] = (m0 + erow[e]) < N;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      if constexpr (B16) dgs16[erow[e]][g * H + ej[e]] = (__bf16)0.f; else dgs[erow[e]][g * H + ej[e]] = 0.f;
+      if constexpr (B16) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dgs16[q][erow[e]][g * H + ej[e]] = (__bf16)0.f;
+      } else {
+        dgs[erow[e]][g * H + ej[e]] = 0.f;
+      }
     }
   }
   __syncthreads();
@@ -976,8 +1029,13 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     if constexpr (B16) {
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
-        const bf16x8 av = *reinterpret_cast<const bf16x8*>(&dgs16[r][khalf * 128 + kc * 32 + 8 * kq]);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wb[kc], acc, 0, 0, 0);
+        bf16x8 av[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) av[q] = *reinterpret_cast<const bf16x8*>(&dgs16[q][r][khalf * 128 + kc * 32 + 8 * kq]);
+        constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int term = (NP == 3 ? 0 : 5); term < 6; ++term)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], wb[ib[term]][kc], acc, 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -1003,10 +1061,19 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
       const float o3 = dh * tc * go * (1.f - go);
       dcreg[e] = dc * gf;
       if constexpr (B16) {
-        dgs16[row][j] = (__bf16)(eok[e] ? o0 : 0.f);
-        dgs16[row][H + j] = (__bf16)(eok[e] ? o1 : 0.f);
-        dgs16[row][2 * H + j] = (__bf16)(eok[e] ? o2 : 0.f);
-        dgs16[row][3 * H + j] = (__bf16)(eok[e] ? o3 : 0.f);
+        const float ov[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float v = eok[e] ? ov[g] : 0.f;
+          if constexpr (PM == 2) {
+            __bf16 pl[3];
+            split3s(v, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) dgs16[q][row][g * H + j] = pl[q];
+          } else {
+            dgs16[0][row][g * H + j] = (__bf16)v;
+          }
+        }
       } else {
         dgs[row][j] = eok[e] ? o0 : 0.f;
         dgs[row][H + j] = eok[e] ? o1 : 0.f;
@@ -1050,8 +1117,8 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
   if (a.pm != DVAE_MODE_F32 && a.pm != DVAE_MODE_BF16 && a.pm != DVAE_MODE_F32X3) return DVAE_EINVAL;
   for (int i = 0; i < ndir; ++i)
     if (dirs[i].packed_mode != a.pm || (a.pm && H != 64 && !dirs[i].w_packed)) return DVAE_EINVAL;
-  // bf16 / fp32x3 frame kernels exist for H = 512, 1024, ...; H = 64 has a bf16 form (it rounds W_hh itself: no pack)
-  if (a.pm && (H % 512) && !(H == 64 && a.pm == DVAE_MODE_BF16)) return DVAE_EINVAL;
+  // bf16 / fp32x3 frame kernels exist for H = 512, 1024, ...; the H = 64 kernels round / split W_hh themselves: no pack
+  if (a.pm && (H % 512) && H != 64) return DVAE_EINVAL;
   a.st16 = dirs[0].state_bf16 ? 1 : 0;
   for (int i = 0; i < ndir; ++i)
     if ((dirs[i].state_bf16 ? 1 : 0) != a.st16) return DVAE_EINVAL;
@@ -1135,8 +1202,9 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_fwd_h64<true>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(lstm_seq_fwd_h64<false>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_fwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_fwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(lstm_seq_fwd_h64<0>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
   if (H % 512 == 0) {
@@ -1193,8 +1261,9 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_bwd_h64<true>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL(lstm_seq_bwd_h64<false>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_bwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_bwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL(lstm_seq_bwd_h64<0>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
   if (H % 512 == 0) {

@@ -31,10 +31,10 @@ def lstm_pack_modes(mode: int, H: int):
     recurrences on bf16 fragments; fp32x3 runs both on three-plane fragments — fp32 results at 6/16 of the fp32-MFMA
     cycles: the W_hh-resident persistent kernels (csrc/lstm_pers.hip) are matrix-pipe bound, forward 7.1 us per H = 1024
     frame against 13.8 on the per-frame kernels, backward (dG split into planes by the consumer) 12.2 against 13.4 on
-    resident fp32 fragments and 16.8-18.9 on the per-frame fp32 kernels.  H = 64 (whole-sequence kernels): bf16 operands
-    in the bf16 mode (W_hh rounded in registers, no pack), fp32 otherwise; other H not a multiple of 512: fp32."""
-    if H == 64 and mode == _lib.MODE_BF16:
-        return _lib.MODE_BF16, _lib.MODE_BF16
+    resident fp32 fragments and 16.8-18.9 on the per-frame fp32 kernels.  H = 64 (whole-sequence kernels): the
+    mode's own arithmetic (W_hh rounded / split in registers, no pack); other H not a multiple of 512: fp32."""
+    if H == 64 and mode in (_lib.MODE_BF16, _lib.MODE_F32X3):
+        return mode, mode
     if H % 512:
         return _lib.MODE_F32, _lib.MODE_F32
     if mode == _lib.MODE_BF16:
