@@ -128,11 +128,12 @@ def _ready(*ps):
                 grad_ready_hook(p)
 
 
-def _split_k(m_tiles: int, k: int) -> int:
+def _split_k(m_tiles: int, k: int, slots: int = 0, fixed: int = 192) -> int:
     """Pick the split of the contraction that minimises (rounds over the chip) x (k per workgroup + fixed cost):
     512 workgroup slots (2 per CU at the 128x128x32 tile), each split keeps >= 256 of K.  Not restricted to
-    powers of two: 80 tiles x 6 splits fill one round where x 8 needs two."""
-    slots, fixed = int(os.environ.get("DVAE_SPLIT_SLOTS", "512")), 192
+    powers of two: 80 tiles x 6 splits fill one round where x 8 needs two.  `slots` / `fixed`: for shapes that run on the
+    256 x 128 kernels (one workgroup per CU; an atomically accumulated 128 KB epilogue per workgroup)."""
+    slots = slots or int(os.environ.get("DVAE_SPLIT_SLOTS", "512"))
     best, best_cost = 1, None
     for s in range(1, max(1, k // 256) + 1):
         rounds = -(-(m_tiles * s) // slots)
@@ -437,7 +438,12 @@ class ConvBnActFn(torch.autograd.Function):
                   "dvae_conv5_dgrad_t")
         with side_work(dy, xa):
             # the weight gradient goes straight into the (packed) gradient view: atomic split-K epilogue
-            sk = _split_k(5 * _tiles(Cout, Cin), R)
+            if Cout >= 256 and Cin > 64:
+                # the 256 x 128 kernels: 256 slots, and every split costs each output tile another atomic epilogue.
+                # bf16, R = 65536, 512 -> 512: 6 splits 162 us, the 19 the 128-tile model picks 210 (scripts/wgrad_split_sweep.py)
+                sk = _split_k(5 * ((Cout + 255) // 256) * ((Cin + 127) // 128), R, slots=256, fixed=384)
+            else:
+                sk = _split_k(5 * _tiles(Cout, Cin), R)
             check(L.dvae_conv5_wgrad(ptr(dy), ptr(xa), ptr(_grad_buf(conv_wp)), R, n_seg, Cin, Cout, sk,
                                      _mflags(mode, dy, xa), stream()), "dvae_conv5_wgrad")
             colsum_add(dy, _grad_buf(conv_b))

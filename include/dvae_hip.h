@@ -160,7 +160,8 @@ typedef struct {
   int packed_mode;    /* DVAE_MODE_F32: w_packed from dvae_lstm_pack_w (fp32 MFMA recurrence); DVAE_MODE_BF16: from
                          dvae_lstm_pack_w_bf16 (bf16 operands / fp32 accumulation on v_mfma_f32_16x16x32_bf16);
                          DVAE_MODE_F32X3: from dvae_lstm_pack_w_x3 (fp32 results: three bf16 planes of W_hh, h split the
-                         same way, six exact partial products).  The last two need H % 512 == 0 */
+                         same way, six exact partial products).  The last two need H % 512 == 0, or H == 64: the whole-sequence
+                         kernels of H = 64 take w_hh itself (no w_packed) and round / split it in registers */
   int step_shift;     /* *_range calls: this entry runs its step s in the launch of global step s + step_shift (0 for
                          the plain calls).  Lets two STACKED layers share launches, the upper one a chunk of frames
                          behind the lower one (whose chunk of outputs has meanwhile gone through the upper layer's input

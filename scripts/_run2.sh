@@ -1,1 +1,1 @@
-python3 scripts/_dbg8.py 2>&1 | grep -v "amdgpu.ids\|Warning" | tail -24
+python3 scripts/wgrad_split_sweep.py 2>&1 | grep -v "amdgpu.ids" | tail -12
