@@ -773,27 +773,31 @@ __device__ __forceinline__ void split3s(float x, __bf16 (&p)[3]) {
   r -= (float)p[1];
   p[2] = (__bf16)r;       // exact: what is left has at most 8 significant bits
 }
+// Waves: PM = 0: 8 (gate, n-half: two 16-unit n-tiles each); PM != 0: 16 (gate, n-tile) and ONE element per thread in
+// the gate arithmetic — with the MFMAs cheap, a frame is a chain of latencies (fragment reads, MFMAs, the gs round
+// trip, ten transcendentals per element, two barriers), and sixteen waves halve the per-wave serial parts of it.
 template <int PM>
-__global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
+__global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_fwd_h64(const StepArgs a) {
   constexpr int H = 64;
   constexpr bool B16 = PM != 0;
   constexpr int NP = PM == 2 ? 3 : 1;
+  constexpr int NTHR = PM ? 1024 : 512, NE = 1024 / NTHR, NT = PM ? 1 : 2;
   const StepDir& d = a.d[blockIdx.y];
   const int N = a.N, T = a.T;
   const int m0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int gate = wave & 3, half = wave >> 2;
+  const int gate = wave & 3, part = wave >> 2;        // n-tiles part * NT .. + NT - 1
   const int r = lane & 15, kq = lane >> 4;
 
   __shared__ __attribute__((aligned(16))) float hs[B16 ? 1 : 16][68];     // h[t-1] rows, k-contiguous
   __shared__ __attribute__((aligned(16))) __bf16 hs16[NP][B16 ? 16 : 1][72];  // ... as bf16 plane(s) (144-byte rows: conflict-free b128 reads)
   __shared__ float gs[4][16][65];                                // recurrent pre-activation [gate][row][unit]
 
-  f32x4 wf[2][4];   // this wave's W_hh fragments: 2 n-tiles x 4 k-chunks, resident for the whole sequence
-  bf16x8 wb[NP][2][2];  // B16: plane x 2 n-tiles x 2 k-chunks of 32 (lane (r, kq) holds k = 32 kc + 8 kq .. + 7 of unit row r)
+  f32x4 wf[NT][4];       // PM = 0: this wave's W_hh fragments: n-tiles x 4 k-chunks, resident for the whole sequence
+  bf16x8 wb[NP][NT][2];  // B16: plane x n-tile x 2 k-chunks of 32 (lane (r, kq) holds k = 32 kc + 8 kq .. + 7 of unit row r)
 #pragma unroll
-  for (int ntl = 0; ntl < 2; ++ntl) {
-    const float* wrow = d.w + ((int64_t)(gate * H + (half * 2 + ntl) * 16 + r)) * H;
+  for (int ntl = 0; ntl < NT; ++ntl) {
+    const float* wrow = d.w + ((int64_t)(gate * H + (part * NT + ntl) * 16 + r)) * H;
     if constexpr (B16) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
@@ -818,15 +822,16 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
     }
   }
 
-  int erow[2], ej[2];
-  bool eok[2];
-  float creg[2] = {0.f, 0.f};
+  int erow[NE], ej[NE];
+  bool eok[NE];
+  float creg[NE];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = tid + 512 * e;
+  for (int e = 0; e < NE; ++e) {
+    const int idx = tid + NTHR * e;
     erow[e] = idx >> 6;
     ej[e] = idx & 63;
     eok[e] = (m0 + erow[e]) < N;
+    creg[e] = 0.f;
     if constexpr (B16) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) hs16[q][erow[e]][ej[e]] = (__bf16)0.f;
@@ -840,23 +845,25 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   // several times one frame's work here).  Two register sets that swap roles every frame (loop unrolled by two) and
   // branch-free loads (rows past N read row N-1 and are never stored): with `x = ok ? load : 0` + a copy per frame,
   // hipcc put every load in its own basic block and drained vmcnt(0) in the middle of the SAME frame's MFMAs.
-  int nrow[2];
+  int nrow[NE];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) nrow[e] = min(m0 + erow[e], N - 1);
-  auto fetch = [&](int step_, float (&x)[2][4]) {
+  for (int e = 0; e < NE; ++e) nrow[e] = min(m0 + erow[e], N - 1);
+  auto fetch = [&](int step_, float (&x)[NE][4]) {
     const int t_ = d.reverse ? (T - 1 - step_) : step_;
     const float* __restrict__ G_ = d.gates + (int64_t)t_ * N * 4 * H;
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < NE; ++e)
 #pragma unroll
       for (int g = 0; g < 4; ++g) x[e][g] = G_[(int64_t)nrow[e] * 4 * H + g * H + ej[e]];
   };
-  auto frame = [&](int step, float (&xp)[2][4], float (&xn)[2][4]) {
+  auto frame = [&](int step, float (&xp)[NE][4], float (&xn)[NE][4]) {
     const int t = d.reverse ? (T - 1 - step) : step;
     float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
     fetch(min(step + 1, T - 1), xn);
 
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NT];
+#pragma unroll
+    for (int ntl = 0; ntl < NT; ++ntl) acc[ntl] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (B16) {
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc) {
@@ -866,29 +873,29 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
         // partial products, small ones first: (2,0) (1,1) (0,2) (1,0) (0,1) (0,0)
         constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int term = (NP == 3 ? 0 : 5); term < 6; ++term) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], wb[ib[term]][0][kc], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], wb[ib[term]][1][kc], acc[1], 0, 0, 0);
-        }
+        for (int term = (NP == 3 ? 0 : 5); term < 6; ++term)
+#pragma unroll
+          for (int ntl = 0; ntl < NT; ++ntl)
+            acc[ntl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[ia[term]], wb[ib[term]][ntl][kc], acc[ntl], 0, 0, 0);
       }
     } else {
 #pragma unroll
       for (int kc = 0; kc < 4; ++kc) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(&hs[r][kc * 16 + 4 * kq]);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[0][kc][e], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[1][kc][e], acc[1], 0, 0, 0);
-        }
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int ntl = 0; ntl < NT; ++ntl)
+            acc[ntl] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[ntl][kc][e], acc[ntl], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int ntl = 0; ntl < 2; ++ntl)
+    for (int ntl = 0; ntl < NT; ++ntl)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) gs[gate][kq * 4 + q][(half * 2 + ntl) * 16 + r] = acc[ntl][q];
+      for (int q = 0; q < 4; ++q) gs[gate][kq * 4 + q][(part * NT + ntl) * 16 + r] = acc[ntl][q];
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < NE; ++e) {
       const int row = erow[e], j = ej[e];
       const float gi = gate_sigmoid(gs[0][row][j] + xp[e][0]);
       const float gf = gate_sigmoid(gs[1][row][j] + xp[e][1]);
@@ -920,7 +927,7 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
     }
     __syncthreads();
   };
-  float xa[2][4], xb[2][4];
+  float xa[NE][4], xb[NE][4];
   fetch(0, xa);
   for (int step = 0; step < T; step += 2) {
     frame(step, xa, xb);
@@ -928,29 +935,33 @@ __global__ __launch_bounds__(512) void lstm_seq_fwd_h64(const StepArgs a) {
   }
 }
 
-template <int PM>      // PM = 1 / 2: dG[t+1] and W_hh as one / three bf16 planes for the recurrent product (see lstm_seq_fwd_h64)
-__global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
+// PM = 1 / 2: dG[t+1] and W_hh as one / three bf16 planes for the recurrent product (see lstm_seq_fwd_h64).  Waves: (n-tile of
+// 16 hidden units, k-part of the 256 gate columns): PM = 0: 8 waves, k-halves; PM != 0: 16 waves, k-quarters, one element
+// per thread in the gate arithmetic.
+template <int PM>
+__global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_bwd_h64(const StepArgs a) {
   constexpr int H = 64;
   constexpr bool B16 = PM != 0;
   constexpr int NP = PM == 2 ? 3 : 1;
+  constexpr int NTHR = PM ? 1024 : 512, NE = 1024 / NTHR, KP = PM ? 4 : 2, KW = 256 / KP;   // k-parts, their width
   const StepDir& d = a.d[blockIdx.y];   // d.w = W_hh^T [H][4H]
   const int N = a.N, T = a.T;
   const int m0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nt = wave & 3, khalf = wave >> 2;
+  const int nt = wave & 3, kp = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
 
   __shared__ __attribute__((aligned(16))) float dgs[B16 ? 1 : 16][260];     // dG[t+1] rows (k = gate*64 + unit)
   __shared__ __attribute__((aligned(16))) __bf16 dgs16[NP][B16 ? 16 : 1][264];  // ... as bf16 plane(s) (528-byte rows)
-  __shared__ float rs[2][16][65];                               // partial dHrec per k-half
+  __shared__ float rs[KP][16][65];                              // partial dHrec per k-part
 
   f32x4 wf[8];
-  bf16x8 wb[NP][4];     // B16: plane x 4 k-chunks of 32 of this wave's k-half
+  bf16x8 wb[NP][KW / 32];     // B16: plane x k-chunks of 32 of this wave's k-part
   {
-    const float* wrow = d.w + (int64_t)(nt * 16 + r) * 4 * H + khalf * 128;
+    const float* wrow = d.w + (int64_t)(nt * 16 + r) * 4 * H + kp * KW;
     if constexpr (B16) {
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
+      for (int kc = 0; kc < KW / 32; ++kc) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + kc * 32 + 8 * kq + 4);
 #pragma unroll
@@ -972,15 +983,16 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     }
   }
 
-  int erow[2], ej[2];
-  bool eok[2];
-  float dcreg[2] = {0.f, 0.f};
+  int erow[NE], ej[NE];
+  bool eok[NE];
+  float dcreg[NE];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = tid + 512 * e;
+  for (int e = 0; e < NE; ++e) {
+    const int idx = tid + NTHR * e;
     erow[e] = idx >> 6;
     ej[e] = idx & 63;
     eok[e] = (m0 + erow[e]) < N;
+    dcreg[e] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if constexpr (B16) {
@@ -996,17 +1008,17 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
   // frame operands of step+1 in flight under frame step: two register sets swapping roles, branch-free clamped loads
   // (see lstm_seq_fwd_h64)
   struct Ops {
-    float gt[2][4], cc[2], cp[2], dho[2];
+    float gt[NE][4], cc[NE], cp[NE], dho[NE];
   };
-  int nrow[2];
+  int nrow[NE];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) nrow[e] = min(m0 + erow[e], N - 1);
+  for (int e = 0; e < NE; ++e) nrow[e] = min(m0 + erow[e], N - 1);
   auto fetch = [&](int step_, Ops& o) {
     const int fs = T - 1 - step_;
     const int t_ = d.reverse ? (T - 1 - fs) : fs;
     const int tp_ = min(max(d.reverse ? t_ + 1 : t_ - 1, 0), T - 1);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < NE; ++e) {
       const int64_t n = nrow[e];
       const int j = ej[e];
 #pragma unroll
@@ -1028,10 +1040,10 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if constexpr (B16) {
 #pragma unroll
-      for (int kc = 0; kc < 4; ++kc) {
+      for (int kc = 0; kc < KW / 32; ++kc) {
         bf16x8 av[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) av[q] = *reinterpret_cast<const bf16x8*>(&dgs16[q][r][khalf * 128 + kc * 32 + 8 * kq]);
+        for (int q = 0; q < NP; ++q) av[q] = *reinterpret_cast<const bf16x8*>(&dgs16[q][r][kp * KW + kc * 32 + 8 * kq]);
         constexpr int ia[6] = {2, 1, 0, 1, 0, 0}, ib[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int term = (NP == 3 ? 0 : 5); term < 6; ++term)
@@ -1040,18 +1052,20 @@ __global__ __launch_bounds__(512) void lstm_seq_bwd_h64(const StepArgs a) {
     } else {
 #pragma unroll
       for (int kc = 0; kc < 8; ++kc) {
-        const f32x4 av = *reinterpret_cast<const f32x4*>(&dgs[r][khalf * 128 + kc * 16 + 4 * kq]);
+        const f32x4 av = *reinterpret_cast<const f32x4*>(&dgs[r][kp * KW + kc * 16 + 4 * kq]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], wf[kc][e], acc, 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) rs[khalf][kq * 4 + q][nt * 16 + r] = acc[q];
+    for (int q = 0; q < 4; ++q) rs[kp][kq * 4 + q][nt * 16 + r] = acc[q];
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < NE; ++e) {
       const int row = erow[e], j = ej[e];
-      const float dh = dho[e] + rs[0][row][j] + rs[1][row][j];
+      float dh = dho[e];
+#pragma unroll
+      for (int p = 0; p < KP; ++p) dh += rs[p][row][j];
       const float gi = gt[e][0], gf = gt[e][1], gg = gt[e][2], go = gt[e][3];
       const float tc = gate_tanh(cc[e]);
       const float dc = dcreg[e] + dh * go * (1.f - tc * tc);
@@ -1202,8 +1216,8 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_fwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
-    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_fwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_fwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
+    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_fwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(lstm_seq_fwd_h64<0>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
@@ -1261,8 +1275,8 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_bwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
-    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_bwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_bwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
+    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_bwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
     else hipLaunchKernelGGL(lstm_seq_bwd_h64<0>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
     return dvae_check_launch();
   }
