@@ -137,7 +137,9 @@ def _split_k(m_tiles: int, k: int, slots: int = 0, fixed: int = 192) -> int:
     best, best_cost = 1, None
     for s in range(1, max(1, k // 256) + 1):
         rounds = -(-(m_tiles * s) // slots)
-        cost = rounds * (-(-k // s) + fixed) * (1.0 if s == 1 else 1.03)
+        # + 4 per split: each split is one more atomic epilogue over the output (dW[256 x 64] over K = 65536: 128 splits
+        # 36 us, the 256 a split-free model picks 46; scripts/skinny_wgrad_sweep.py)
+        cost = rounds * (-(-k // s) + fixed) * (1.0 if s == 1 else 1.03) + (4 * s if s > 1 else 0)
         if best_cost is None or cost < best_cost:
             best, best_cost = s, cost
     return best
