@@ -247,6 +247,13 @@ def test_split_k_chooser():
             s = ops._split_k(tiles, k)
             assert s >= 1 and (s == 1 or k // s >= 256), (tiles, k, s)
     assert ops._split_k(513, 16384) > 1            # 513 tiles: a second, nearly empty round unless the work is split
+    # the 256 x 128 kernels' model (conv weight gradients, Cout >= 256): one round of 256 slots, the atomic epilogue priced in
+    assert ops._split_k(40, 16384, slots=256, fixed=384) == 6
+    assert ops._split_k(40, 65536, slots=256, fixed=384) == 6      # (the 128-tile model said 19: 210 us against 162)
+    # every split is one more atomic pass over the output: the tiny H = 64 weight gradients stop at k = 512 per split
+    assert ops._split_k(2, 65280) == 128 and ops._split_k(2, 16256) == 63
+    # the two 134 MB Linear weights keep their single, storing launch (FlatAdam.set_store_first depends on it)
+    assert ops._split_k(ops._tiles(2048, 16384), 128) == 1 and ops._split_k(ops._tiles(16384, 2048), 128) == 1
 
 
 def test_stacked_lstm_schedule_rules():
