@@ -637,7 +637,10 @@ __device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, Is...>
   (f(std::integral_constant<int, Is>{}), ...);
 }
 
-template <bool A_KC, bool B_KC, bool BNS>
+// BNU (with BNS): every 64-row statistics chunk lies inside ONE group (group size a multiple of 64): two FMAs per element
+// instead of the per-element row arithmetic and four selects; a separate instantiation (as a run-time branch inside the
+// unrolled epilogue it made both paths slower)
+template <bool A_KC, bool B_KC, bool BNS, bool BNU = false>
 __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 128, BK = 16, NTHR = 256, MTW = 4, NTW = 2;
   constexpr int LD_KC = BK + 8;
@@ -981,7 +984,11 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
                 if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
               }
               x[e] = v;
-              if constexpr (BNS) {
+              if constexpr (BNS && BNU) {
+                const float uu = ok ? v : 0.f;
+                bst[nt][0] += uu;
+                bst[nt][1] += uu * uu;
+              } else if constexpr (BNS) {
                 const int nseg = p.bn_nseg;
                 int rm = bmod + m2 * 32 + dr;
                 if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
@@ -1020,8 +1027,15 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
       }
       if constexpr (BNS) {
         const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+        bool second = false;      // BNU: the chunk's sums belong to the second group
+        if constexpr (BNU) second = ((m0 + wm * 128 + half * 64) % p.bn_nseg) >= p.bn_nseg / p.bn_groups;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
+          if (second) {
+            bst[nt][2] = bst[nt][0];
+            bst[nt][3] = bst[nt][1];
+            bst[nt][0] = bst[nt][1] = 0.f;
+          }
           const int col = n0 + wn * 64 + nt * 32 + l31;
 #pragma unroll
           for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
@@ -1061,7 +1075,7 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
 //                 barrier
 //                 sub-step 3:    MFMAs; fragment reads of tile i+1, sub-step 0
 // Requires k ranges that are multiples of 64 and operands < 1 GiB (else the 128 x 128 kernel).
-template <bool A_KC, bool B_KC, bool BNS>
+template <bool A_KC, bool B_KC, bool BNS, bool BNU = false>      // BNU: see gemm_x3_tall_kernel
 __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p) {
   constexpr int BM = 256, BN = 128, BK = 64, NTHR = 256, MTW = 4, NTW = 2;
   constexpr int LD_KC = BK + 8;
@@ -1292,7 +1306,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p)
                 if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
               }
               x[e] = v;
-              if constexpr (BNS) {
+              if constexpr (BNS && BNU) {
+                const float uu = ok ? v : 0.f;
+                bst[nt][0] += uu;
+                bst[nt][1] += uu * uu;
+              } else if constexpr (BNS) {
                 const int nseg = p.bn_nseg;
                 int rm = bmod + m2 * 32 + dr;
                 if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
@@ -1331,8 +1349,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p)
       }
       if constexpr (BNS) {
         const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+        bool second = false;      // BNU: the chunk's sums belong to the second group
+        if constexpr (BNU) second = ((m0 + wm * 128 + half * 64) % p.bn_nseg) >= p.bn_nseg / p.bn_groups;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
+          if (second) {
+            bst[nt][2] = bst[nt][0];
+            bst[nt][3] = bst[nt][1];
+            bst[nt][0] = bst[nt][1] = 0.f;
+          }
           const int col = n0 + wn * 64 + nt * 32 + l31;
 #pragma unroll
           for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
@@ -1533,9 +1558,12 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap, tag, alg_bytes);
   if (p.bn_part && (!a_kc || !b_kc || big || p.split_k != 1 || p.epi != DVAE_EPI_STORE || p.act != DVAE_ACT_NONE))
     return DVAE_EINVAL;
+  // statistics chunks (64 rows) that never straddle a group or a frame: the cheap form of the BatchNorm epilogue
+  const bool bn_uniform = p.bn_part && p.bn_groups >= 1 && ((p.bn_nseg / p.bn_groups) % 64 == 0) && (p.bn_nseg % p.bn_groups == 0);
   if (tall16) {
 #define TALL16(AK_, BK_, BNS_) hipLaunchKernelGGL((gemm_bf16_tall_kernel<AK_, BK_, BNS_>), grid, dim3(256), 0, s, p)
-    if (p.bn_part) TALL16(true, true, true);
+    if (p.bn_part && bn_uniform) hipLaunchKernelGGL((gemm_bf16_tall_kernel<true, true, true, true>), grid, dim3(256), 0, s, p);
+    else if (p.bn_part) TALL16(true, true, true);
     else if (a_kc && b_kc) TALL16(true, true, false);
     else if (a_kc && !b_kc) TALL16(true, false, false);
     else if (!a_kc && b_kc) TALL16(false, true, false);
@@ -1543,7 +1571,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
 #undef TALL16
   } else if (tall) {
 #define TALL(AK_, BK_, BNS_) hipLaunchKernelGGL((gemm_x3_tall_kernel<AK_, BK_, BNS_>), grid, dim3(256), 0, s, p)
-    if (p.bn_part) TALL(true, true, true);
+    if (p.bn_part && bn_uniform) hipLaunchKernelGGL((gemm_x3_tall_kernel<true, true, true, true>), grid, dim3(256), 0, s, p);
+    else if (p.bn_part) TALL(true, true, true);
     else if (a_kc && b_kc) TALL(true, true, false);
     else if (a_kc && !b_kc) TALL(true, false, false);
     else if (!a_kc && b_kc) TALL(false, true, false);

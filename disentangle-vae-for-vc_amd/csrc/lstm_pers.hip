@@ -1335,6 +1335,11 @@ int pers_mt(int N, int H, int cus) {
 #define PERS_KL 2
 #endif
 
+__global__ __launch_bounds__(256) void pers_clear_kernel(unsigned* __restrict__ w, int n) {
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(n, (int)(blockIdx.x + 1) * 1024); i += 256)
+    __hip_atomic_store(w + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // one launch: LDS padded so that exactly one workgroup fits a CU
 template <class K>
 int pers_go(K kern, int need_lds, const PersArgs& a, int grid, hipStream_t s) {
@@ -1451,10 +1456,13 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
 #endif
   const int grid = (kind < 2 ? H / 32 : H / 16) * a.n_rb;
   const size_t flag_bytes = (size_t)a.n_rb * (kind < 2 ? PERS_FLAG_LD : PERS_FLAG_LD_X3) * 4;
-  if (hipMemsetAsync(ws, 0, flag_bytes, s) != hipSuccess) {
-    g_dvae_last_hip_error = (int)hipGetLastError();
-    return DVAE_ELAUNCH;
-  }
+  // The flags are cleared by a kernel of our own with write-through (agent-scope) stores, NOT by hipMemsetAsync: as a
+  // memset node of a replayed hipGraph the clear was not always in memory when the next node's workgroups polled — about 1
+  // replayed step in 100 read a flag of the PREVIOUS launch, went ahead and took that launch's rows out of the ring (a loss
+  // off by 1e-5; scripts/replay_stress.py with several inputs).  Eager launches never showed it.
+  const int n_words = (int)(flag_bytes / 4);
+  hipLaunchKernelGGL(pers_clear_kernel, dim3((n_words + 1023) / 1024), dim3(256), 0, s, (unsigned*)ws, n_words);
+  if (dvae_check_launch() != DVAE_OK) return DVAE_ELAUNCH;
   return pers_dispatch(kind, H, mt, a, grid, s);
 }
 

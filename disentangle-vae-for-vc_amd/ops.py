@@ -470,7 +470,8 @@ def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1, bwd: bool =
 
 def lstm_pers_workspace(dev) -> torch.Tensor:
     """Flags + sticky error record + two-slot exchange ring of the persistent LSTM launches of one device (zeroed once;
-    every launch re-zeroes its flags with a memset node of its own; launches of one stream share it).
+    every launch clears its flags with a small kernel of its own in front of it — not hipMemsetAsync, see
+    csrc/lstm_pers.hip dvae_pers_launch; launches of one stream share it).
     (One exchange slot PER FRAME read with plain, L2-cached loads was tried and REMOVED: under hipGraph replay an XCD's L2
     can still hold a slot's lines from the previous launch — the write-through-coherent loads of the ring are what makes
     the hand-off independent of cache state)"""

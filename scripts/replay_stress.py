@@ -1,4 +1,4 @@
-"""GPU box: is the train step reproducible?  lr = 0, the same input and noise every time: the eight loss scalars of N
+"""GPU box: is the train step reproducible?  lr = 0, NIN inputs (with their noise) cycled through: the eight loss scalars of the N
 steps (graph replay / eager, persistent LSTM on / off) must agree to the noise of the atomically accumulated split-k
 sums (~1e-7).  Prints the worst relative deviation from the median per configuration and the outlier steps."""
 import os
@@ -24,17 +24,23 @@ def make():
     return w
 
 
-x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 150))
-eps = synthetic_eps(B, seed=250)
+NIN = int(os.environ.get("NIN", 5))        # distinct inputs cycled through: a stale hand-off would show the previous input's data
+inputs = [tuple(t.cuda() for t in synthetic_pair(B, T, 150 + k)) + (synthetic_eps(B, seed=250 + k),) for k in range(NIN)]
 for pers in (True, False):
     for graph in (True, False):
         ops.LSTM_PERSISTENT = pers
         w = make()
         w.enable_graph(graph)
-        w.model.eps_override = eps
-        rows = np.array([w.step(x1, x2, None, train=True) for _ in range(N)], dtype=np.float64)
-        med = np.median(rows, axis=0)
-        dev = np.abs(rows - med) / np.maximum(np.abs(med), 1e-9)
+        rows = []
+        for i in range(N):
+            x1, x2, eps = inputs[i % NIN]
+            w.model.eps_override = eps
+            rows.append(w.step(x1, x2, None, train=True))
+        rows = np.array(rows, dtype=np.float64)
+        dev = np.zeros_like(rows)
+        for k in range(NIN):                       # lr = 0: every step on input k must give input k's losses
+            med = np.median(rows[k::NIN], axis=0)
+            dev[k::NIN] = np.abs(rows[k::NIN] - med) / np.maximum(np.abs(med), 1e-9)
         bad = np.where(dev.max(axis=1) > 2e-6)[0]
         print(f"persistent={pers} graph={graph}: worst {dev.max():.2e}; {len(bad)} of {N} steps off by > 2e-6:",
               [(int(i), f"{dev[i].max():.1e}") for i in bad[:12]], flush=True)

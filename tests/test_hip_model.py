@@ -219,7 +219,9 @@ def test_graph_replay_matches_eager():
             assert rel(lb[k], la[k]) <= 1e-5, (i, k, la[k], lb[k])
     assert b._graph is not None and b.optimizer.t == 4 and a.optimizer.t == 4
     for x, y in ((a.optimizer.exp_avg, b.optimizer.exp_avg), (a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)):
-        assert float((x - y).norm()) <= 1e-2 * float(x.norm())   # gradient flip noise, ~1e-3 per step
+        # gradient flip noise: two runs of ONE code path differ by 0.5-2.5e-2 per step in relative gradient norm at this size
+        # (scripts/two_trainer_stress.py, any mode), so the moments after 4 steps by up to ~2e-2
+        assert float((x - y).norm()) <= 4e-2 * float(x.norm())
     for (n1, v1), (n2, v2) in zip(a.model.named_buffers(), b.model.named_buffers()):
         if n1.endswith("num_batches_tracked"):
             assert int(v1) == int(v2) == 8
@@ -237,13 +239,35 @@ def test_graph_replay_matches_eager():
     la, lb = a.step(x1, x2, None, train=True), b.step(x1, x2, None, train=True)
     for k in range(8):
         assert rel(lb[k], la[k]) <= 1e-5, (k, la[k], lb[k])
-    assert float((a.optimizer.exp_avg - b.optimizer.exp_avg).norm()) <= 1e-2 * float(a.optimizer.exp_avg.norm())
+    assert float((a.optimizer.exp_avg - b.optimizer.exp_avg).norm()) <= 4e-2 * float(a.optimizer.exp_avg.norm())
     # and with a real learning rate the replayed steps train: loss goes down
     c = make(B, T)
     c.enable_graph(True)
     x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 7))
     hist = [c.step(x1, x2, None, train=True)[0] for _ in range(5)]
     assert hist[-1] < hist[0], hist
+
+
+def test_replayed_steps_do_not_depend_on_the_previous_input():
+    """lr = 0, four inputs cycled through a graph-replayed trainer: every step on input k must return input k's eight
+    losses (to the 1e-6 of the atomically accumulated sums) whatever the step before it saw.  Regression test of the
+    persistent LSTM launches' flag clear: as a memset node of the replayed graph it let about one step in a hundred read
+    the PREVIOUS step's rows out of the exchange ring (loss off by 1e-5) — invisible when every step sees the same input."""
+    B, T, NIN, N = 4, 64, 4, 120
+    w = make(B, T, lr=0.0)
+    w.enable_graph(True)
+    inputs = [tuple(t.cuda() for t in synthetic_pair(B, T, 300 + k)) + (synthetic_eps(B, seed=400 + k),) for k in range(NIN)]
+    rows = []
+    for i in range(N):
+        x1, x2, eps = inputs[i % NIN]
+        w.model.eps_override = eps
+        rows.append(w.step(x1, x2, None, train=True))
+    rows = np.array(rows, dtype=np.float64)
+    for k in range(NIN):
+        r = rows[k::NIN]
+        med = np.median(r, axis=0)
+        dev = np.abs(r - med) / np.maximum(np.abs(med), 1e-9)
+        assert dev.max() <= 5e-6, (k, float(dev.max()), int(np.argmax(dev.max(axis=1))))
 
 
 def test_config0_run_training_and_resume(tmp_path):
