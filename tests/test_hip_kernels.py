@@ -547,3 +547,31 @@ def test_fused_loss_gvae2(ops, B, T):
                                  -0.5 / B, -1.0 / bs, mse_cof, kl_cof)
     out2[0].backward()
     assert rd2[2].grad is not None and float(rd2[2].grad.abs().max()) == pytest.approx(mse_cof / bs, rel=1e-6)
+
+
+# ------------------------------------------------------------------ zero / sum (what replaced ATen's fills and gradient adds)
+@pytest.mark.parametrize("n", [4, 7, 1000, 4099, 1 << 20])
+def test_zero_f32(ops, n):
+    from dvae_amd._lib import check, lib, ptr, stream
+    x = torch.full((n + 8,), 3.0, device="cuda")
+    check(lib().dvae_zero_f32(ptr(x), n, stream()), "dvae_zero_f32")
+    assert float(x[:n].abs().max()) == 0.0 and bool((x[n:] == 3.0).all())     # exactly n elements, nothing behind them
+    assert lib().dvae_zero_f32(x.data_ptr() + 4, 4, stream()) != 0                # misaligned: refused, not a fault
+
+
+@pytest.mark.parametrize("n,three", [(4, False), (4096, True), (40960, False), (1 << 20, True)])
+def test_sum_f32_and_fanout(ops, n, three):
+    from dvae_amd._lib import check, lib, ptr, stream
+    a, b, c = (dev(rnd(n, seed=s)) for s in (1, 2, 3))
+    out = torch.empty_like(a)
+    check(lib().dvae_sum_f32(ptr(a), ptr(b), ptr(c) if three else None, ptr(out), n, stream()), "dvae_sum_f32")
+    want = a + b + (c if three else 0)
+    assert torch.equal(out, want)                        # same additions in the same order: bit-exact
+    # through autograd: a tensor with several consumers gets ONE summed gradient
+    x = dev(rnd(n // 4, 4, seed=4)).requires_grad_()
+    y = x * 2.0
+    parts = ops.fanout(y, 3 if three else 2)
+    loss = sum(((k + 1.0) * p).sum() for k, p in enumerate(parts))
+    loss.backward()
+    k = 6.0 if three else 3.0
+    assert torch.equal(x.grad, torch.full_like(x, 2.0 * k))
