@@ -1,6 +1,8 @@
 """GPU box: is the train step reproducible?  lr = 0, NIN inputs (with their noise) cycled through: the eight loss scalars of the N
 steps (graph replay / eager, persistent LSTM on / off) must agree to the noise of the atomically accumulated split-k
-sums (~1e-7).  Prints the worst relative deviation from the median per configuration and the outlier steps."""
+sums (~1e-7).  Prints the worst relative deviation from the median per configuration and the outlier steps.
+(DVAE_COMPUTE_DTYPE=bf16: the floor is ~3e-5 in every mode, eager and per-frame kernels included — a 1e-7 difference that
+crosses a bf16 rounding boundary comes out as 2^-9 of that operand.)"""
 import os
 import sys
 
