@@ -472,9 +472,8 @@ def lstm_pers_workspace(dev) -> torch.Tensor:
     """Flags + sticky error record + two-slot exchange ring of the persistent LSTM launches of one device (zeroed once;
     every launch clears its flags with a small kernel of its own in front of it — not hipMemsetAsync, see
     csrc/lstm_pers.hip dvae_pers_launch; launches of one stream share it).
-    (One exchange slot PER FRAME read with plain, L2-cached loads was tried and REMOVED: under hipGraph replay an XCD's L2
-    can still hold a slot's lines from the previous launch — the write-through-coherent loads of the ring are what makes
-    the hand-off independent of cache state)"""
+    (One exchange slot PER FRAME read with plain, L2-cached loads was tried and removed: wrong results under hipGraph
+    replay — blamed on stale L2 lines then, possibly the flag-clear hazard above — and no faster)"""
     key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     ws = _pers_ws.get(key)
     if ws is None:
