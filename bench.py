@@ -6,6 +6,14 @@ per GPU, fp32, through the HIP path (BASELINE.json configs[1]; weak scaling for 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+`--gpus N` MEANS N ranks.  Started without a rendezvous in the environment (no WORLD_SIZE) and N > 1, this process is
+only a LAUNCHER: before anything touches the GPU it starts N fresh rank processes of this script (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, one GPU each), relays rank 0's stdout — its last line is the JSON
+line — and exits with the first non-zero exit code of any rank (the others are terminated by PID).  Started by
+torch.distributed.run (WORLD_SIZE set), it is one of the ranks; WORLD_SIZE != --gpus is an error, never a silent N=1 run.
+`--dry-launch` runs the same launcher / rendezvous / barrier / max-over-ranks timing with the gloo backend and NO GPU work
+(tests/test_host_logic.py: the launcher is exercised on CPU).
+
 Rank 0 prints ONE JSON line.  Extra objects:
   roofline     dominant kernel family = the contraction kernel gemm_f32_kernel (every Linear, LSTM input projection,
                weight gradient and k5 conv), AND its single dominant instantiation (template arguments named).
@@ -157,6 +165,92 @@ def cpu_baseline(batch, frames, steps=3, timeout_s=240):
                        f"; the faster sample ({best['threads']} threads, {best['ms_per_step']:.0f} ms/step) is the baseline")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, dry=False):
+    """`--gpus n` without a rendezvous in the environment: start n fresh rank processes of this script (one per GPU) and
+    relay rank 0's stdout.  Runs BEFORE anything in this process touches the GPU (torch is imported, HIP is not
+    initialised: torch.cuda.device_count() does not initialise it on this image) and never replaces this process with
+    another program.  Returns the exit code: 0 only if every rank exited 0."""
+    import subprocess
+    import threading
+    if not dry:
+        n_dev = torch.cuda.device_count()
+        if n_dev < n and os.environ.get("DVAE_ALLOW_SHARED_GPU", "0") != "1":
+            log(f"--gpus {n} but only {n_dev} GPU(s) are visible: one process per GPU is the design")
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool
+        env.setdefault("OMP_NUM_THREADS", "4")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    log(f"launcher: started {n} rank processes (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}")
+    lines = []
+
+    def pump():
+        for line in procs[0].stdout:
+            lines.append(line)
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                log(f"launcher: rank {r} exited with {code}; stopping the others")
+                for q in live:
+                    procs[q].terminate()              # exactly the PIDs started above
+        time.sleep(0.05)
+    th.join(10)
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    if rc == 0 and not any(l.lstrip().startswith("{") for l in lines):
+        log("launcher: rank 0 printed no JSON line")
+        rc = 4
+    return rc if rc >= 0 else 128 - rc
+
+
+def dry_launch(args, world, rank):
+    """The rendezvous, barrier and max-over-ranks timing of a real run with the gloo backend and no GPU work: proves that
+    `--gpus N` reaches N cooperating ranks (CPU test)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    one = torch.ones(1)
+    dist.all_reduce(one)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))               # ranks differ: the line must carry the SLOWEST rank's time
+    dist.barrier()
+    own = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(own, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        el = float(own.item())
+        print(json.dumps({"metric": f"utterances/sec (B={args.batch}, 80-mel, T={args.frames}) train step", "value": None,
+                          "unit": "utterances/sec", "n_gpus": int(one.item()), "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * el / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none", "dry_launch": True,
+                          "config": {"workload": "dry launch: rendezvous + barrier only, no GPU work",
+                                     "parallelism": f"dp{dist.get_world_size()}"}}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def build_trainer(dev, B, T, dtype, world=1, rank=0, force_ddp=False):
     import dvae_amd
     from dvae_amd import ddp, ops
@@ -291,6 +385,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher / rendezvous check only: gloo backend, no GPU work, the line carries dry_launch=true")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--threads", type=int, default=8, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -298,23 +394,47 @@ def main():
         _cpu_baseline_child(args.batch, args.frames, args.steps, args.threads)
         return
     dtype = "fp32" if args.dtype == "f32" else args.dtype
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launcher: nothing in THIS process ever touches the GPU
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], dry=args.dry_launch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the environment says WORLD_SIZE={world}: refusing to run a "
+                         f"{world}-rank job under an n_gpus={args.gpus} label (start it with --gpus {world}, or unset "
+                         "WORLD_SIZE and let bench.py launch the ranks)")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    shared_gpu = world > n_dev           # more ranks than GPUs: only as a functional check (DVAE_ALLOW_SHARED_GPU=1)
+    if shared_gpu and os.environ.get("DVAE_ALLOW_SHARED_GPU", "0") != "1":
+        raise SystemExit(f"bench.py: {world} ranks but only {n_dev} visible GPU(s): one process per GPU is the design "
+                         "(DVAE_ALLOW_SHARED_GPU=1 runs ranks on shared devices as a functional check, not a measurement)")
+    local = local % max(1, n_dev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_ddp = os.environ.get("DVAE_FORCE_DDP", "0") == "1"      # exercise the RCCL path with one rank (testing)
     dp = world > 1 or force_ddp
+    backend = os.environ.get("DVAE_DIST_BACKEND", "nccl")          # "nccl" IS RCCL on ROCm; gloo only for shared-GPU checks
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from dvae_amd import ops
     from dvae_amd.data import SyntheticPairs
+    if shared_gpu:
+        # two persistent grids cannot both be resident on one GPU (each wants every CU): per-frame recurrences
+        ops.LSTM_PERSISTENT = False
 
     B, T = args.batch, args.frames
     w = build_trainer(dev, B, T, dtype, world, rank, force_ddp)
@@ -322,7 +442,10 @@ def main():
     x1, x2, spk = data.batch()
     n_params = sum(p.numel() for p in w.model.parameters())
 
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where the small control tensors of the collectives live
+
     def barrier():
+        torch.cuda.synchronize()
         if dp:
             dist.barrier()
         torch.cuda.synchronize()
@@ -338,7 +461,7 @@ def main():
         own = time.perf_counter() - t0
         el = own
         if dp:
-            tmax = torch.tensor([own], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([own], device=cdev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
         return el, last, own
@@ -372,12 +495,13 @@ def main():
         el_e, last, own_e = timed(args.steps)
         last = tuple(last.tolist())
         ms_eager = 1e3 * el_e / args.steps
-        per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
+        per_rank = torch.zeros(world, device=cdev, dtype=torch.float64)
         per_rank[rank] = 1e3 * own_e / args.steps
         dist.all_reduce(per_rank)
         red = w.reducer
         extra.update({"ms_per_step_eager": ms_eager, "per_rank_ms_eager": [round(v, 3) for v in per_rank.tolist()],
                       "rccl_ranks": dist.get_world_size(), "visible_devices": torch.cuda.device_count(),
+                      "backend": backend, "ranks_share_a_gpu": bool(shared_gpu),
                       "buckets": {"count": len(red.buckets), "bytes": [4 * (hi - lo) for lo, hi in red.buckets],
                                   "launched_from_backward_hooks": red.stats["hook"], "left_for_finish": red.stats["finish"],
                                   "steps": red.stats["steps"]}})
@@ -385,14 +509,16 @@ def main():
         elapsed, launch = el_e, "eager (bucketed RCCL all-reduce launched from backward hooks)"
         # graph attempt, guarded three ways: try/except around the capture, agreement of all ranks, and a watchdog that
         # prints the eager-only line and ends the process if the attempt hangs
-        if args.graph and os.environ.get("DVAE_BENCH_DDP_GRAPH", "1") != "0":
+        # OPT-IN (DVAE_BENCH_DDP_GRAPH=1): no multi-rank run has shown the captured step equal to the eager one, so it is
+        # neither attempted nor allowed to become the headline by default
+        if args.graph and os.environ.get("DVAE_BENCH_DDP_GRAPH", "0") == "1":
             import threading
             state = {"line": None}
 
             def give_up():
                 if rank == 0 and state["line"] is not None:
                     print(state["line"], flush=True)
-                os._exit(0)
+                os._exit(3)             # a wedged attempt is a failure, even though the eager line above is valid
             state["line"] = json.dumps(_result(args, world, B, T, dtype, n_params, elapsed, last, launch,
                                                dict(extra, graph_error="graph attempt exceeded its time limit"), None))
             dog = threading.Timer(float(os.environ.get("DVAE_BENCH_GRAPH_TIMEOUT", "150")), give_up)
@@ -407,7 +533,7 @@ def main():
                     ok, err = 0, w.graph_fallback
             except Exception as e:
                 ok, err = 0, repr(e)[:300]
-            flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+            flag = torch.tensor([ok], device=cdev, dtype=torch.int32)
             try:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())

@@ -150,6 +150,20 @@ class GpuPairLoader:
                                      self.Lmax, stream()), "dvae_gather_crop")
         return out
 
+    def sample_batch(self, seed: int = 0):
+        """One batch drawn with a PRIVATE generator: leaves the epoch permutation and crop streams untouched, so a rank
+        that looks at a batch on its own (rank 0's estimate_trained_model) stays in step with its peers."""
+        rs = np.random.RandomState(seed)
+        n = len(self.dataset)
+        sel = rs.permutation(n)[:min(self.batch_size, n)]
+        pairs = self.dataset.utterance_fp[sel]
+        u1 = np.array([self.index[p[0]] for p in pairs], dtype=np.int32)
+        u2 = np.array([self.index[p[1]] for p in pairs], dtype=np.int32)
+        off = lambda us: np.array([int(rs.randint(0, int(self.lengths[u]) - self.T)) if self.lengths[u] > self.T else 0
+                                   for u in us], dtype=np.int32)
+        spk = np.array([self.dataset.speaker_ids.index(os.path.basename(os.path.dirname(p[0]))) for p in pairs])
+        return self.gather(u1, off(u1)), self.gather(u2, off(u2)), torch.from_numpy(spk).to(self.device)
+
     def __iter__(self):
         n = len(self.dataset)
         order = self.rng.permutation(n) if self.shuffle else np.arange(n)     # identical on every rank

@@ -53,6 +53,10 @@ class GradReducer:
         self.works = []
         self.active = False
         self.force = False      # issue the collective even with one rank (tests of the RCCL path)
+        # a backend without device-memory collectives (gloo on GPU tensors: the shared-GPU functional checks) gets the
+        # buckets staged through host memory in finish(); RCCL ("nccl") reduces the device slices in place
+        self.staged = bool(flat_grad.is_cuda and dist.is_initialized() and dist.get_backend(group) != "nccl")
+        self._deferred: List[int] = []
         # buckets launched from the autograd hook (overlapped with backward) / left over for finish(), cumulative
         self.stats = {"hook": 0, "finish": 0, "steps": 0}
 
@@ -65,6 +69,9 @@ class GradReducer:
 
     def _launch(self, b):
         lo, hi = self.buckets[b]
+        if self.staged:
+            self._deferred.append(b)
+            return
         if self.world_size > 1 or (dist.is_initialized() and self.force):
             self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
@@ -97,15 +104,28 @@ class GradReducer:
         for w in self.works:
             w.wait()
         self.works = []
+        if self._deferred:
+            torch.cuda.current_stream().synchronize()
+            for b in self._deferred:
+                lo, hi = self.buckets[b]
+                host = self.flat[lo:hi].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat[lo:hi].copy_(host)
+            self._deferred = []
 
 
 def broadcast_parameters(flat_params: torch.Tensor, buffers: Sequence[torch.Tensor] = (), src: int = 0, group=None):
     """Rank `src`'s weights (and BatchNorm buffers) to every rank, once, before training."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
-    dist.broadcast(flat_params, src=src, group=group)
-    for b in buffers:
-        dist.broadcast(b, src=src, group=group)
+    staged = flat_params.is_cuda and dist.get_backend(group) != "nccl"
+    for t in [flat_params, *buffers]:
+        if staged:
+            host = t.detach().cpu()
+            dist.broadcast(host, src=src, group=group)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t, src=src, group=group)
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

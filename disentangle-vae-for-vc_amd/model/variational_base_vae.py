@@ -267,7 +267,9 @@ class VariationalBaseModelVAE:
         self.model.eval()
         os.makedirs(estimation_dir, exist_ok=True)
         try:
-            data1, data2, _ = next(iter(test_loader))
+            # a loader with sample_batch (data.GpuPairLoader) hands out a batch WITHOUT advancing its epoch streams: under
+            # data parallelism only rank 0 comes here and must not fall out of step with the other ranks' permutations
+            data1, data2, _ = test_loader.sample_batch() if hasattr(test_loader, "sample_batch") else next(iter(test_loader))
             data1 = data1.to(self.device).float()
             data2 = data2.to(self.device).float()
             outs = self.model(data1, data2, train=False)

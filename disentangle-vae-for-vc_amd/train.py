@@ -8,6 +8,14 @@ Kept flags: --batch-size --latent-size --speaker_size --lr --epochs --report-int
 train.py:53).  Parsed-and-ignored flags of the reference (--hidden-size --alpha --normalize --beta_cof --style_cof
 --sample-size --no-cuda --do-not-resume --log-interval) are accepted for command-line compatibility.
 --convert (voice conversion + vocoder) is out of scope.
+
+Data parallel (new; the reference is single-device, train.py:49-58): started as one of WORLD_SIZE > 1 ranks —
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m dvae_amd.train ...` or with
+`--gpus N` (this process then only launches N rank processes before anything touches the GPU) — every rank takes
+LOCAL_RANK's GPU, joins the RCCL group, receives rank 0's weights, attaches ddp.GradReducer (bucketed all-reduce
+overlapped with backward, 1/world inside Adam) and feeds from its shard of the device-resident corpus
+(data.GpuPairLoader(rank=, world_size=): same epoch permutation on every rank, pairs rank, rank + world, ...).
+--batch-size stays the PER-GPU batch (weak scaling).  Rank 0 writes checkpoints and logs.
 """
 import argparse
 import json
@@ -44,6 +52,11 @@ def get_parse():
     p.add_argument("--train", type=bool, default=False)
     p.add_argument("--convert", type=bool, default=False)
     p.add_argument("--graph", type=int, default=1, help="replay the step from a hipGraph (fixed batch shape)")
+    p.add_argument("--gpus", type=int, default=0,
+                   help="data-parallel ranks on this node; > 1 without WORLD_SIZE in the environment: launch them")
+    p.add_argument("--gpu-loader", type=int, default=-1,
+                   help="1: device-resident corpus + HIP gather/crop (data.GpuPairLoader); 0: the reference's DataLoader; "
+                        "-1: the GPU loader when data parallel, the DataLoader otherwise")
     return p
 
 
@@ -54,32 +67,121 @@ def get_dataset(dataset_fp, batch_size, samples_length=64, seed=None):
     return DataLoader(ds, batch_size=batch_size, pin_memory=True, shuffle=True, drop_last=True), ds
 
 
+def launch_ranks(n, argv):
+    """--gpus n without a rendezvous in the environment: n fresh rank processes of this module, started before anything
+    here touches the GPU; returns the first non-zero exit code (0 if all ranks succeeded)."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        procs.append(subprocess.Popen([sys.executable, "-c", "import dvae_amd.train as t, sys; t.main(sys.argv[1:])"]
+                                      + list(argv), env=env))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:
+                    procs[q].terminate()          # exactly the PIDs started above
+        time.sleep(0.05)
+    return rc if rc >= 0 else 128 - rc
+
+
+def setup_data_parallel(vsc, seed):
+    """Join the process group (RCCL; DVAE_DIST_BACKEND overrides for functional checks), take rank 0's weights and
+    BatchNorm buffers, attach the gradient reducer.  Returns (rank, world)."""
+    import torch.distributed as dist
+    from . import ddp
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29519")
+        backend = os.environ.get("DVAE_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device(vsc.device)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    opt = vsc.optimizer
+    ddp.broadcast_parameters(opt.flat_p, list(vsc.model.buffers()))
+    red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets)
+    red.force = os.environ.get("DVAE_FORCE_DDP", "0") == "1"      # issue the collectives with one rank too (tests)
+    vsc.attach_reducer(red)
+    return rank, world
+
+
 def main(argv=None):
     args = get_parse().parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
+    if args.gpus and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     from .model.disentangled_vae import ConvolutionalMulVAE
     rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
+    if world > 1:
+        if world > n_dev and os.environ.get("DVAE_ALLOW_SHARED_GPU", "0") != "1":
+            raise SystemExit(f"{world} ranks but {n_dev} visible GPU(s): one process per GPU")
+        if world > n_dev:
+            from . import ops
+            ops.LSTM_PERSISTENT = False      # two persistent grids cannot both be resident on one GPU
+        torch.cuda.set_device(local % max(1, n_dev))
+    device = torch.device("cuda", torch.cuda.current_device())
     torch.manual_seed(args.seed)
     torch.cuda.manual_seed(args.seed + 7919 * rank)      # every rank its own reparameterisation-noise stream
-    loader, _ = get_dataset(args.dataset_fp, args.batch_size, args.samples_length, seed=args.seed)
-    os.makedirs(args.log_dir, exist_ok=True)
-    with open(os.path.join(args.log_dir, "config.json"), "w") as fp:
-        json.dump(vars(args), fp, indent=4)
+    if rank == 0:
+        os.makedirs(args.log_dir, exist_ok=True)
+        with open(os.path.join(args.log_dir, "config.json"), "w") as fp:
+            json.dump(vars(args), fp, indent=4)
     vsc = ConvolutionalMulVAE(args.dataset, args.samples_length, 80, args.latent_size, args.lr, args.alpha,
-                              args.log_interval, args.normalize, speaker_size=args.speaker_size,
+                              args.log_interval, args.normalize, speaker_size=args.speaker_size, device=device,
                               latent_dim=args.latent_size, beta=args.beta_cof, batch_size=args.batch_size,
                               mse_cof=args.mse_cof, kl_cof=args.kl_cof, style_cof=args.style_cof)
+    dp = world > 1 or os.environ.get("DVAE_FORCE_DDP", "0") == "1"
+    if dp:
+        setup_data_parallel(vsc, args.seed)
+    use_gpu_loader = args.gpu_loader == 1 or (args.gpu_loader < 0 and dp)
+    if use_gpu_loader:
+        from .data import GpuPairLoader, SpeechDatasetGVAE
+        ds = SpeechDatasetGVAE(args.dataset_fp, samples_length=args.samples_length, seed=args.seed)
+        loader = GpuPairLoader(ds, args.batch_size, device=device, seed=args.seed, rank=rank, world_size=world)
+    else:
+        if world > 1:
+            raise SystemExit("--gpu-loader 0 has no sharding: data-parallel runs feed from data.GpuPairLoader")
+        loader, _ = get_dataset(args.dataset_fp, args.batch_size, args.samples_length, seed=args.seed)
     if args.graph:
-        vsc.enable_graph(True)
+        vsc.enable_graph(True)     # with a reducer attached the step still runs eagerly unless DVAE_DDP_GRAPH=1
     hist = None
-    if args.train:
-        hist = vsc.run_training(loader, loader, args.epochs, args.report_interval, args.sample_size,
-                                reload_model=not args.do_not_resume,
-                                checkpoints_path=os.path.join(args.log_dir, "checkpoints"),
-                                images_path=os.path.join(args.log_dir, "images"),
-                                logs_path=os.path.join(args.log_dir, "logs"),
-                                estimation_dir=os.path.join(args.log_dir, "images", "estimation"))
-    if args.convert:
-        raise SystemExit("--convert (mel conversion + vocoder) is outside the training hot path (SURVEY.md §8f-3)")
+    try:
+        if args.train:
+            hist = vsc.run_training(loader, loader, args.epochs, args.report_interval, args.sample_size,
+                                    reload_model=not args.do_not_resume,
+                                    checkpoints_path=os.path.join(args.log_dir, "checkpoints"),
+                                    images_path=os.path.join(args.log_dir, "images"),
+                                    logs_path=os.path.join(args.log_dir, "logs"),
+                                    estimation_dir=os.path.join(args.log_dir, "images", "estimation"))
+        if args.convert:
+            raise SystemExit("--convert (mel conversion + vocoder) is outside the training hot path (SURVEY.md §8f-3)")
+    finally:
+        if dp:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
     return hist
 
 

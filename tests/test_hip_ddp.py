@@ -63,3 +63,76 @@ def test_ddp_step_trains_like_plain_step(graph):
     # only (see _ddp_gpu_child.py): well under the distance either has travelled
     assert o["param_dist_rel"] <= 0.5 * o["param_moved_rel"], (o["param_dist_rel"], o["param_moved_rel"])
     assert o["views_intact"] and o["stats"]["finish"] == 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# TWO ranks of the data-parallel step on the HIP kernels (configs[3]'s mechanics at B = 2 per rank).  One GPU on the box:
+# the ranks share cuda:0 and exchange through gloo (tests/_ddp2_gpu_child.py); sharding, rank-local BatchNorm, loss / local
+# batch, bucketed sum from the autograd hooks and 1/world inside Adam are the product path.
+def _two_ranks(tmp_path, lr, steps):
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), WORLD_SIZE="2",
+                   LOCAL_RANK=str(r), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp2_gpu_child.py"), str(tmp_path),
+                                       str(lr), str(steps)], env=env, stderr=subprocess.PIPE, text=True))
+    for p in procs:
+        try:
+            _, err = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-3000:]
+    import torch
+    return [(json.load(open(tmp_path / f"rank{r}.json")), torch.load(tmp_path / f"rank{r}.pt")) for r in range(2)]
+
+
+def test_two_rank_step_equals_chunked_oracle_step_on_hip(tmp_path):
+    """The averaged gradient both ranks hand to Adam == the oracle's single-process chunked step (BatchNorm statistics per
+    shard, loss / shard size, mean over shards: SURVEY.md §8e), and rank 1 — which never loaded the weights — got them."""
+    import torch
+    from oracle.dvae_ref import RefTrainer, chunked_step_grads
+    from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+    (j0, t0), (j1, t1) = _two_ranks(tmp_path, 0.0, 1)
+    assert j0["t"] == j1["t"] == 1 and j0["buckets"] >= 3
+    assert j0["stats"]["finish"] == 0 and j1["stats"]["finish"] == 0         # every bucket fired from a backward hook
+    for n in t0["grads"]:
+        assert torch.equal(t0["grads"][n], t1["grads"][n]), n               # the SAME sum on both ranks, bit for bit
+    Bg, T = 4, 64
+    x1, x2 = synthetic_pair(Bg, T, 21)
+    eps = synthetic_eps(Bg, seed=22)
+    tr = RefTrainer(Bg // 2, n_frames=T)
+    tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
+    tr.model.train()
+    want = chunked_step_grads(tr, x1, x2, eps, 2)
+    worst = 0.0
+    for n, g in want.items():
+        denom = float(g.norm())
+        if denom > 1e-3:
+            worst = max(worst, float((t0["grads"][n] - g).norm()) / denom)
+    assert worst < 2e-3, worst           # fp32 round-off floor of the gradients (DESIGN.md: ReLU-gate flips), as in test_hip_model
+    # losses: each rank reports ITS shard's losses; their mean is the chunked step's loss
+    from oracle.dvae_ref import loss_gvae2
+    ref = []
+    for r in range(2):
+        sl = slice(r * 2, r * 2 + 2)
+        outs = tr.model(x1[sl], x2[sl], tuple(e[sl] for e in eps))
+        ref.append([float(v) for v in loss_gvae2(x1[sl], x2[sl], outs, 2, tr.mse_cof, tr.kl_cof)])
+    # (BatchNorm running statistics moved during chunked_step_grads; the training-mode forward does not read them)
+    for r, j in enumerate((j0, j1)):
+        for k in range(8):
+            assert _rel(j["losses"][0][k], ref[r][k]) <= 1e-4, (r, k, j["losses"][0], ref[r])
+
+
+def test_two_rank_training_keeps_replicas_identical(tmp_path):
+    """Three Adam steps at lr = 1e-4: both replicas hold bit-identical weights and moments afterwards (same summed
+    gradients, same optimizer arithmetic), and the loss went down on both shards."""
+    import torch
+    (j0, t0), (j1, t1) = _two_ranks(tmp_path, 1e-4, 3)
+    assert torch.equal(t0["flat_p"], t1["flat_p"])
+    assert torch.equal(t0["exp_avg"], t1["exp_avg"])
+    assert j0["t"] == j1["t"] == 3
+    for j in (j0, j1):
+        assert all(map(lambda v: v == v, j["losses"][-1]))
