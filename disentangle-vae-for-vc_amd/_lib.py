@@ -18,6 +18,11 @@ _lib = None
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 
+class Ranges(C.Structure):
+    """dvae_ranges_t"""
+    _fields_ = [("lo", i64 * 8), ("hi", i64 * 8), ("n", i32)]
+
+
 class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
@@ -47,7 +52,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 302     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 303     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
@@ -89,7 +94,8 @@ SIGNATURES = {
     "dvae_loss_fwd": (i32, [C.POINTER(LossDesc), vp, vp, vp]),
     "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
-    "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp]),
+    "dvae_lstm_pers_err_word": (vp, [vp]),
     "dvae_sum_f32": (i32, [vp, vp, vp, vp, i64, vp]),
     "dvae_zero_f32": (i32, [vp, i64, vp]),
     "dvae_mel_to_frames": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),

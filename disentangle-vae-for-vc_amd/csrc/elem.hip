@@ -304,39 +304,61 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
-// Device-resident step counter and bias corrections, so that a captured hipGraph replays a correct Adam step:
-// state[0] = t (as float), state[1] = 1 - beta1^t, state[2] = sqrt(1 - beta2^t)
-__global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2) {
+// Device-resident step counter, bias corrections, learning rate and gradient scale, so that a captured hipGraph replays a
+// correct Adam step: state[0] = t (as float), state[1] = 1 - beta1^t, state[2] = sqrt(1 - beta2^t), state[4] = lr,
+// state[5] = grad_scale.  `skip`: while *skip != 0 (sticky error word of the persistent LSTM launches) nothing is touched.
+__global__ void adam_tick_kernel(float* __restrict__ state, float b1, float b2, const unsigned* __restrict__ skip) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const double t = (double)state[0] + 1.0;
     state[0] = (float)t;
     state[1] = (float)(1.0 - pow((double)b1, t));
     state[2] = (float)sqrt(1.0 - pow((double)b2, t));
   }
 }
-__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                       float lr, float b1, float b2, float eps, float gs,
-                                                       const float* __restrict__ state) {
-  const float bc1 = state[1], bc2s = state[2];
-  const int64_t n4 = n >> 2;
+struct AdamClear {
+  int64_t lo[8], hi[8];
+  int n;
+};
+template <int U>
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, int64_t n4,
+                                                       float b1, float b2, float eps, const float* __restrict__ state,
+                                                       const unsigned* __restrict__ skip, AdamClear clr) {
+  if (skip && __hip_atomic_load(skip, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  const float bc1 = state[1], bc2s = state[2], lr = state[4], gs = state[5];
   const float step_size = lr / bc1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    // streamed once per step: non-temporal accesses keep 2.7 GB of optimiser traffic from evicting the caches
-    f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + 4 * i));
-    const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + 4 * i));
-    f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + 4 * i));
-    f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + 4 * i));
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  // U independent 16-byte accesses per tensor and thread per trip: 4 U loads in flight before the first use
+  for (int64_t i0 = (int64_t)blockIdx.x * (256 * U) + threadIdx.x; i0 < n4; i0 += (int64_t)gridDim.x * (256 * U)) {
+    f32x4 pp[U], gg[U], mm[U], vv[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float gr = gg[k] * gs;
-      mm[k] = mm[k] + (gr - mm[k]) * (1.f - b1);
-      vv[k] = vv[k] * b2 + (1.f - b2) * gr * gr;
-      pp[k] -= step_size * (mm[k] / (sqrtf(vv[k]) / bc2s + eps));
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 256 < n4 ? i0 + u * 256 : i0;      // clamped: the tail re-reads element i0, stores are guarded
+      // streamed once per step: non-temporal accesses keep 2.7 GB of optimiser traffic from evicting the caches
+      pp[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + 4 * i));
+      gg[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + 4 * i));
+      mm[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + 4 * i));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + 4 * i));
     }
-    __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + 4 * i));
-    __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + 4 * i));
-    __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + 4 * i));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t i = i0 + u * 256;
+      if (i >= n4) break;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gr = gg[u][k] * gs;
+        mm[u][k] = mm[u][k] + (gr - mm[u][k]) * (1.f - b1);
+        vv[u][k] = vv[u][k] * b2 + (1.f - b2) * gr * gr;
+        pp[u][k] -= step_size * (mm[u][k] / (sqrtf(vv[u][k]) / bc2s + eps));
+      }
+      __builtin_nontemporal_store(pp[u], reinterpret_cast<f32x4*>(p + 4 * i));
+      __builtin_nontemporal_store(mm[u], reinterpret_cast<f32x4*>(m + 4 * i));
+      __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4*>(v + 4 * i));
+      bool c = false;
+      for (int r = 0; r < clr.n; ++r) c |= (4 * i >= clr.lo[r]) & (4 * i < clr.hi[r]);
+      if (c) *reinterpret_cast<f32x4*>(g + 4 * i) = z;     // plain store: the next step's launches accumulate into it
+    }
   }
 }
 
@@ -702,14 +724,27 @@ DVAE_API int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                                float beta2, float eps, float grad_scale, float* state, void* stream) {
+DVAE_API int dvae_adam_flat_dev(float* p, float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                                float* state, const unsigned* skip_if_nonzero, const dvae_ranges_t* clear, void* stream) {
   if (!p || !g || !m || !v || !state || n < 4 || (n & 3)) return DVAE_EINVAL;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return DVAE_EINVAL;
+  AdamClear c{};
+  if (clear) {
+    if (clear->n < 0 || clear->n > 8) return DVAE_EINVAL;
+    c.n = clear->n;
+    for (int r = 0; r < c.n; ++r) {
+      if (clear->lo[r] < 0 || clear->hi[r] > n || clear->lo[r] > clear->hi[r] || ((clear->lo[r] | clear->hi[r]) & 3))
+        return DVAE_EINVAL;
+      c.lo[r] = clear->lo[r];
+      c.hi[r] = clear->hi[r];
+    }
+  }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2);
-  hipLaunchKernelGGL(adam_dev_kernel, dim3(nblk(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2,
-                     eps, grad_scale, state);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2, skip_if_nonzero);
+  constexpr int U = 2;
+  const int64_t n4 = n >> 2;
+  hipLaunchKernelGGL(adam_dev_kernel<U>, dim3(nblk((n4 + U - 1) / U, 256, 2048)), dim3(256), 0, s, p, g, m, v, n4, beta1,
+                     beta2, eps, state, skip_if_nonzero, c);
   return dvae_check_launch();
 }
 

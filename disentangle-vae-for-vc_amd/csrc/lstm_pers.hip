@@ -1466,6 +1466,10 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   return pers_dispatch(kind, H, mt, a, grid, s);
 }
 
+DVAE_API const unsigned* dvae_lstm_pers_err_word(void* ws) {
+  return ws ? (const unsigned*)((char*)ws + PERS_ERR_OFF) : nullptr;
+}
+
 DVAE_API int dvae_lstm_pers_check(void* ws, int* info4, void* stream) {
   if (!ws) return DVAE_EINVAL;
   unsigned rec[4] = {0, 0, 0, 0};

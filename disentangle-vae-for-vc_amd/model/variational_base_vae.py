@@ -68,10 +68,12 @@ class VariationalBaseModelVAE:
     def enable_graph(self, flag: bool = True, ddp=None):
         """Capture the train step into a hipGraph on its second call and replay it afterwards.  The first call runs
         eagerly (it is a real step, warms everything up and, under data parallelism, lets RCCL set up its communicator
-        outside the capture).  The graph bakes host scalars into kernel arguments (learning rate, loss coefficients,
-        1/batch_size, BatchNorm train/eval, shapes): `_graph_signature` is compared on every step and the graph is
-        re-captured when any of them changed, so `optimizer.param_groups[0]['lr'] = ...`, `update_kl()` or
-        `model.eval()` take effect exactly as in the eager path.
+        outside the capture).  The graph bakes host scalars into kernel arguments (loss coefficients, 1/batch_size,
+        BatchNorm train/eval, shapes): `_graph_signature` is compared on every step and the graph is re-captured when
+        any of them changed, so `update_kl()` or `model.eval()` take effect exactly as in the eager path.  The learning
+        rate is NOT baked in: it lives in the optimizer's device state (`FlatAdam.sync_scalars`, called before every
+        replay), so `optimizer.param_groups[0]['lr'] = ...` every step — a schedule — costs one 8-byte copy when the
+        value changed and never a re-capture.
         `ddp`: with a reducer attached the bucketed RCCL all-reduces can be captured INSIDE the graph (ranks replay the
         same step a single GPU does).  OPT-IN (ddp=True or DVAE_DDP_GRAPH=1): no run with two or more ranks has shown
         it equal to the eager data-parallel step yet; without it a data-parallel step runs eagerly whatever `flag` says.
@@ -86,7 +88,7 @@ class VariationalBaseModelVAE:
     def _graph_signature(self, data1):
         from .. import ops
         opt = self.optimizer
-        return (tuple(data1.shape), float(opt.param_groups[0]["lr"]), tuple(opt.betas), float(opt.eps),
+        return (tuple(data1.shape), tuple(opt.betas), float(opt.eps),
                 float(self.mse_cof), float(self.kl_cof), int(self.batch_size), bool(self.model.training),
                 self.reducer is not None, getattr(self.reducer, "world_size", 1), ops.current_mode(),
                 bool(ops.LSTM_PERSISTENT))
@@ -146,6 +148,12 @@ class VariationalBaseModelVAE:
             for dst, src in zip(self._g_eps, user_eps):
                 dst.copy_(src.to(dev))
         m.eps_override = self._g_eps
+        # learning rate / gradient scale: device scalars, refreshed OUTSIDE the captured region
+        self.optimizer.sync_scalars(1.0 / self.reducer.world_size if self.reducer is not None else 1.0)
+        if self._graph is not None and not getattr(self.optimizer, "_clean", True):
+            # something accumulated into the gradient buffer since the last Adam launch (a manual backward between two
+            # replays): a graph captured on a clean buffer holds no zero_grad launch of its own
+            self.optimizer.zero_grad()
         try:
             if self._graph is None:
                 torch.cuda.synchronize()
@@ -168,6 +176,8 @@ class VariationalBaseModelVAE:
                     return self._eager_train_step(self._g_x1, self._g_x2)
                 self._graph = g
             self._graph.replay()
+            if getattr(self.optimizer, "fold_zero_grad", False):
+                self.optimizer._clean = True        # the replayed Adam launch cleared the ranges (host flags do not replay)
         finally:
             m.eps_override = user_eps
         return self._g_losses.clone()       # the static buffer is overwritten by the next replay
@@ -184,7 +194,7 @@ class VariationalBaseModelVAE:
     def step(self, data1, data2, speaker_ids, train=False):
         if train:
             out = tuple(self.step_async(data1, data2, speaker_ids).tolist())   # one D2H copy, not 8 .item() syncs
-            self._check_device_errors()
+            self._check_and_recover()
             return out
         outs = self.model(data1, data2)
         losses = self.loss_functionGVAE2(data1, data2, *outs, train=train)
@@ -196,6 +206,16 @@ class VariationalBaseModelVAE:
         synchronised at every call site of this)."""
         from .. import ops
         ops.lstm_pers_check()
+
+    def _check_and_recover(self):
+        try:
+            self._check_device_errors()
+        except Exception:
+            # the Adam launches skipped their update (and their gradient clear) while the error word was set: the next
+            # zero_grad must really clear
+            if self.optimizer is not None and hasattr(self.optimizer, "_clean"):
+                self.optimizer._clean = False
+            raise
 
     # ---- variational_base_vae.py:74-101
     def train(self, train_loader, epoch, logging_func=print):
@@ -211,7 +231,7 @@ class VariationalBaseModelVAE:
             last = self.step_async(data1, data2, speaker_ids)
             tot.add_(last)
         tot = tot.tolist()
-        self._check_device_errors()
+        self._check_and_recover()
         last_style = float(last[7]) if last is not None else 0.0
         if hasattr(train_loader, "dataset") and hasattr(train_loader.dataset, "shuffle_data"):
             train_loader.dataset.shuffle_data()
@@ -236,7 +256,7 @@ class VariationalBaseModelVAE:
         opt = last[:-4] + ".opt"
         if os.path.exists(opt):
             sd = torch.load(opt, map_location="cpu")
-            self.optimizer.load_state_dict(sd)
+            self.optimizer.load_state_dict(sd, legacy_layout=os.environ.get("DVAE_OPT_LEGACY_LAYOUT"))
             if sd.get("cuda_rng_state") is not None and torch.device(self.device).type == "cuda":
                 g = torch.cuda.default_generators[torch.device(self.device).index or 0]
                 if self.reducer is not None and self.reducer.rank > 0:

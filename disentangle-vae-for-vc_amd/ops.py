@@ -112,6 +112,9 @@ def act_storage(mode) -> torch.dtype:
 
 
 def _grad_buf(p: torch.Tensor) -> torch.Tensor:
+    owner = getattr(p, "_dvae_owner", None)
+    if owner is not None:
+        owner._clean = False              # a backward kernel is about to write into the flat gradient buffer
     if p.grad is None:
         if getattr(p, "_dvae_flat_owned", False):
             raise RuntimeError("gradient of a FlatAdam-owned parameter was set to None (model.zero_grad()?): its "
@@ -338,6 +341,8 @@ class LinearFn(torch.autograd.Function):
                 raise RuntimeError("store-first weight gradient: the launch would be split; clear the flag "
                                    "(FlatAdam.set_store_first) for this shape")
             linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode, store=store)
+            if store:
+                weight._dvae_sf_writes = getattr(weight, "_dvae_sf_writes", 0) + 1     # FlatAdam.step checks: exactly one
             colsum_add(dy, _grad_buf(bias))
         _ready(weight, bias)
         return dx, None, None, None, None, None
@@ -458,9 +463,25 @@ class ConvBnActFn(torch.autograd.Function):
 # W_hh-resident persistent recurrence (csrc/lstm_pers.hip): one launch per sequence where the shape has such a kernel
 # (bf16 compute mode, H = 512 / 1024, (H/32) * ceil(N/32) <= CU count); DVAE_LSTM_PERSISTENT=0 keeps one launch per frame.
 LSTM_PERSISTENT = os.environ.get("DVAE_LSTM_PERSISTENT", "1") != "0"
+
+
+def _ranks_share_a_gpu() -> bool:
+    """More ranks on this node than visible GPUs (a functional check, never the product set-up): two persistent grids
+    each want every CU of the device, neither becomes resident, both run into their bounded waits."""
+    try:
+        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        n_dev = torch.cuda.device_count()          # does not initialise HIP
+        return n_dev > 0 and n_local > n_dev
+    except Exception:
+        return False
+
+
+if _ranks_share_a_gpu():
+    LSTM_PERSISTENT = False
 LSTM_PERS_TIMEOUT_US = 0                    # 0: the library's default bound (2 s) on every cross-workgroup wait
 _PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the workspace any supported (N, H) needs
 _pers_ws: dict = {}
+_pers_owner: dict = {}                      # device index -> the torch stream whose launches used the workspace last
 
 
 def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1, bwd: bool = False) -> bool:
@@ -482,8 +503,27 @@ def lstm_pers_workspace(dev) -> torch.Tensor:
     return ws
 
 
+def _pers_claim(dev):
+    """ONE persistent launch at a time per device: a launch owns every CU and the device's one workspace (flags, exchange
+    ring).  Launches of one stream are ordered by the stream; a DIFFERENT stream may take over only when the previous
+    owner has nothing in flight — otherwise two grids would clear and overwrite each other's flags and ring (silent
+    corruption of h / dG, not a timeout) and neither could become fully resident.  Raises instead.  A capturing stream
+    is exempt (torch synchronises the device around a capture; a replayed graph runs on the stream that replays it)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(key)
+    own = _pers_owner.get(key)
+    if own is not None and own.cuda_stream != cur.cuda_stream and not own.query():
+        raise RuntimeError("persistent LSTM launch requested on a second stream while launches of another stream are "
+                           "still in flight on this device: one persistent recurrence at a time per GPU (synchronise the "
+                           "streams, or set DVAE_LSTM_PERSISTENT=0 for concurrent trainers)")
+    _pers_owner[key] = cur
+
+
 def _pers_fill(d, dev):
     """pers_ws / pers_timeout_us of a dvae_lstm_dir_t"""
+    _pers_claim(dev)
     d.pers_ws, d.pers_timeout_us = ptr(lstm_pers_workspace(dev)), LSTM_PERS_TIMEOUT_US
 
 

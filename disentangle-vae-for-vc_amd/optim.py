@@ -1,7 +1,15 @@
 """Flat-buffer Adam: all parameters live in ONE contiguous fp32 buffer (each parameter a 16-byte
 aligned view), likewise gradients and both moments, so the optimiser is a single HBM-bound HIP
-launch (dvae_adam_flat: 7 x 4 bytes per parameter) and a data-parallel all-reduce runs over
+launch (dvae_adam_flat_dev: 7 x 4 bytes per parameter) and a data-parallel all-reduce runs over
 contiguous slices of the gradient buffer without any packing copy.
+
+Everything that changes between steps lives ON THE DEVICE (`dev_state`: step count, bias corrections, learning rate,
+gradient scale), so a captured hipGraph replays a correct step and `param_groups[0]["lr"] = ...` (a schedule) needs no
+re-capture: `sync_scalars()` — called by `step()` outside a capture and by the trainer before every replay — copies the
+host values over when they changed.  The same launch clears the gradient ranges `zero_grad()` covers after reading them
+(the next step's zero_grad is then free), and it does NOTHING while the sticky error word of the persistent LSTM launches
+is non-zero: a recurrence that gave up a bounded wait leaves garbage gradients, and weights / moments must not consume
+them before the host has looked (`ops.lstm_pers_check`).
 
 Replaces torch.optim.Adam(self.model.parameters(), lr) at /root/reference/model/disentangled_vae.py:304
 (betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad).
@@ -50,9 +58,17 @@ class FlatAdam:
             p.data = view
             p.grad = self.flat_g[o:o + p.numel()].view_as(p)
             p._dvae_flat_owned = True      # ops._grad_buf refuses to re-allocate a gradient for such a parameter
+            p._dvae_owner = self           # ... and marks this optimizer's gradient buffer as written to
         self.lr, self.betas, self.eps = lr, betas, eps
         self._zero_ranges = [(0, off)]     # what zero_grad clears: everything, minus store-first parameters
-        self.dev_state = torch.zeros(4, device=dev, dtype=torch.float32)   # [t, 1-b1^t, sqrt(1-b2^t), -]
+        # [t, 1-b1^t, sqrt(1-b2^t), -, lr, grad_scale, -, -]
+        self.dev_state = torch.zeros(8, device=dev, dtype=torch.float32)
+        self._dev_scalars = None           # (lr, grad_scale) as last written to dev_state[4:6]
+        # True: the zero_grad ranges of flat_g are known to be zero (the last Adam launch cleared them after reading and no
+        # backward kernel has accumulated since: ops._grad_buf resets it) — zero_grad() is then free
+        self._clean = False
+        self.fold_zero_grad = True         # let the Adam launch clear them (False: zero_grad launches every time)
+        self.guard_device_errors = True    # skip the update while a persistent LSTM launch's error word is set
         # torch.optim-compatible surface used by callers of the reference wrapper
         self.param_groups = [{"params": self.params, "lr": lr, "betas": betas, "eps": eps}]
 
@@ -82,29 +98,73 @@ class FlatAdam:
         if lo < self.numel:
             out.append((lo, self.numel))
         self._zero_ranges = out
+        self._clean = False
 
     def zero_grad(self, set_to_none: bool = False):
         # gradients are accumulated by the HIP backward kernels directly into flat_g
+        if self._clean:
+            return      # the previous step's Adam launch cleared these ranges and nothing has accumulated since
         for lo, hi in self._zero_ranges:
             if self.flat_g.is_cuda:
                 check(lib().dvae_zero_f32(self.flat_g.data_ptr() + 4 * lo, hi - lo, stream()), "dvae_zero_f32")
             else:
                 self.flat_g[lo:hi].zero_()
+        self._clean = self.flat_g.is_cuda and not torch.cuda.is_current_stream_capturing()
+
+    def sync_scalars(self, grad_scale: float = None):
+        """Host -> device copy of (lr, grad_scale) when they changed since the last copy.  NOT capturable by design: the
+        trainer calls it before capture / replay, `step()` calls it itself when the stream is not capturing."""
+        lr = float(self.param_groups[0]["lr"])
+        gs = float(self._dev_scalars[1] if (grad_scale is None and self._dev_scalars) else (grad_scale or 1.0))
+        if self._dev_scalars != (lr, gs):
+            self.dev_state[4:6].copy_(torch.tensor([lr, gs], dtype=torch.float32), non_blocking=False)
+            self._dev_scalars = (lr, gs)
+
+    def _store_first_guard(self):
+        """A store-first parameter is excluded from zero_grad: its gradient must have been WRITTEN exactly once since the
+        last step (ops.LinearFn.backward counts), else Adam would consume a stale or a partial gradient."""
+        for n, p in zip(self.names, self.params):
+            if getattr(p, "_dvae_grad_store_first", False):
+                w = getattr(p, "_dvae_sf_writes", None)
+                if w is not None and w != 1:
+                    p._dvae_sf_writes = 0
+                    raise RuntimeError(f"FlatAdam: store-first gradient of {n} was written {w} times since the last step "
+                                       "(exactly one backward pass per step; for gradient accumulation clear the flag "
+                                       "with set_store_first(()) first)")
+                p._dvae_sf_writes = 0
 
     def step(self, grad_scale: float = 1.0):
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdam.step runs only on the HIP device (no CPU fallback)")
         from . import ops
+        from ._lib import Ranges
+        import ctypes as C
         if not self.views_intact():
             # model.zero_grad() (set_to_none), .to()/.float() or `p.grad = None` would detach parameters from the flat
             # buffers: the kernels would then accumulate elsewhere while Adam and the all-reduce read stale zeros
             raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
                                "(use optimizer.zero_grad(), never model.zero_grad()/p.grad = None/model.to())")
+        self._store_first_guard()
         ops.join_side()     # weight-gradient work may still be running on the side stream
-        lr = self.param_groups[0]["lr"]
+        if torch.cuda.is_current_stream_capturing():
+            if self._dev_scalars is None or self._dev_scalars[1] != float(grad_scale):
+                raise RuntimeError("FlatAdam.step under capture: call sync_scalars(grad_scale) before the capture")
+        else:
+            self.sync_scalars(grad_scale)
+        skip = None
+        if self.guard_device_errors and ops.LSTM_PERSISTENT:
+            skip = lib().dvae_lstm_pers_err_word(ptr(ops.lstm_pers_workspace(self.flat_p.device)))
+        rg = Ranges()
+        if self.fold_zero_grad:
+            if len(self._zero_ranges) > 8:
+                raise RuntimeError("FlatAdam: more than 8 zero_grad ranges")
+            rg.n = len(self._zero_ranges)
+            for i, (lo, hi) in enumerate(self._zero_ranges):
+                rg.lo[i], rg.hi[i] = lo, hi
         check(lib().dvae_adam_flat_dev(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                       self.numel, lr, self.betas[0], self.betas[1], self.eps, grad_scale,
-                                       ptr(self.dev_state), stream()), "dvae_adam_flat_dev")
+                                       self.numel, self.betas[0], self.betas[1], self.eps, ptr(self.dev_state), skip,
+                                       C.byref(rg), stream()), "dvae_adam_flat_dev")
+        self._clean = bool(self.fold_zero_grad)
 
     @property
     def t(self) -> int:
@@ -133,22 +193,35 @@ class FlatAdam:
                 "exp_avg_sq": {n: self._to_ref(n, v).detach().cpu().contiguous()
                                for n, v in self._moment_views(self.exp_avg_sq)}}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, legacy_layout=None):
+        """legacy_layout: only for format-1 files (see below): "packed" | "torch"."""
         if sorted(sd["names"]) != sorted(self.names):
             raise ValueError("optimizer state was saved for a different set of parameters")
         fmt = int(sd.get("format", 1))
         if fmt == 1:
-            # raw flat vectors written before conv weights were stored packed: every slice is in torch's layout and in
-            # the order of ITS `names`
+            # raw flat vectors in the order of ITS `names`.  Two builds wrote this format and nothing in the file tells
+            # them apart: before conv weights were stored packed every slice was in torch's layout [Cout][Cin][5]; the
+            # build right before format 2 already stored (and saved) conv slices packed [5][Cout][Cin].  Guessing would
+            # silently scramble every conv moment, so the caller has to say which one it is.
             if list(sd["names"]) != self.names:
                 raise ValueError("format-1 optimizer state needs the parameter order it was saved with")
+            if legacy_layout not in ("packed", "torch"):
+                differs = [n for n, p in zip(self.names, self.params) if tuple(self._to_ref(n, p).shape) != tuple(p.shape)]
+                if differs:
+                    raise ValueError("format-1 optimizer state does not record how conv-weight slices are laid out: pass "
+                                     "legacy_layout='packed' (files written by the build that stored conv weights "
+                                     "[5][Cout][Cin]) or 'torch' ([Cout][Cin][5]); env DVAE_OPT_LEGACY_LAYOUT for "
+                                     f"load_last_model.  Affected: {differs[:3]} ...")
             per = {}
             for key in ("exp_avg", "exp_avg_sq"):
                 flat, d = sd[key], {}
                 for n, p in zip(self.names, self.params):
                     o = self.offsets[n]
-                    ref_shape = tuple(self._to_ref(n, p).shape)
-                    d[n] = flat[o:o + p.numel()].view(ref_shape)
+                    sl = flat[o:o + p.numel()]
+                    if legacy_layout == "packed":
+                        d[n] = self._to_ref(n, sl.view_as(p))          # slice in STORAGE layout -> reference layout
+                    else:
+                        d[n] = sl.view(tuple(self._to_ref(n, p).shape))
                 per[key] = d
         elif fmt == self.STATE_FORMAT:
             per = {"exp_avg": sd["exp_avg"], "exp_avg_sq": sd["exp_avg_sq"]}
@@ -156,6 +229,7 @@ class FlatAdam:
             raise ValueError(f"optimizer state format {fmt} is newer than this build understands ({self.STATE_FORMAT})")
         self.dev_state.zero_()
         self.dev_state[0] = float(sd["t"])
+        self._dev_scalars = None           # lr / grad_scale are re-sent by the next sync_scalars
         self.param_groups[0]["lr"] = float(sd["lr"])
         for key, flat in (("exp_avg", self.exp_avg), ("exp_avg_sq", self.exp_avg_sq)):
             for n, v in self._moment_views(flat):

@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 302
+#define DVAE_ABI_VERSION 303
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -227,6 +227,9 @@ int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
 int dvae_lstm_pers_supported(int N, int H, int mode, int bwd);
 int64_t dvae_lstm_pers_ws_bytes(int N, int H);
 int dvae_lstm_pers_check(void* ws, int* info4, void* stream);
+/* device address of the sticky error word of workspace `ws` (non-zero from the first bounded wait that gave up until
+ * dvae_lstm_pers_check reported it): the `skip_if_nonzero` argument of dvae_adam_flat_dev */
+const unsigned* dvae_lstm_pers_err_word(void* ws);
 int dvae_lstm_pers_selftest(const dvae_lstm_dir_t* dir, int T, int N, int H, int64_t ldh, int drop_bid, void* stream);
 
 int dvae_lstm_seq_fwd(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int H, int64_t ldh, void* stream);
@@ -290,10 +293,22 @@ int dvae_loss_bwd(const dvae_loss_desc_t* desc, const float* g8, float* d_recon1
 int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                    float beta2, float eps, float grad_scale, int step, void* stream);
 
-/* Same update with the step counter and bias corrections kept ON THE DEVICE (state[0]=t, state[1]=1-beta1^t,
- * state[2]=sqrt(1-beta2^t); zero-initialised by the caller): replayable from a captured hipGraph.  n % 4 == 0. */
-int dvae_adam_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
-                       float beta2, float eps, float grad_scale, float* state, void* stream);
+/* Same update with every scalar that changes between steps kept ON THE DEVICE, so that a captured hipGraph replays a
+ * correct Adam step and a learning-rate schedule needs no re-capture.  state: float[8], zero-initialised by the caller:
+ *   [0] t (advanced by this call)   [1] 1 - beta1^t   [2] sqrt(1 - beta2^t)   [4] lr   [5] grad_scale
+ * ([4], [5] written by the caller — optim.FlatAdam.sync_scalars — outside any capture).
+ * skip_if_nonzero (optional): a device word; while it is non-zero the call changes NOTHING (no tick, no update, no clear).
+ *   optim.FlatAdam passes the sticky error word of the persistent LSTM launches (dvae_lstm_pers_err_word): a launch that gave
+ *   up a bounded wait left garbage gradients, and the weights / moments must not consume them before the host has looked.
+ * clear: up to 8 ranges [lo, hi) of g (multiples of 4 elements) that are zeroed AFTER they were read — the
+ *   optimizer.zero_grad() of the NEXT step (variational_base_vae.py:86) rides on this launch's pass over g.
+ * n % 4 == 0. */
+typedef struct {
+  int64_t lo[8], hi[8];
+  int n;
+} dvae_ranges_t;
+int dvae_adam_flat_dev(float* p, float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
+                       float* state, const unsigned* skip_if_nonzero, const dvae_ranges_t* clear, void* stream);
 
 /* x[0, n) = 0 (16-byte aligned): optimizer.zero_grad() (variational_base_vae.py:86) and the outputs that split-k
  * contractions accumulate into atomically, zeroed by a launch of their own right in front of the accumulation. */

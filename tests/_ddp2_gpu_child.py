@@ -33,6 +33,7 @@ def main():
         w.model.load_state_dict(fill_state_dict(w.model.state_dict()))
     w.model.train()
     opt = w.optimizer
+    opt.fold_zero_grad = False           # this test reads the summed gradients AFTER the step
     ddp.broadcast_parameters(opt.flat_p, list(w.model.buffers()))
     red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets, bucket_bytes=32 << 20)
     assert red.staged and red.world_size == world

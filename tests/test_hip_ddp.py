@@ -107,12 +107,16 @@ def test_two_rank_step_equals_chunked_oracle_step_on_hip(tmp_path):
     tr.model.load_state_dict(fill_state_dict(tr.model.state_dict()))
     tr.model.train()
     want = chunked_step_grads(tr, x1, x2, eps, 2)
-    worst = 0.0
+    # conv biases in front of a training-mode BatchNorm have a mathematically zero gradient (round-off on both sides)
+    prebn = lambda n: n.endswith(".0.conv.bias") or (n.startswith("dec_modules.") and n.endswith(".0.bias"))
+    bad = []
     for n, g in want.items():
-        denom = float(g.norm())
-        if denom > 1e-3:
-            worst = max(worst, float((t0["grads"][n] - g).norm()) / denom)
-    assert worst < 2e-3, worst           # fp32 round-off floor of the gradients (ReLU-gate flips), as in test_hip_model
+        err, ref = float((t0["grads"][n] - g).norm()), float(g.norm())
+        if prebn(n):
+            assert err <= 1e-2, (n, err)
+        elif err > 5e-3 * ref:             # the tolerance of test_hip_model (fp32 round-off floor: ReLU-gate flips)
+            bad.append((n, err, ref))
+    assert not bad, bad
     # losses: each rank reports ITS shard's losses; their mean is the chunked step's loss
     from oracle.dvae_ref import loss_gvae2
     ref = []

@@ -275,8 +275,9 @@ def test_frontend_refuses_cpu():
 
 def test_flat_adam_state_is_layout_independent():
     """The optimizer checkpoint holds the moments per parameter in the REFERENCE's layout: a conv weight stored packed
-    [5][Cout][Cin] round-trips through [Cout][Cin][5], and a format-1 file (raw flat vectors written when conv weights
-    were still stored in torch's layout) is converted instead of being silently permuted."""
+    [5][Cout][Cin] round-trips through [Cout][Cin][5].  A format-1 file (raw flat vectors) was written by TWO builds —
+    conv slices in torch's layout, later packed — and says nowhere which: the loader refuses to guess and
+    converts either variant when told (`legacy_layout`)."""
     import dvae_amd  # noqa: F401
     from dvae_amd.optim import FlatAdam
 
@@ -313,7 +314,22 @@ def test_flat_adam_state_is_layout_independent():
     old = {"t": 3, "lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "names": ["conv.weight", "lin.weight"],
            "exp_avg": flat, "exp_avg_sq": flat.clone()}
     c = make()
-    c.load_state_dict(old)
+    with pytest.raises(ValueError, match="legacy_layout"):
+        c.load_state_dict(old)                                  # nothing in the file says which variant it is
+    c.load_state_dict(old, legacy_layout="torch")
     assert torch.equal(c.exp_avg[:30].view(5, 3, 2), ref.permute(2, 0, 1))
+    # the variant the build right before format 2 wrote: the conv slice is already in STORAGE (packed) layout
+    packed = torch.arange(30, dtype=torch.float32)
+    flat_p = torch.zeros(a.numel)
+    flat_p[:30] = packed
+    d = make()
+    d.load_state_dict(dict(old, exp_avg=flat_p, exp_avg_sq=flat_p.clone()), legacy_layout="packed")
+    assert torch.equal(d.exp_avg[:30], packed)                  # unchanged: same storage layout then and now
+    assert d.t == 3
+    # a format-1 file for a model WITHOUT layout differences needs no hint
+    e = FlatAdam([("lin.weight", torch.nn.Parameter(torch.zeros(4, 6)))], lr=1e-3)
+    e.load_state_dict({"t": 1, "lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "names": ["lin.weight"],
+                       "exp_avg": torch.ones(24), "exp_avg_sq": torch.ones(24)})
+    assert float(e.exp_avg.sum()) == 24.0
     with pytest.raises(ValueError):
         c.load_state_dict(dict(sd, format=3))
