@@ -112,6 +112,8 @@ SIGNATURES = {
     "dvae_mul_div": (i32, [vp, vp, vp, vp, i64, vp]),
     "dvae_set_compute_mode": (i32, [i32]),
     "dvae_get_compute_mode": (i32, []),
+    "dvae_set_deterministic": (i32, [i32]),
+    "dvae_get_deterministic": (i32, []),
     "dvae_stft_frames": (i32, [vp, i64, vp, vp, i32, i32, i32, i32, vp]),
     "dvae_stft_magnitude": (i32, [vp, vp, i64, i32, vp]),
     "dvae_mel_db_normalize": (i32, [vp, vp, i32, i32, i64, i64, f32, f32, f32, vp]),

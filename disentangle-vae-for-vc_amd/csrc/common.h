@@ -59,6 +59,7 @@ static inline int dvae_dev_knob(const char* name, int dflt) {
 #endif
 
 extern int g_dvae_compute_mode;   // gemm.hip: process default of the contraction arithmetic (DVAE_MODE_*)
+extern int g_dvae_deterministic;  // gemm.hip: dvae_set_deterministic
 
 extern int g_dvae_last_hip_error;
 

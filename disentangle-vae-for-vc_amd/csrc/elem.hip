@@ -850,6 +850,7 @@ DVAE_API int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int
   // [16384 x 4096] fp32 54 / 52 / 48 / 41): 512, and 1024 once there are >= 512 workgroups even so
   int rows_pb = ((int64_t)R * cb >= (int64_t)512 * 1024) ? 1024 : 512;
   if (dvae_dev_knob("DVAE_COLSUM_ROWS", 0) > 0) rows_pb = dvae_dev_knob("DVAE_COLSUM_ROWS", 0);
+  if (g_dvae_deterministic) rows_pb = R;      // one workgroup per column block walks all rows: one add per column
   dim3 grid(cb, (R + rows_pb - 1) / rows_pb);
   if (x_bf16) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);
   else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb);

@@ -35,6 +35,7 @@
 #endif
 
 int g_dvae_compute_mode = 0;   // process default of the contraction mode (DVAE_MODE_*, dvae_set_compute_mode)
+int g_dvae_deterministic = 0;  // dvae_set_deterministic: every accumulated output element gets ONE writer in a fixed order
 
 #ifdef DVAE_GEMM_TS
 // Development probe (build with -DDVAE_GEMM_TS): wave 0 of every workgroup measures the s_memtime cycles of its whole
@@ -1450,7 +1451,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   if ((((uintptr_t)p.A) | ((uintptr_t)p.B)) & 15) return DVAE_EINVAL;
   if (!a_kc && (p.M & 3)) return DVAE_EINVAL;
   if (!b_kc && (p.N & 3)) return DVAE_EINVAL;
-  if (p.split_k < 1) p.split_k = 1;
+  if (p.split_k < 1 || g_dvae_deterministic) p.split_k = 1;   // deterministic: one writer per element, no atomic races
   if (p.split_k > 1 && (p.epi != DVAE_EPI_ATOMIC || p.act != DVAE_ACT_NONE)) return DVAE_EINVAL;
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
   // tuning knobs for experiments (scripts/one_shape.py): environment variables in the DEV build, constants in the product
@@ -1606,6 +1607,11 @@ DVAE_API int dvae_set_compute_mode(int mode) {
   return DVAE_OK;
 }
 DVAE_API int dvae_get_compute_mode(void) { return g_dvae_compute_mode; }
+DVAE_API int dvae_set_deterministic(int on) {
+  g_dvae_deterministic = on ? 1 : 0;
+  return DVAE_OK;
+}
+DVAE_API int dvae_get_deterministic(void) { return g_dvae_deterministic; }
 
 DVAE_API int dvae_gemm_f32(const void* A, const void* B, void* C, const float* bias, int M, int N, int K,
                            int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int act,

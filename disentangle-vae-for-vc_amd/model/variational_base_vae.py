@@ -91,7 +91,7 @@ class VariationalBaseModelVAE:
         return (tuple(data1.shape), tuple(opt.betas), float(opt.eps),
                 float(self.mse_cof), float(self.kl_cof), int(self.batch_size), bool(self.model.training),
                 self.reducer is not None, getattr(self.reducer, "world_size", 1), ops.current_mode(),
-                bool(ops.LSTM_PERSISTENT))
+                bool(ops.LSTM_PERSISTENT), bool(ops.deterministic()))
 
     def _eager_train_step(self, data1, data2):
         self.optimizer.zero_grad()

@@ -131,11 +131,32 @@ def _ready(*ps):
                 grad_ready_hook(p)
 
 
+_DETERMINISTIC = False
+
+
+def set_deterministic(flag: bool = True):
+    """TEST mode (not the benchmarked path): every accumulated output element gets one writer in a fixed order — no
+    split-k atomics (contractions run unsplit), column sums by one workgroup per column block, the recurrences' bias
+    gradients by such a column sum instead of the persistent launches' atomics.  Two runs of a step on the same inputs
+    are then BIT-identical, so graph replay vs eager and RCCL vs plain can be compared exactly
+    (tests/test_hip_determinism.py) instead of through the 1e-5 ... 4e-2 tolerances the atomics' run-to-run noise
+    needs.  Slower (under-filled launches); `DVAE_DETERMINISTIC=1` in the environment switches it on at import."""
+    global _DETERMINISTIC
+    _DETERMINISTIC = bool(flag)
+    check(lib().dvae_set_deterministic(int(_DETERMINISTIC)), "dvae_set_deterministic")
+
+
+def deterministic() -> bool:
+    return _DETERMINISTIC
+
+
 def _split_k(m_tiles: int, k: int, slots: int = 0, fixed: int = 192) -> int:
     """Pick the split of the contraction that minimises (rounds over the chip) x (k per workgroup + fixed cost):
     512 workgroup slots (2 per CU at the 128x128x32 tile), each split keeps >= 256 of K.  Not restricted to
     powers of two: 80 tiles x 6 splits fill one round where x 8 needs two.  `slots` / `fixed`: for shapes that run on the
     256 x 128 kernels (one workgroup per CU; an atomically accumulated 128 KB epilogue per workgroup)."""
+    if _DETERMINISTIC:
+        return 1
     slots = slots or int(os.environ.get("DVAE_SPLIT_SLOTS", "512"))
     best, best_cost = 1, None
     for s in range(1, max(1, k // 256) + 1):
@@ -650,9 +671,11 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].reverse = d
             dirs[d].state_bf16 = int(s16)
         pers = lstm_persistent_usable(N, H, bf, ndir, bwd=True)
+        pers_bias = pers and not _DETERMINISTIC      # (atomics across row groups and waves: not in the deterministic mode)
         if pers:
-            # the persistent launch also leaves the bias gradients (column sums of dG): no colsum pass below
             _pers_fill(dirs[0], dev)
+        if pers_bias:
+            # the persistent launch also leaves the bias gradients (column sums of dG): no colsum pass below
             dirs[0].dbias_ih, dirs[0].dbias_hh = ptr(_grad_buf(params[0][2])), ptr(_grad_buf(params[0][3]))
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         dx = None
@@ -677,7 +700,7 @@ class LstmLayerFn(torch.autograd.Function):
                     sk = _split_k(_tiles(4 * H, H), rows)
                     gemm(a_ptr, b_ptr, gw, None, 4 * H, H, rows, 4 * H, ldh, H, False, False, ACT_NONE, EPI_ATOMIC, sk, mode,
                          flags=(A_BF16 | B_BF16) if s16 else 0)
-                if not pers:
+                if not pers_bias:
                     colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         for (wi, wh, bi, bh) in params:
             _ready(wi, wh, bi, bh)
@@ -1104,3 +1127,7 @@ def prof_collect():
     ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
     check(lib().dvae_prof_collect(C.byref(ms), C.byref(n), C.byref(fl)), "dvae_prof_collect")
     return ms.value, n.value, fl.value
+
+
+if os.environ.get("DVAE_DETERMINISTIC", "0") == "1":
+    set_deterministic(True)

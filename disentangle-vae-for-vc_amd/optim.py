@@ -123,15 +123,17 @@ class FlatAdam:
     def _store_first_guard(self):
         """A store-first parameter is excluded from zero_grad: its gradient must have been WRITTEN exactly once since the
         last step (ops.LinearFn.backward counts), else Adam would consume a stale or a partial gradient."""
+        bad = None
         for n, p in zip(self.names, self.params):
             if getattr(p, "_dvae_grad_store_first", False):
                 w = getattr(p, "_dvae_sf_writes", None)
-                if w is not None and w != 1:
-                    p._dvae_sf_writes = 0
-                    raise RuntimeError(f"FlatAdam: store-first gradient of {n} was written {w} times since the last step "
-                                       "(exactly one backward pass per step; for gradient accumulation clear the flag "
-                                       "with set_store_first(()) first)")
+                if w is not None and w != 1 and bad is None:
+                    bad = (n, w)
                 p._dvae_sf_writes = 0
+        if bad is not None:
+            raise RuntimeError(f"FlatAdam: store-first gradient of {bad[0]} was written {bad[1]} times since the last step "
+                               "(exactly one backward pass per step; for gradient accumulation clear the flag with "
+                               "set_store_first(()) first)")
 
     def step(self, grad_scale: float = 1.0):
         if not self.flat_p.is_cuda:

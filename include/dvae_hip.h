@@ -72,6 +72,15 @@ int dvae_version(void);
 #define DVAE_MODE_F32X3 2
 int dvae_set_compute_mode(int mode);
 int dvae_get_compute_mode(void);
+
+/* Deterministic mode (a TEST mode; off by default, not on the benchmarked path).  The fast path accumulates split-k
+ * partial products, column sums and the recurrences' bias gradients with float atomics, whose order — hence the last
+ * bits of every gradient — changes from run to run.  With the mode on every accumulated output element has ONE writer
+ * in a fixed order: contractions run unsplit (split_k is forced to 1), dvae_colsum_add walks all rows in one
+ * workgroup per column block; callers keep the recurrences' bias gradients out of the persistent launches (ops.py).
+ * Two runs of the same step on the same inputs are then bit-identical (tests/test_hip_determinism.py). */
+int dvae_set_deterministic(int on);
+int dvae_get_deterministic(void);
 /* hipError_t of the last failed launch (0 if none) */
 int dvae_last_hip_error(void);
 

@@ -51,6 +51,8 @@ def main():
         out["losses_plain"].append(list(a.step(x1, x2, None, train=True)))
         out["losses_ddp"].append(list(b.step(x1, x2, None, train=True)))
     torch.cuda.synchronize()
+    from dvae_amd import ops
+    out["deterministic"] = bool(ops.deterministic())
     out["graph_captured"] = b._graph is not None
     out["stats"] = red.stats
     out["views_intact"] = bool(a.optimizer.views_intact() and b.optimizer.views_intact())

