@@ -264,7 +264,9 @@ def build_trainer(dev, B, T, dtype, world=1, rank=0, force_ddp=False):
     torch.cuda.manual_seed(1234 + 7919 * rank)
     if world > 1 or force_ddp:
         ddp.broadcast_parameters(w.optimizer.flat_p, [b for b in w.model.buffers()])
-        red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets)
+        red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets,
+                              mode=os.environ.get("DVAE_DDP_MODE", "all_reduce"),      # or "rs_ag": sharded Adam
+                              issue=os.environ.get("DVAE_DDP_ISSUE", "hook"))          # or "finish": no overlap
         red.force = force_ddp
         w.attach_reducer(red)
     return w
@@ -425,6 +427,9 @@ def main():
     if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        if os.environ.get("DVAE_RCCL_MAX_CHANNELS"):
+            # bound the CUs an in-flight collective occupies beside the W_hh-resident recurrences (which want every CU)
+            os.environ["NCCL_MAX_NCHANNELS"] = os.environ["DVAE_RCCL_MAX_CHANNELS"]
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
@@ -502,6 +507,8 @@ def main():
         extra.update({"ms_per_step_eager": ms_eager, "per_rank_ms_eager": [round(v, 3) for v in per_rank.tolist()],
                       "rccl_ranks": dist.get_world_size(), "visible_devices": torch.cuda.device_count(),
                       "backend": backend, "ranks_share_a_gpu": bool(shared_gpu),
+                      "ddp_mode": red.mode, "ddp_issue": red.issue,
+                      "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"),
                       "buckets": {"count": len(red.buckets), "bytes": [4 * (hi - lo) for lo, hi in red.buckets],
                                   "launched_from_backward_hooks": red.stats["hook"], "left_for_finish": red.stats["finish"],
                                   "steps": red.stats["steps"]}})

@@ -94,7 +94,7 @@ SIGNATURES = {
     "dvae_loss_fwd": (i32, [C.POINTER(LossDesc), vp, vp, vp]),
     "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
-    "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, vp]),
+    "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, i32, vp]),
     "dvae_lstm_pers_err_word": (vp, [vp]),
     "dvae_sum_f32": (i32, [vp, vp, vp, vp, i64, vp]),
     "dvae_zero_f32": (i32, [vp, i64, vp]),

@@ -725,7 +725,8 @@ DVAE_API int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_
 }
 
 DVAE_API int dvae_adam_flat_dev(float* p, float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
-                                float* state, const unsigned* skip_if_nonzero, const dvae_ranges_t* clear, void* stream) {
+                                float* state, const unsigned* skip_if_nonzero, const dvae_ranges_t* clear, int tick,
+                                void* stream) {
   if (!p || !g || !m || !v || !state || n < 4 || (n & 3)) return DVAE_EINVAL;
   if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return DVAE_EINVAL;
   AdamClear c{};
@@ -740,7 +741,7 @@ DVAE_API int dvae_adam_flat_dev(float* p, float* g, float* m, float* v, int64_t 
     }
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2, skip_if_nonzero);
+  if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2, skip_if_nonzero);
   constexpr int U = 2;
   const int64_t n4 = n >> 2;
   hipLaunchKernelGGL(adam_dev_kernel<U>, dim3(nblk((n4 + U - 1) / U, 256, 2048)), dim3(256), 0, s, p, g, m, v, n4, beta1,

@@ -64,6 +64,10 @@ class VariationalBaseModelVAE:
     # ---- data parallel (new functionality: the reference is single-device)
     def attach_reducer(self, reducer):
         self.reducer = reducer
+        if reducer is not None and getattr(reducer, "mode", "all_reduce") == "rs_ag" and self.optimizer is not None:
+            # a sharded step reads (and could clear) only this rank's slices of the gradient buffer: zero_grad launches
+            self.optimizer.fold_zero_grad = False
+            self.optimizer._clean = False
 
     def enable_graph(self, flag: bool = True, ddp=None):
         """Capture the train step into a hipGraph on its second call and replay it afterwards.  The first call runs
@@ -113,11 +117,11 @@ class VariationalBaseModelVAE:
             torch.autograd.backward(vec, self._loss_seed)
         else:
             losses[0].backward()
-        scale = 1.0
         if self.reducer is not None:
             self.reducer.finish()
-            scale = 1.0 / self.reducer.world_size
-        self.optimizer.step(grad_scale=scale)
+            self.reducer.step(self.optimizer)       # full Adam after an all-reduce, or the sharded step (mode "rs_ag")
+        else:
+            self.optimizer.step(grad_scale=1.0)
         return vec.detach() if vec is not None else torch.stack([l.detach() for l in losses])
 
     def _step_graph(self, data1, data2):
@@ -381,6 +385,9 @@ class VariationalBaseModelVAE:
                 if log_f:
                     log_f.write(json.dumps(rec) + "\n")
                     log_f.flush()
+            if epoch % report_interval == 0 and checkpoints_path and self.reducer is not None \
+                    and hasattr(self.reducer, "gather_moments"):
+                self.reducer.gather_moments(self.optimizer)      # a collective: every rank, before rank 0 writes
             if epoch % report_interval == 0 and self._is_rank0() and checkpoints_path:
                 os.makedirs(checkpoints_path, exist_ok=True)
                 with torch.no_grad():

@@ -23,6 +23,7 @@ import torch
 from ._lib import check, lib, ptr, stream
 
 _ALIGN = 4  # elements (16 bytes)
+_PAD = 32   # the flat buffers' length is a multiple of this: any world size up to 8 cuts it into 16-byte aligned shards
 
 
 class FlatAdam:
@@ -46,6 +47,8 @@ class FlatAdam:
                 raise ValueError("FlatAdam needs fp32 parameters on one device")
             self.offsets[n] = off
             off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.n_used = off                                  # elements that belong to parameters
+        off = (off + _PAD - 1) // _PAD * _PAD              # zero tail: a sharded step cuts the buffers into equal parts
         self.numel = off
         self.flat_p = torch.zeros(off, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(off, device=dev, dtype=torch.float32)
@@ -136,37 +139,51 @@ class FlatAdam:
                                "set_store_first(()) first)")
 
     def step(self, grad_scale: float = 1.0):
+        """One Adam step over all parameters: one launch."""
+        self.step_range(0, self.numel, grad_scale, tick=True)
+
+    def step_range(self, lo: int, hi: int, grad_scale: float = 1.0, tick: bool = True):
+        """The update of elements [lo, hi) of the flat buffers.  `tick` advances the step counter first: exactly one call
+        per step has it set (the first).  A sharded optimizer (ddp.GradReducer(mode="rs_ag")) calls this once per bucket
+        on the slice this rank owns."""
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdam.step runs only on the HIP device (no CPU fallback)")
         from . import ops
         from ._lib import Ranges
         import ctypes as C
-        if not self.views_intact():
-            # model.zero_grad() (set_to_none), .to()/.float() or `p.grad = None` would detach parameters from the flat
-            # buffers: the kernels would then accumulate elsewhere while Adam and the all-reduce read stale zeros
-            raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
-                               "(use optimizer.zero_grad(), never model.zero_grad()/p.grad = None/model.to())")
-        self._store_first_guard()
-        ops.join_side()     # weight-gradient work may still be running on the side stream
-        if torch.cuda.is_current_stream_capturing():
-            if self._dev_scalars is None or self._dev_scalars[1] != float(grad_scale):
-                raise RuntimeError("FlatAdam.step under capture: call sync_scalars(grad_scale) before the capture")
-        else:
-            self.sync_scalars(grad_scale)
+        if lo % 4 or hi % 4 or not 0 <= lo < hi <= self.numel:
+            raise ValueError(f"FlatAdam.step_range: [{lo}, {hi}) is not a 16-byte aligned range of the flat buffers")
+        if tick:
+            if not self.views_intact():
+                # model.zero_grad() (set_to_none), .to()/.float() or `p.grad = None` would detach parameters from the flat
+                # buffers: the kernels would then accumulate elsewhere while Adam and the all-reduce read stale zeros
+                raise RuntimeError("FlatAdam: a parameter or its .grad is no longer a view of the flat buffers "
+                                   "(use optimizer.zero_grad(), never model.zero_grad()/p.grad = None/model.to())")
+            self._store_first_guard()
+            ops.join_side()     # weight-gradient work may still be running on the side stream
+            if torch.cuda.is_current_stream_capturing():
+                if self._dev_scalars is None or self._dev_scalars[1] != float(grad_scale):
+                    raise RuntimeError("FlatAdam.step under capture: call sync_scalars(grad_scale) before the capture")
+            else:
+                self.sync_scalars(grad_scale)
         skip = None
         if self.guard_device_errors and ops.LSTM_PERSISTENT:
             skip = lib().dvae_lstm_pers_err_word(ptr(ops.lstm_pers_workspace(self.flat_p.device)))
         rg = Ranges()
         if self.fold_zero_grad:
-            if len(self._zero_ranges) > 8:
+            spans = [(max(a, lo) - lo, min(b, hi) - lo) for a, b in self._zero_ranges if min(b, hi) > max(a, lo)]
+            if len(spans) > 8:
                 raise RuntimeError("FlatAdam: more than 8 zero_grad ranges")
-            rg.n = len(self._zero_ranges)
-            for i, (lo, hi) in enumerate(self._zero_ranges):
-                rg.lo[i], rg.hi[i] = lo, hi
-        check(lib().dvae_adam_flat_dev(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                                       self.numel, self.betas[0], self.betas[1], self.eps, ptr(self.dev_state), skip,
-                                       C.byref(rg), stream()), "dvae_adam_flat_dev")
-        self._clean = bool(self.fold_zero_grad)
+            rg.n = len(spans)
+            for i, (a, b) in enumerate(spans):
+                rg.lo[i], rg.hi[i] = a, b
+        o = 4 * lo
+        check(lib().dvae_adam_flat_dev(self.flat_p.data_ptr() + o, self.flat_g.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                                       self.exp_avg_sq.data_ptr() + o, hi - lo, self.betas[0], self.betas[1], self.eps,
+                                       ptr(self.dev_state), skip, C.byref(rg), int(tick), stream()), "dvae_adam_flat_dev")
+        # the whole buffer was read and cleared only by a full step; a sharded step leaves the other ranks' slices
+        # untouched, and says so itself (GradReducer.step)
+        self._clean = bool(self.fold_zero_grad) and lo == 0 and hi == self.numel
 
     @property
     def t(self) -> int:

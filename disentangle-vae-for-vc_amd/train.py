@@ -111,11 +111,15 @@ def setup_data_parallel(vsc, seed):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29519")
         backend = os.environ.get("DVAE_DIST_BACKEND", "nccl")
+        if os.environ.get("DVAE_RCCL_MAX_CHANNELS"):
+            os.environ["NCCL_MAX_NCHANNELS"] = os.environ["DVAE_RCCL_MAX_CHANNELS"]
         kw = {"device_id": torch.device(vsc.device)} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     opt = vsc.optimizer
     ddp.broadcast_parameters(opt.flat_p, list(vsc.model.buffers()))
-    red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets)
+    red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets,
+                          mode=os.environ.get("DVAE_DDP_MODE", "all_reduce"),     # "rs_ag": reduce-scatter + sharded Adam
+                          issue=os.environ.get("DVAE_DDP_ISSUE", "hook"))         # "finish": collectives after backward
     red.force = os.environ.get("DVAE_FORCE_DDP", "0") == "1"      # issue the collectives with one rank too (tests)
     vsc.attach_reducer(red)
     return rank, world

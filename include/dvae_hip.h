@@ -311,13 +311,16 @@ int dvae_adam_flat(float* p, const float* g, float* m, float* v, int64_t n, floa
  *   up a bounded wait left garbage gradients, and the weights / moments must not consume them before the host has looked.
  * clear: up to 8 ranges [lo, hi) of g (multiples of 4 elements) that are zeroed AFTER they were read — the
  *   optimizer.zero_grad() of the NEXT step (variational_base_vae.py:86) rides on this launch's pass over g.
+ * tick: 1 advances t and the bias corrections first (one call per step); 0 applies the update of the CURRENT t to another
+ *   slice of the buffers (a sharded optimizer — ddp.GradReducer(mode="rs_ag") — updates one slice per bucket; clear ranges
+ *   are relative to the `g` passed).
  * n % 4 == 0. */
 typedef struct {
   int64_t lo[8], hi[8];
   int n;
 } dvae_ranges_t;
 int dvae_adam_flat_dev(float* p, float* g, float* m, float* v, int64_t n, float beta1, float beta2, float eps,
-                       float* state, const unsigned* skip_if_nonzero, const dvae_ranges_t* clear, void* stream);
+                       float* state, const unsigned* skip_if_nonzero, const dvae_ranges_t* clear, int tick, void* stream);
 
 /* x[0, n) = 0 (16-byte aligned): optimizer.zero_grad() (variational_base_vae.py:86) and the outputs that split-k
  * contractions accumulate into atomically, zeroed by a launch of their own right in front of the accumulation. */

@@ -33,7 +33,9 @@ def main():
         red = None
         if with_reducer:
             ddp.broadcast_parameters(w.optimizer.flat_p, list(w.model.buffers()))
-            red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets)
+            red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets,
+                                  mode=os.environ.get("DVAE_DDP_MODE", "all_reduce"),
+                                  issue=os.environ.get("DVAE_DDP_ISSUE", "hook"))
             red.force = True                    # issue the collectives although world_size == 1
             w.attach_reducer(red)
             if use_graph:
@@ -53,6 +55,7 @@ def main():
     torch.cuda.synchronize()
     from dvae_amd import ops
     out["deterministic"] = bool(ops.deterministic())
+    out["ddp_mode"] = red.mode
     out["graph_captured"] = b._graph is not None
     out["stats"] = red.stats
     out["views_intact"] = bool(a.optimizer.views_intact() and b.optimizer.views_intact())

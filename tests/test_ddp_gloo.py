@@ -142,6 +142,88 @@ def _worker_step_equivalence(rank, world, port, q):
     dist.destroy_process_group()
 
 
+class _CpuAdam:
+    """TEST stand-in for FlatAdam's device launch on CPU tensors (the product's Adam runs only on the HIP device): the same
+    flat buffers, `step` / `step_range` with torch arithmetic — what GradReducer.step drives."""
+
+    def __init__(self, opt, lr=1e-2, b1=0.9, b2=0.999, eps=1e-8):
+        self.o, self.lr, self.b1, self.b2, self.eps, self.t = opt, lr, b1, b2, eps, 0
+        self.flat_p, self.exp_avg, self.exp_avg_sq = opt.flat_p, opt.exp_avg, opt.exp_avg_sq
+        self.calls = []
+
+    def step(self, grad_scale=1.0):
+        self.step_range(0, self.o.numel, grad_scale, tick=True)
+
+    def step_range(self, lo, hi, grad_scale=1.0, tick=True):
+        if tick:
+            self.t += 1
+        self.calls.append((lo, hi, tick))
+        g = self.o.flat_g[lo:hi] * grad_scale
+        m, v, p = self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], self.flat_p[lo:hi]
+        m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+        v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+        bc1, bc2 = 1 - self.b1 ** self.t, 1 - self.b2 ** self.t
+        p.sub_(self.lr / bc1 * m / (v.sqrt() / bc2 ** 0.5 + self.eps))
+
+
+def _worker_rs_ag(rank, world, port, q):
+    """World 4: three optimizer steps with the sharded path (reduce-scatter -> Adam on 1/world -> all-gather) against the
+    all-reduce path on the same per-rank gradients: parameters equal to 1e-6 on every rank, each rank updated exactly its
+    own slices, the gathered moments equal the all-reduce path's."""
+    _init(rank, world, port)
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ddp, ops
+    from dvae_amd.optim import FlatAdam
+    sizes = (900, 40, 3000, 8, 2500, 310, 1200, 64, 2048, 37)
+
+    def build(mode, issue="hook"):
+        torch.manual_seed(5)
+        ps = [(f"p{i}", torch.nn.Parameter(torch.randn(n))) for i, n in enumerate(sizes)]
+        opt = FlatAdam(ps, lr=1e-2)
+        assert opt.numel % 32 == 0 and opt.numel >= opt.n_used
+        red = ddp.GradReducer(opt.flat_g, opt.names, opt.params, opt.offsets, bucket_bytes=6000, mode=mode, issue=issue)
+        return ps, opt, red, _CpuAdam(opt)
+
+    A = build("all_reduce")
+    S = build("rs_ag")
+    F = build("rs_ag", issue="finish")
+    assert len(S[2].buckets) >= 4
+    for lo, hi in S[2].buckets:
+        assert (hi - lo) % (4 * world) == 0                       # equal, 16-byte aligned shards
+    assert S[2].buckets[0][0] == 0 and S[2].buckets[-1][1] == S[1].numel
+    own = sum(S[2].shard(b)[1] - S[2].shard(b)[0] for b in range(len(S[2].buckets)))
+    assert own * world == S[1].numel
+    for step in range(3):
+        g = torch.Generator().manual_seed(100 * step + rank)      # a different gradient per rank and step
+        grads = [torch.randn(n, generator=g) for n in sizes]
+        for ps, opt, red, adam in (A, S, F):
+            opt.zero_grad()
+            red.begin()
+            order = list(range(len(ps)))
+            import random
+            random.Random(step * 10 + rank).shuffle(order)          # hooks fire in a different order on every rank
+            for i in order:
+                ps[i][1].grad.add_(grads[i])
+                ops.grad_ready_hook(ps[i][1])
+            red.finish()
+            red.step(adam)
+        assert F[2].stats["hook"] == 0                            # issue="finish": nothing left the hooks
+        for name, X in (("rs_ag", S), ("rs_ag/finish", F)):
+            d = float((A[1].flat_p - X[1].flat_p).abs().max())
+            assert d <= 1e-6, (name, step, rank, d)
+    # every rank ran Adam on its own slices only: one call per bucket, 1/world of the elements, one tick per step
+    calls = S[3].calls
+    assert len(calls) == 3 * len(S[2].buckets) and sum(c[2] for c in calls) == 3
+    assert sum(c[1] - c[0] for c in calls) * world == 3 * S[1].numel
+    S[2].gather_moments(S[1])
+    assert float((A[1].exp_avg - S[1].exp_avg).abs().max()) <= 1e-6
+    assert float((A[1].exp_avg_sq - S[1].exp_avg_sq).abs().max()) <= 1e-6
+    dist.barrier()
+    if rank == 0:
+        q.put("ok")
+    dist.destroy_process_group()
+
+
 def _run(fn, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
@@ -167,3 +249,7 @@ def test_reducer_world4_uneven_ready_order_gloo():
 def test_two_rank_step_equals_chunked_oracle_step():
     worst = _run(_worker_step_equivalence)
     assert worst < 1e-4, worst
+
+
+def test_sharded_optimizer_rs_ag_world4_gloo():
+    assert _run(_worker_rs_ag, world=4) == "ok"

@@ -106,17 +106,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("graph", [0, 1])
-def test_rccl_step_equals_plain_step_bitwise(graph):
+@pytest.mark.parametrize("graph,mode", [(0, "all_reduce"), (1, "all_reduce"), (0, "rs_ag"), (1, "rs_ag")])
+def test_rccl_step_equals_plain_step_bitwise(graph, mode):
     """tests/_ddp_gpu_child.py with DVAE_DETERMINISTIC=1: a plain trainer and one whose step goes through GradReducer and
-    the real RCCL backend (one rank, collectives forced), eagerly and captured in the hipGraph, lr = 1e-4, 5 steps."""
+    the real RCCL backend (one rank, collectives forced), eagerly and captured in the hipGraph, lr = 1e-4, 5 steps;
+    mode "rs_ag": reduce_scatter_tensor -> Adam per bucket slice (dvae_adam_flat_dev, tick on the first) -> all_gather_into_tensor."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DVAE_DETERMINISTIC="1")
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0", DVAE_DETERMINISTIC="1", DVAE_DDP_MODE=mode)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_ddp_gpu_child.py"), str(graph), "1e-4", "5"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     o = json.loads([l for l in r.stdout.splitlines() if l.startswith("DDPCHILD ")][-1][len("DDPCHILD "):])
-    assert o["deterministic"] is True
+    assert o["deterministic"] is True and o["ddp_mode"] == mode
     assert o["losses_plain"] == o["losses_ddp"], (o["losses_plain"], o["losses_ddp"])
     assert o["param_dist_rel"] == 0.0 and o["exp_avg_rel"] == 0.0, (o["param_dist_rel"], o["exp_avg_rel"])
     assert o["graph_captured"] == bool(graph) and o["stats"]["finish"] == 0
