@@ -93,6 +93,7 @@ SIGNATURES = {
     "dvae_loss_ws_bytes": (i64, [i64]),
     "dvae_loss_fwd": (i32, [C.POINTER(LossDesc), vp, vp, vp]),
     "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
+    "dvae_gemm_f32_batched": (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, i32, vp]),
     "dvae_lstm_pers_err_word": (vp, [vp]),

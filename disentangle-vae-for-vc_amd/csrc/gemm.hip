@@ -76,6 +76,10 @@ struct GemmParams {
   // (64-row chunk, group, column) in the layout bn.hip's finalize kernels read — drops bn_partial's pass over Y
   double* bn_part;
   int bn_groups, bn_nseg;
+  // batched launch (dvae_gemm_f32_batched; 128 x 128 kernel, tap_mode 0): `batch` products of one shape in grid.z, product b
+  // on A + a_boff[b] ... (byte offsets) — several small under-filled launches become one that fills the chip
+  int batch;
+  int64_t a_boff[4], b_boff[4], c_boff[4];
 };
 
 // BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
@@ -161,13 +165,23 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     tap_fixed = blockIdx.z % p.taps;
     ks = blockIdx.z / p.taps;
   }
+  const char* pA = (const char*)p.A;
+  const char* pB = (const char*)p.B;
+  char* pC = (char*)p.C;
+  if (p.batch > 1) {            // batched launch: product b = ks / split_k on its own operands
+    const int b = ks / p.split_k;
+    ks -= b * p.split_k;
+    pA += p.a_boff[b];
+    pB += p.b_boff[b];
+    pC += p.c_boff[b];
+  }
   const int k_begin = ks * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int klen = k_end - k_begin;
   const int kiters = (klen + BK - 1) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
 
-  float* __restrict__ C = (float*)p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+  float* __restrict__ C = (float*)pC + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // ---- per-thread source descriptors (byte pointers), computed once
   const char* a_src[NLA];
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       const int row = idx / KQA, kq = idx % KQA;
       const int64_t m = m0 + row;
       a_k[j] = EA * kq;
-      a_src[j] = (const char*)p.A + (m * p.lda + k_begin + EA * kq) * ESA;
+      a_src[j] = pA + (m * p.lda + k_begin + EA * kq) * ESA;
       unsigned ok = 0;
       if (m < p.M) {
         if (p.tap_mode == 1) {
@@ -197,7 +211,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     } else {
       const int kr = idx / (BM / EA), m4 = idx % (BM / EA);
       a_k[j] = kr;
-      a_src[j] = (const char*)p.A + ((int64_t)(k_begin + kr) * p.lda + m0 + EA * m4) * ESA;
+      a_src[j] = pA + ((int64_t)(k_begin + kr) * p.lda + m0 + EA * m4) * ESA;
       a_ok[j] = (m0 + EA * m4 < p.M) ? 1u : 0u;
     }
   }
@@ -210,13 +224,13 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
     if (B_KC) {
       const int row = idx / KQB, kq = idx % KQB;
       b_k[j] = EB * kq;
-      b_src[j] = (const char*)p.B + ((int64_t)(n0 + row) * p.ldb + k_begin + EB * kq) * ESB;
+      b_src[j] = pB + ((int64_t)(n0 + row) * p.ldb + k_begin + EB * kq) * ESB;
       b_ok[j] = (n0 + row < p.N) ? 1u : 0u;
     } else {
       const int kr = idx / (BN / EB), n4 = idx % (BN / EB);
       b_k[j] = kr;
       const int64_t shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
-      b_src[j] = (const char*)p.B + (((int64_t)(k_begin + kr) + shift) * p.ldb + n0 + EB * n4) * ESB;
+      b_src[j] = pB + (((int64_t)(k_begin + kr) + shift) * p.ldb + n0 + EB * n4) * ESB;
       b_ok[j] = (n0 + EB * n4 < p.N) ? 1u : 0u;
     }
   }
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       const int row0 = m0 + wm * 64 + mt * 32 + 4 * kh;
       float* cbase = C + (int64_t)row0 * p.ldc + col;
       if (epi == DVAE_EPI_STORE && p.c16) {       // bf16 output (bf16 mode: the consumer is another contraction)
-        __bf16* cb = (__bf16*)p.C + (int64_t)row0 * p.ldc + col;
+        __bf16* cb = (__bf16*)pC + (int64_t)row0 * p.ldc + col;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = (r & 3) + 8 * (r >> 2);
@@ -1468,6 +1482,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   kps = ((kps + bk - 1) / bk) * bk;
   p.k_per_split = kps;
   p.split_k = (p.K + kps - 1) / kps;
+  if (p.batch > 1 && (p.tap_mode != 0 || p.bias || p.bn_part || p.batch > 4 || p.c16)) return DVAE_EINVAL;
   int zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
   // split mode: the 256 x 128 tile (gemm_x3_tall_kernel, one workgroup per CU) when it still fills the chip; an
   // atomically accumulated product (weight gradients) is cut into twice the k-splits for it
@@ -1478,7 +1493,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   const int64_t b_bytes = (int64_t)(b_kc ? p.N : p.K) * p.ldb * 4 * (p.tap_mode == 1 ? p.taps : 1);
   const bool tall_ok = (p.K % 16 == 0) && a_bytes < (1ll << 30) && b_bytes < (1ll << 30) &&   // + 16-byte stores of C
                        (p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.c_tap_stride % 4 == 0);
-  if (mode == DVAE_MODE_F32X3 && tall_env != 0 && tall_ok && p.M >= 256 && p.N > 64) {
+  if (mode == DVAE_MODE_F32X3 && tall_env != 0 && tall_ok && p.M >= 256 && p.N > 64 && p.batch <= 1) {
     const int t2 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     if (t2 * zdim < 192 && p.split_k > 1 && p.epi == DVAE_EPI_ATOMIC && kps >= 1024) {
       kps = ((kps / 2 + bk - 1) / bk) * bk;
@@ -1495,7 +1510,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   }
   // bf16 mode, both operands bf16 in memory, fp32 result: gemm_bf16_tall_kernel (64-deep k-tiles) under the same rules
   bool tall16 = false;
-  if (bf && p.a16 && p.b16 && !p.c16 && tall_env != 0 && p.M >= 256 && p.N > 64 && (p.K % 64 == 0) &&
+  if (bf && p.batch <= 1 && p.a16 && p.b16 && !p.c16 && tall_env != 0 && p.M >= 256 && p.N > 64 && (p.K % 64 == 0) &&
       (p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.c_tap_stride % 4 == 0) &&
       a_bytes < (1ll << 31) && b_bytes < (1ll << 31)) {      // (a_bytes / b_bytes above count 4 bytes per element)
     int kps64 = ((kps + 63) / 64) * 64;
@@ -1519,8 +1534,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   static const int big_env = dvae_dev_knob("DVAE_GEMM_BIG", -1);
   // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
-  bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0);
-  if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0);
+  bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0) && (p.batch <= 1);
+  if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0) && (p.batch <= 1);
   if (mode != DVAE_MODE_F32) big = false;   // the 16-wave tile exists for the fp32 MFMA only (128 registers per lane)
   const int bm = (big || tall || tall16) ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
@@ -1546,7 +1561,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     p.map_gn = gn;
     p.map_nstr = tiles_n / gn;
   }
-  dim3 grid(p.tiles_m * tiles_n, 1, zdim);
+  const int nb = p.batch > 1 ? p.batch : 1;
+  dim3 grid(p.tiles_m * tiles_n, 1, zdim * nb);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
   const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
                        ((big ? 4u : (tall || tall16) ? 1u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15) |
@@ -1556,7 +1572,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   const double ea = p.a16 ? 2.0 : 4.0, eb = p.b16 ? 2.0 : 4.0;   // bf16 mode: operands that are bf16 in memory
   const double alg_bytes = ea * (double)p.M * p.K + eb * (double)p.K * p.N * (p.tap_mode == 1 ? ntap : 1.0) +
                            (p.c16 ? 2.0 : 4.0) * (double)p.M * p.N * (p.tap_mode == 2 ? ntap : 1.0);
-  ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap, tag, alg_bytes);
+  ProfScope prof(1, s, 2.0 * p.M * p.N * (double)p.K * ntap * nb, tag, alg_bytes * nb);
   if (p.bn_part && (!a_kc || !b_kc || big || p.split_k != 1 || p.epi != DVAE_EPI_STORE || p.act != DVAE_ACT_NONE))
     return DVAE_EINVAL;
   // statistics chunks (64 rows) that never straddle a group or a frame: the cheap form of the BatchNorm epilogue
@@ -1622,6 +1638,26 @@ DVAE_API int dvae_gemm_f32(const void* A, const void* B, void* C, const float* b
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.taps = 1; p.tap_mode = 0;
   p.split_k = split_k; p.act = act; p.epi = epi;
+  return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
+}
+
+DVAE_API int dvae_gemm_f32_batched(const void* const* A, const void* const* B, void* const* C, int batch, int M, int N,
+                                   int K, int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int epi,
+                                   int split_k, int mode, void* stream) {
+  if (!A || !B || !C || batch < 1 || batch > 4) return DVAE_EINVAL;
+  GemmParams p{};
+  p.A = A[0]; p.B = B[0]; p.C = C[0]; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.taps = 1; p.tap_mode = 0;
+  p.split_k = split_k; p.act = DVAE_ACT_NONE; p.epi = epi;
+  p.batch = batch;
+  for (int b = 0; b < batch; ++b) {
+    if (!A[b] || !B[b] || !C[b] || ((((uintptr_t)A[b]) | ((uintptr_t)B[b]) | ((uintptr_t)C[b])) & 15)) return DVAE_EINVAL;
+    p.a_boff[b] = (const char*)A[b] - (const char*)A[0];
+    p.b_boff[b] = (const char*)B[b] - (const char*)B[0];
+    p.c_boff[b] = (char*)C[b] - (char*)C[0];
+  }
   return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
 }
 

@@ -243,6 +243,17 @@ def gemm(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act=ACT_NONE, epi
                               act, epi, split_k, _mflags(_mode(mode), A, B, Cout) | flags, stream()), "dvae_gemm_f32")
 
 
+def gemm_batched(As, Bs, Cs, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi=EPI_ATOMIC, split_k=1, mode=None, flags=0):
+    """len(As) (<= 4) products of one shape in ONE launch (dvae_gemm_f32_batched): C[b] (+)= opA(A[b]) opB(B[b]).
+    As / Bs / Cs: tensors or raw device addresses."""
+    a = lambda t: t if isinstance(t, int) else t.data_ptr()
+    n = len(As)
+    arr = lambda xs: (C.c_void_p * n)(*[a(x) for x in xs])
+    m = _mode(mode)
+    check(lib().dvae_gemm_f32_batched(arr(As), arr(Bs), arr(Cs), n, M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), epi,
+                                      split_k, _mflags(m, As[0], Bs[0], Cs[0]) | flags, stream()), "dvae_gemm_f32_batched")
+
+
 def zeros(shape, dev):
     """fp32 zeros written by dvae_zero_f32 (a launch of its own right in front of the atomic accumulation into it).
     (One arena for all split-k outputs of a step, cleared by the step's Adam launch, was tried and dropped: with two
@@ -686,7 +697,27 @@ class LstmLayerFn(torch.autograd.Function):
                 gemm(dgs[d], der[d].w_ih_t, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
                      EPI_STORE if d == 0 else EPI_ACCUM, mode=mode)
         with side_work(x, h_out, *dgs):
-            for d, (wi, wh, bi, bh) in enumerate(params):
+            if ndir == 2 and 4 * H < 1024:
+                # the two directions of a narrow layer (H = 64 encoder BiLSTM): each weight gradient alone is a few output
+                # tiles over 16 384 rows — the forward and the reverse direction's products share ONE launch
+                Nout, K = params[0][0].shape
+                sk = _split_k(2 * _tiles(Nout, K), R)
+                epi = EPI_ATOMIC if sk > 1 else EPI_ACCUM
+                gemm_batched(dgs, [x, x], [_grad_buf(params[0][0]), _grad_buf(params[1][0])], Nout, K, R, 4 * H, In, K,
+                             False, False, epi, sk, mode)
+                gws = [_grad_buf(params[0][1]), _grad_buf(params[1][1])]
+                if T > 1:
+                    rows = R - N
+                    sk = _split_k(2 * _tiles(4 * H, H), rows)
+                    gemm_batched([dgs[0].data_ptr() + esz * N * 4 * H, dgs[1].data_ptr()],
+                                 [h_out.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)], gws, 4 * H, H, rows, 4 * H, ldh, H,
+                                 False, False, EPI_ATOMIC if sk > 1 else EPI_ACCUM, sk, mode,
+                                 flags=(A_BF16 | B_BF16) if s16 else 0)
+                for d, (wi, wh, bi, bh) in enumerate(params):
+                    if not pers_bias:
+                        colsum_add(dgs[d], _grad_buf(bi), _grad_buf(bh))
+            else:
+              for d, (wi, wh, bi, bh) in enumerate(params):
                 dg = dgs[d]
                 linear_wgrad_acc(dg, x, _grad_buf(wi), mode=mode)
                 gw = _grad_buf(wh)      # exists (zero) even when T == 1 leaves W_hh without a gradient

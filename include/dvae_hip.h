@@ -96,6 +96,15 @@ int dvae_last_hip_error(void);
 int dvae_gemm_f32(const void* A, const void* B, void* C, const float* bias,
                   int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                   int a_kcontig, int b_kcontig, int act, int epi, int split_k, int mode, void* stream);
+
+/* `batch` (1..4) products of ONE shape in one launch: product b is C[b] (+)= opA(A[b]) * opB(B[b]) (no bias, no
+ * activation; epi / split_k / mode as above, storage flags apply to every product).  For contractions too small to fill
+ * the chip on their own — the weight gradients of the two directions of the H = 64 encoder BiLSTM (disentangled_vae.py:163):
+ * dW_ih, dW_hh of the forward and the reverse direction are two launches of batch 2 instead of four under-filled ones.
+ * A, B, C: host arrays of `batch` device pointers (read during the call only), each 16-byte aligned. */
+int dvae_gemm_f32_batched(const void* const* A, const void* const* B, void* const* C, int batch, int M, int N, int K,
+                          int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int epi, int split_k,
+                          int mode, void* stream);
 /* ---- Conv1d(k=5, stride 1, pad 2) on frame-major data (disentangled_vae.py:111-114, 178-181) ----
  * Weights are used in PACKED form Wp[5][Cout][Cin] (see dvae_conv_pack_w).
  * fwd : Y[R,Cout]   = sum_tap X[r+(tap-2)*N, :] * Wp[tap]^T + bias      (rows outside [0,R) are zero)

@@ -101,6 +101,36 @@ def test_gemm_tn_wgrad(ops, M, N, K, sk):
     close(dw, base.double() + dy.double().t() @ x.double(), name="gemm_tn")
 
 
+@pytest.mark.parametrize("M,N,K,sk,nb", [(256, 64, 16256, 16, 2), (256, 512, 4096, 4, 2), (256, 128, 1024, 1, 4),
+                                         (80, 72, 200, 1, 3)])
+def test_gemm_batched_equals_separate_launches(ops, M, N, K, sk, nb):
+    """dvae_gemm_f32_batched: nb products of one shape in one launch (the two directions' weight gradients of the H = 64
+    BiLSTM).  Unsplit, every product is bit-identical to its own dvae_gemm_f32 launch (same tile arithmetic); split,
+    both are compared with fp64."""
+    dys = [dev(rnd(K, M, seed=10 + b)) for b in range(nb)]
+    xs = [dev(rnd(K, N, seed=20 + b)) for b in range(nb)]
+    base = [rnd(M, N, seed=30 + b) for b in range(nb)]
+    got = [dev(b_.clone()) for b_ in base]
+    epi = ops.EPI_ATOMIC if sk > 1 else ops.EPI_ACCUM
+    ops.gemm_batched(dys, xs, got, M, N, K, M, N, N, False, False, epi, sk)
+    for b in range(nb):
+        ref = base[b].double() + dys[b].cpu().double().t() @ xs[b].cpu().double()
+        close(got[b], ref, name=f"batched[{b}]")
+        if sk == 1:
+            one = dev(base[b].clone())
+            ops.gemm(dys[b], xs[b], one, None, M, N, K, M, N, N, False, False, 0, ops.EPI_ACCUM, 1)
+            assert torch.equal(one, got[b]), b
+    # shared B operand (the dW_ih case: both directions contract with the same x)
+    got2 = [torch.zeros(M, N, device="cuda") for _ in range(2)]
+    ops.gemm_batched(dys[:2], [xs[0], xs[0]], got2, M, N, K, M, N, N, False, False, epi, sk)
+    for b in range(2):
+        close(got2[b], dys[b].cpu().double().t() @ xs[0].cpu().double(), name=f"batched shared B[{b}]")
+    from dvae_amd._lib import lib
+    import ctypes as C
+    arr = (C.c_void_p * 5)(*[got[0].data_ptr()] * 5)
+    assert lib().dvae_gemm_f32_batched(arr, arr, arr, 5, M, N, K, M, N, N, 0, 0, epi, sk, -1, None) == -1   # batch > 4
+
+
 def test_gemm_rejects_bad_args(ops):
     from dvae_amd._lib import DvaeHipError
     a = torch.zeros(16, 6, device="cuda")
