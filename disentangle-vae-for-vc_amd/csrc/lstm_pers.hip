@@ -1306,6 +1306,348 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
   }
 }
 
+// ======================================================================================================================
+// fp32x3 backward, K-SPLIT form (round 4).  lstm_pers_bwd_x3 gives a workgroup 16 hidden units over ALL of K = 4H: every one
+// of the 64 workgroups of a row group pulls the whole 32 x 4H fp32 slab of dG[t+1] (512 KB at H = 1024) through its L2 -> CU
+// path and splits every value it loads (44 VALU operations per 8 values): 7.3 us of loads and 5.9 us of VALU issue per
+// frame against 3.2 us of MFMA issue.  Here a workgroup owns 64 hidden units x ONE QUARTER of K (the gate columns of the
+// hidden units [kq H/4, (kq+1) H/4), all four gates): the same W_hh bytes on chip and the same MFMAs, but a quarter of the dG
+// rows (128 KB) and a quarter of the splits per CU — each loaded fragment now feeds four n-tiles (24 MFMAs instead of 6).
+// The price is a second hand-off per frame: the four k-quarter workgroups of a (row group, 64-unit block) each hold a
+// PARTIAL dh[32 x 64]; workgroup kq finishes the 16 units [16 kq, 16 kq + 16) of the block, so every workgroup sends three
+// 32 x 16 tiles (2 KB each, one per peer, each with a flag of its own) and sums the three it receives with its own in the
+// fixed order kq = 0..3.  From there the frame is lstm_pers_bwd_x3's: gate-derivative epilogue on 32 x 16 elements, dG[t] of
+// those 16 units published in the same fragment order, same flags (producer index jb = 4 ub + kq = bid / n_rb).
+//   wave w of workgroup (rb, ub, kq): k-chunks 8 kq + 2 w, + 1 of every gate (H = 1024), all four 16-unit n-tiles of ub.
+//   exchange slot = [dG fragments as before | inbox: [workgroup][sender kq][row tile][lane] f32x4]
+//   flags: dG flags as before; partial flags behind them, one 32-byte granule per (receiver, sender).
+// ======================================================================================================================
+constexpr int PERS_PFLAG_OFF = 4 * PERS_FLAG_LD_X3;      // words: partial flags start behind the dG flags of 4 row groups
+constexpr int PERS_PFLAG_STRIDE = 8;                     // words between two partial flags
+static_assert((PERS_PFLAG_OFF + 256 * 4 * PERS_PFLAG_STRIDE) * 4 <= PERS_FLAG_BYTES, "partial flags of 256 workgroups fit");
+
+struct X3KLds {
+  bf16x8 w2[NWV][4][4][2][64];   // plane 2 of W_hh: [wave][n-tile][gate][chunk][lane]  (H = 1024: 128 KB)
+  union {
+    f32x4 red[NWV][3][2][64];    // cross-wave reduction: wave w's partial tiles for the three n-tiles it does not finish
+    struct {
+      f32x4 fin[4][2][64];       // the four partial dh tiles of this workgroup's 16 units: [sender kq][row tile][lane]
+      float gx[4 * 2][16][20];   // dG[t] (fp32) [(g, mt)][row][16 units + pad]
+    } e;
+  } u;
+  float bsum[4][16];
+  int dead;
+};
+
+template <int H>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs a) {
+  constexpr int MT = 2, NEL = 2;
+  constexpr int NCH = H / 32;           // 32-deep k-chunks per gate
+  constexpr int KQ = NCH / 4;           // chunks per gate of one k-quarter
+  constexpr int KW = KQ / NWV;          // chunks per gate and wave (2 at H = 1024, 1 at H = 512)
+  constexpr int NU = 4 * KW * MT;       // (gate, chunk, row tile) units a wave loads per frame
+#ifndef PERS_RD_X3K
+#define PERS_RD_X3K 6
+#endif
+  constexpr int RD = NU < PERS_RD_X3K ? NU : PERS_RD_X3K;   // units in flight (two 1-KiB loads per lane each)
+  static_assert(KW >= 1 && KW <= 2, "H = 512 or 1024");
+  const int T = a.T, N = a.N;
+  const int bid = blockIdx.x;
+  const int rb = bid % a.n_rb, jb = bid / a.n_rb;      // jb = 4 ub + kq: the 16-unit block this workgroup FINISHES
+  const int kq = jb & 3, ub = jb >> 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  X3KLds& L = *reinterpret_cast<X3KLds*>(lds_raw);
+  volatile int* dead = &L.dead;
+  if (tid == 0) *dead = 0;
+  if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // packed_bwd (three planes): [(jb'*4 + g)][chunk][plane][lane][8] <- W[g*H + 32*chunk + 8q + j][jb'*16 + r]
+  bf16x8 W01[4][4][KW][2];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const bf16x8 w = *reinterpret_cast<const bf16x8*>(
+              a.wp + (((((int64_t)((ub * 4 + nt) * 4 + g)) * NCH + kq * KQ + wave * KW + k) * 3 + p) * 64 + lane) * 16);
+          if (p < 2) W01[nt][g][k][p < 2 ? p : 0] = w;
+          else L.w2[wave][nt][g][k][lane] = w;
+        }
+
+  const int emt = wave >> 1, e0 = (wave & 1) * 2;
+  const int erow0 = emt * 16 + q * 4 + e0;
+  int el_n[NEL];
+  bool el_ok[NEL];
+  float dcreg[NEL], ccreg[NEL];
+#pragma unroll
+  for (int i = 0; i < NEL; ++i) {
+    el_ok[i] = rb * 32 + erow0 + i < N;
+    el_n[i] = min(rb * 32 + erow0 + i, N - 1);
+    dcreg[i] = 0.f;
+  }
+  const int j0 = jb * 16;
+  const int64_t H4 = 4 * (int64_t)H;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, a.xch_bytes, 0x00020000);
+  const int dg_bytes = a.n_rb * 4 * NCH * MT * 2048;                      // dG part of a slot
+  const int slot_bytes = dg_bytes + (int)gridDim.x * 4 * MT * 1024;       // + inbox: [workgroup][sender][mt][lane] f32x4
+  const int xld = (rb * 4 * NCH + kq * KQ + wave * KW) * MT * 2048 + lane * 16;     // + ((g*NCH + k)*MT + mt)*2048 + half*1024
+  // this workgroup's 16 units are half of chunk jb/2: lanes 32*(jb&1) + (r + 16 q'), q' in {0,1}
+  const int xst = (rb * 4 * NCH + (jb >> 1)) * MT * 2048 + ((jb & 1) * 32 + lane) * 16;
+  // the dG of this k-quarter comes from the NPQ = H/64 workgroups that finish its units: jb' = NPQ kq .. NPQ kq + NPQ - 1
+  constexpr int NPQ = H / 64;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD_X3 + (NPQ * kq + (lane < NPQ ? lane : 0)) * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD_X3 + jb * PERS_FLAG_STRIDE;
+  // partial tiles: wave w != kq sends n-tile w to the peer that finishes it, bid_w = rb + n_rb (4 ub + w)
+  const int peer_bid = rb + a.n_rb * (ub * 4 + wave);
+  const int inb_st = dg_bytes + ((peer_bid * 4 + kq) * MT) * 1024 + lane * 16;     // + mt * 1024   (peer's inbox, sender = me)
+  const int inb_ld = dg_bytes + ((bid * 4 + wave) * MT) * 1024 + lane * 16;        // + mt * 1024   (my inbox, sender = wave)
+  unsigned* pf_out = a.flags + PERS_PFLAG_OFF + (peer_bid * 4 + kq) * PERS_PFLAG_STRIDE;
+  const unsigned* pf_in = a.flags + PERS_PFLAG_OFF + (bid * 4 + (lane < 4 ? lane : 0)) * PERS_PFLAG_STRIDE;
+
+  struct Ops {
+    float gt[NEL][4], cp[NEL], dho[NEL];
+  };
+  auto frame_t = [&](int step_) { const int fs = T - 1 - step_; return a.reverse ? (T - 1 - fs) : fs; };
+  auto fetch = [&](int step_, Ops& o) __attribute__((always_inline)) {
+    const int t_ = frame_t(step_);
+    const int tp_ = min(max(a.reverse ? t_ + 1 : t_ - 1, 0), T - 1);
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) o.gt[i][g] = a.gates[((int64_t)t_ * N + el_n[i]) * H4 + g * H + j0 + r];
+      o.cp[i] = a.c_all[((int64_t)tp_ * N + el_n[i]) * H + j0 + r];
+      o.dho[i] = a.dh_out[((int64_t)t_ * N + el_n[i]) * a.ldh + j0 + r];
+    }
+  };
+
+  auto frame = [&](int step, Ops& cur, Ops& nxt) __attribute__((always_inline)) -> bool {
+    const int fstep = T - 1 - step;
+    const int t = frame_t(step);
+    PERS_STAMP(0);
+    if (step > 0) {
+      f32x4 acc[4][MT];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPQ, (unsigned)step, a.timeout)) {
+        pers_give_up(a.err, 2, bid, step, wave);
+        *dead = 1;
+      }
+      __syncthreads();                                             // barrier A
+      PERS_STAMP(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int so = ((step - 1) & 1) * slot_bytes;
+      // unit u: gate g = u / (KW*MT), chunk k = (u / MT) % KW, row tile mt = u % MT; RD units in flight
+      f32x4 av[RD][2];
+      auto load = [&](int u) __attribute__((always_inline)) {
+        const int g = u / (KW * MT), k = (u / MT) % KW, mt = u % MT;
+        const int off = so + ((g * NCH + k) * MT + mt) * 2048;
+        av[u % RD][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld, off, 16));
+        av[u % RD][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld, off + 1024, 16));
+      };
+      auto split = [&](int u, bf16x8 (&pl)[3]) __attribute__((always_inline)) {
+        bf16x4 lo[3], hi[3];
+        PERS_SPLIT3(av[u % RD][0], lo);
+        PERS_SPLIT3(av[u % RD][1], hi);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) pl[p] = __builtin_shufflevector(lo[p], hi[p], 0, 1, 2, 3, 4, 5, 6, 7);
+      };
+#pragma unroll
+      for (int u = 0; u < RD; ++u) load(u);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 pl[2][3];                         // planes of the unit being multiplied / of the next one (split under its MFMAs)
+      split(0, pl[0]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+            const int u = (g * KW + k) * MT + mt;
+            if (u + 1 < NU) split(u + 1, pl[(u + 1) & 1]);
+            const bf16x8 (&pc)[3] = pl[u & 1];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              const bf16x8 w2 = L.w2[wave][nt][g][k][lane];
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[0], W01[nt][g][k][0], acc[nt][mt], 0, 0, 0);
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[0], W01[nt][g][k][1], acc[nt][mt], 0, 0, 0);
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[1], W01[nt][g][k][0], acc[nt][mt], 0, 0, 0);
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[1], W01[nt][g][k][1], acc[nt][mt], 0, 0, 0);
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[0], w2, acc[nt][mt], 0, 0, 0);
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pc[2], W01[nt][g][k][0], acc[nt][mt], 0, 0, 0);
+            }
+            if (u + RD < NU) {
+              __builtin_amdgcn_sched_barrier(0);
+              load(u + RD);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
+      // next frame's epilogue operands: in flight across the two hand-offs below (fetched here, not under the MFMAs, where
+      // their 12 registers made the loop spill)
+      fetch(min(step + 1, T - 1), nxt);
+      // ---- cross-wave reduction: wave w finishes n-tile w; its partial tiles of the other three go to LDS
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (nt == wave) continue;
+        const int sidx = wave < nt ? wave : wave - 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) L.u.red[nt][sidx][mt][lane] = acc[nt][mt];
+      }
+      PERS_STAMP(2);
+      __syncthreads();                                             // barrier B
+      f32x4 mine[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        // fixed order: waves 0..3 (own partial in its place)
+        f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+          f32x4 v;
+          if (w == wave) {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) v = (nt == wave) ? acc[nt][mt] : v;
+          } else {
+            v = L.u.red[wave][w < wave ? w : w - 1][mt][lane];
+          }
+          s4 += v;
+        }
+        mine[mt] = s4;
+      }
+      // ---- partial hand-off: n-tile `wave` belongs to peer kq' = wave; the workgroup's own tile stays
+      if (wave != kq) {
+        if (bid != a.drop_bid) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, mine[mt]), xrs, inb_st, so + mt * 1024, 16);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(pf_out, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      PERS_STAMP(3);
+      __syncthreads();                 // barrier C: `red` is dead from here (fin / gx alias it)
+      if (wave == kq) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) L.u.e.fin[kq][mt][lane] = mine[mt];
+      }
+      if (wave == NWV - 1 && !poll_ge(pf_in, lane < 4 && lane != kq, (unsigned)step, a.timeout)) {
+        pers_give_up(a.err, 2, bid, step, wave);
+        *dead = 1;
+      }
+      __syncthreads();                                             // barrier D
+      PERS_STAMP(4);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (wave != kq && !*dead) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          L.u.e.fin[wave][mt][lane] =
+              __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, inb_ld, so + mt * 1024, 16));
+      }
+    } else {
+      fetch(min(step + 1, T - 1), nxt);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) L.u.e.fin[wave][mt][lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                                               // barrier E
+    PERS_STAMP(5);
+    if (*dead) return false;
+
+    {
+      f32x2 rec = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.u.e.fin[0][emt][lane]) + e0);
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        rec += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.u.e.fin[w][emt][lane]) + e0);
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const float dh = cur.dho[i] + rec[i];
+        const float gi = cur.gt[i][0], gf = cur.gt[i][1], gg = cur.gt[i][2], go = cur.gt[i][3];
+        const float cp = fstep > 0 ? cur.cp[i] : 0.f;
+        const float tc = gate_tanh(ccreg[i]);
+        const float dc = dcreg[i] + dh * go * (1.f - tc * tc);
+        float o[4];
+        o[0] = dc * gg * gi * (1.f - gi);
+        o[1] = dc * cp * gf * (1.f - gf);
+        o[2] = dc * gi * (1.f - gg * gg);
+        o[3] = dh * tc * go * (1.f - go);
+        dcreg[i] = dc * gf;
+        ccreg[i] = cp;
+        const int row = erow0 + i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          L.u.e.gx[g * MT + (row >> 4)][row & 15][r] = o[g];
+          if (el_ok[i]) bs[g] += o[g];
+        }
+      }
+    }
+    __syncthreads();                                               // barrier F
+    PERS_STAMP(6);
+    if (wave == 0) {
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
+        if (lane < 32) {               // lane (r, q' in {0,1}): units 8q' + 4h .. + 3 of row r go to half h
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&L.u.e.gx[g * MT + mt][r][(q & 1) * 8 + 4 * h]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst,
+                                                       so + ((g * NCH * MT) + mt) * 2048 + h * 1024, 16);
+              }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_STAMP(7);
+        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
+        const int g = f / MT, mt = f - g * MT;
+        const int n = rb * 32 + mt * 16 + r;
+        if (n < N)
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dgates) + ((int64_t)t * N + n) * H4 + g * H + j0 + q * 4) =
+              *reinterpret_cast<const f32x4*>(&L.u.e.gx[f][r][q * 4]);
+      }
+    }
+    // (gx / fin are rewritten only behind the next frame's barriers A..C; `red` aliases them and is written after barrier A)
+    return true;
+  };
+
+  {
+    const int t0 = frame_t(0);
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) ccreg[i] = a.c_all[((int64_t)t0 * N + el_n[i]) * H + j0 + r];
+  }
+  Ops oa, ob;
+  fetch(0, oa);
+  __syncthreads();
+  for (int step = 0; step < T; step += 2) {
+    if (!frame(step, oa, ob)) break;
+    if (step + 1 < T && !frame(step + 1, ob, oa)) break;
+  }
+  if (a.db1 || a.db2) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][r], bs[g]);
+    __syncthreads();
+    if (tid < 64) {
+      const int g = tid >> 4, u = tid & 15;
+      const float v = L.bsum[g][u];
+      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
+      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
+    }
+  }
+}
+
 #ifdef DVAE_PERS_TS
 unsigned long long* g_pers_ts = nullptr;
 int g_pers_ts_bid = 0;
@@ -1349,7 +1691,7 @@ int pers_go(K kern, int need_lds, const PersArgs& a, int grid, hipStream_t s) {
   return dvae_check_launch();
 }
 
-// kind: 0 bf16 forward, 1 bf16 backward, 2 fp32x3 forward, 3 fp32 backward, 4 fp32x3 backward
+// kind: 0 bf16 forward, 1 bf16 backward, 2 fp32x3 forward, 3 fp32 backward, 4 fp32x3 backward, 5 fp32x3 backward (k-split)
 int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStream_t s) {
   constexpr int KL = PERS_KL;
   switch (kind) {
@@ -1369,6 +1711,9 @@ int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStrea
     case 3:
       if (H == 1024) return pers_go(lstm_pers_bwd_f32<1024, 8>, (int)sizeof(F32BwdLds<8>), a, grid, s);
       return pers_go(lstm_pers_bwd_f32<512, 0>, (int)sizeof(F32BwdLds<0>), a, grid, s);
+    case 5:
+      if (H == 1024) return pers_go(lstm_pers_bwd_x3k<1024>, (int)sizeof(X3KLds), a, grid, s);
+      return pers_go(lstm_pers_bwd_x3k<512>, (int)sizeof(X3KLds), a, grid, s);
     default:
       if (H == 1024) return pers_go(lstm_pers_bwd_x3<1024, 8>, (int)sizeof(X3BwdLds<8>), a, grid, s);
       return pers_go(lstm_pers_bwd_x3<512, 0>, (int)sizeof(X3BwdLds<0>), a, grid, s);
@@ -1389,6 +1734,8 @@ int64_t pers_slot_bytes(int kind, int N, int H, int mt) {
     case 1: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * 4 * (H / 32) * mt * 1024;
     case 2: return (int64_t)((N + 31) / 32) * (H / 32) * 2 * 3 * 1024;
     case 3: return (int64_t)((N + 31) / 32) * 4 * (H / 16) * 2 * 1024;
+    case 5: return (int64_t)((N + 31) / 32) * 4 * (H / 32) * 2 * 2048 +            // dG fragments
+                   (int64_t)((N + 31) / 32) * (H / 16) * 4 * 2 * 1024;             // + every workgroup's inbox of partial tiles
     default: return (int64_t)((N + 31) / 32) * 4 * (H / 32) * 2 * 2048;
   }
 }
@@ -1414,7 +1761,7 @@ static int64_t pers_ws_need(int T, int N, int H) {
   if (int mt = pers_mt(N, H, 256))
     for (int kind = 0; kind < 2; ++kind) slot = std::max(slot, pers_slot_bytes(kind, N, H, mt));
   if (pers_x3_ok(N, H, 256))
-    for (int kind = 2; kind < 5; ++kind) slot = std::max(slot, pers_slot_bytes(kind, N, H, 2));
+    for (int kind = 2; kind < 6; ++kind) slot = std::max(slot, pers_slot_bytes(kind, N, H, 2));
   if (!slot) return 0;
   return PERS_XCH_OFF + (T > 0 ? (int64_t)T : 2) * slot;
 }
@@ -1433,7 +1780,11 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     kind = bwd ? 1 : 0;
   } else {
     if (d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
-    if (d.packed_mode == DVAE_MODE_F32X3) kind = bwd ? 4 : 2;
+    // backward: the k-split form at H = 1024 (a quarter of the dG rows per CU); DVAE_PERS_BWD_KSPLIT
+    // (dev build) picks per H: bit 0 H = 1024, bit 1 H = 512
+    static const int ksplit = dvae_dev_knob("DVAE_PERS_BWD_KSPLIT", 1);
+    const bool ks = bwd && ((H == 1024 && (ksplit & 1)) || (H == 512 && (ksplit & 2)));
+    if (d.packed_mode == DVAE_MODE_F32X3) kind = bwd ? (ks ? 5 : 4) : 2;
     else if (d.packed_mode == DVAE_MODE_F32 && bwd) kind = 3;
     else return DVAE_EINVAL;
   }
@@ -1455,7 +1806,8 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   a.ts_bid = g_pers_ts_bid;
 #endif
   const int grid = (kind < 2 ? H / 32 : H / 16) * a.n_rb;
-  const size_t flag_bytes = (size_t)a.n_rb * (kind < 2 ? PERS_FLAG_LD : PERS_FLAG_LD_X3) * 4;
+  const size_t flag_bytes = kind == 5 ? (size_t)PERS_FLAG_BYTES      // + the partial flags behind the dG flags
+                                      : (size_t)a.n_rb * (kind < 2 ? PERS_FLAG_LD : PERS_FLAG_LD_X3) * 4;
   // The flags are cleared by a kernel of our own with write-through (agent-scope) stores, NOT by hipMemsetAsync: as a
   // memset node of a replayed hipGraph the clear was not always in memory when the next node's workgroups polled — about 1
   // replayed step in 100 read a flag of the PREVIOUS launch, went ahead and took that launch's rows out of the ring (a loss

@@ -66,3 +66,15 @@ for w in (0, 1, pw):
         txt += f", payload+drain (5->6) {float((s[2:-1, 0, 6] - s[2:-1, 0, 5]).median()):.0f}"
         txt += f", own flag -> next barA {float((s[3:, 0, 1] - s[2:-1, 0, 6]).median()):.0f}"
     print(f"wave {w}: " + txt)
+if os.environ.get("ALL_STAMPS"):
+    # k-split backward (lstm_pers_bwd_x3k): 0 frame start, 1 dG flags seen + barrier A, 2 MFMAs done + cross-wave tiles written,
+    # 3 own n-tile summed + partial tile published, 4 partial flags seen + barrier D, 5 barrier E, 6 epilogue + barrier F,
+    # 7 (wave 0) dG payload drained
+    for w in range(4):
+        row = []
+        for p in range(7):
+            a, b = s[2:-1, w, p], s[2:-1, w, p + 1]
+            ok = (a > 0) & (b > 0)
+            row.append(float((b - a)[ok].median()) if ok.any() else float("nan"))
+        print(f"wave {w}: " + ", ".join(f"{p}->{p + 1} {v:.0f}" for p, v in enumerate(row)))
+    print(f"wave 0: own dG flag (7) -> next barrier A (1): {float((s[3:, 0, 1] - s[2:-1, 0, 7]).median()):.0f}")
