@@ -605,7 +605,8 @@ def main():
                                                "algorithmic_bytes_per_launch": dom["bytes"] / max(1, dom["launches"])},
                     "instantiations": [{"kernel": t["kernel"], "ms_per_step": t["ms"] / prof_steps,
                                         "launches_per_step": t["launches"] / prof_steps,
-                                        "tflops": t["flops"] / (t["ms"] * 1e-3) / 1e12} for t in tags[:8]],
+                                        "tflops": t["flops"] / (t["ms"] * 1e-3) / 1e12,
+                                        "algorithmic_bytes_per_launch": t["bytes"] / max(1, t["launches"])} for t in tags],
                     "timed": f"HIP events around every launch, {prof_steps} eager steps right after the graph-replayed "
                              "timed region"}
 

@@ -1742,6 +1742,13 @@ int64_t pers_slot_bytes(int kind, int N, int H, int mt) {
 
 }  // namespace
 
+// fp32x3 backward: 1 when the k-split kernel (lstm_pers_bwd_x3k) runs for this H — H = 1024 (measured 12.7 -> 9.85 us per
+// frame; H = 512: 6.74 -> 6.56, not worth a second hand-off).  DVAE_PERS_BWD_KSPLIT (dev build): bit 0 H = 1024, bit 1 H = 512.
+int dvae_pers_bwd_ksplit(int H) {
+  static const int ksplit = dvae_dev_knob("DVAE_PERS_BWD_KSPLIT", 1);
+  return ((H == 1024 && (ksplit & 1)) || (H == 512 && (ksplit & 2))) ? 1 : 0;
+}
+
 // used by lstm.hip: 1 when (N, H, mode, pass) has a persistent kernel on this device
 int dvae_pers_usable(int N, int H, int pm, int bwd) {
   if (pm == DVAE_MODE_F32X3) return pers_x3_ok(N, H, pers_cu_count());      // forward, and backward with consumer-side split
@@ -1782,8 +1789,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     if (d.state_bf16 || !pers_x3_ok(N, H, cus) || (ldh & 3)) return DVAE_EINVAL;
     // backward: the k-split form at H = 1024 (a quarter of the dG rows per CU); DVAE_PERS_BWD_KSPLIT
     // (dev build) picks per H: bit 0 H = 1024, bit 1 H = 512
-    static const int ksplit = dvae_dev_knob("DVAE_PERS_BWD_KSPLIT", 1);
-    const bool ks = bwd && ((H == 1024 && (ksplit & 1)) || (H == 512 && (ksplit & 2)));
+    const bool ks = bwd && dvae_pers_bwd_ksplit(H);
     if (d.packed_mode == DVAE_MODE_F32X3) kind = bwd ? (ks ? 5 : 4) : 2;
     else if (d.packed_mode == DVAE_MODE_F32 && bwd) kind = 3;
     else return DVAE_EINVAL;

@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-root, steps = sys.argv[1], float(sys.argv[2])
+root, steps = sys.argv[1], float(sys.argv[2])      # steps: fallback only — the real count is the number of Adam launches
 tag = sys.argv[3] if len(sys.argv) > 3 else "pmc"
 traffic_json = sys.argv[4] if len(sys.argv) > 4 else None
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,6 +26,33 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         k = fam(r["Kernel_Name"])
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
+# steps actually profiled = dispatches of the optimizer kernel (one per step) in one pass: the bench command runs warm-up,
+# timed AND the step()-timing steps, so a count passed on the command line was wrong by 5/3 in round 3
+n_adam = collections.Counter()
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "adam_dev_kernel" in r["Kernel_Name"]:
+            n_adam[(f, r["Counter_Name"])] += 1
+if n_adam:
+    steps = float(max(n_adam.values()))
+# algorithmic bytes per launch and instantiation, from a bench.py line of the same build (profile_round.sh: alg.json)
+alg = {}
+try:
+    line = [l for l in open(os.path.join(root, "alg.json")) if l.lstrip().startswith("{")][-1]
+    for it in json.loads(line)["roofline"]["instantiations"]:
+        import re as _re
+        name = it["kernel"].split("<")[0]
+        kv = dict(_re.findall(r"(\w+)=(\d+)", it["kernel"]))
+        b = lambda k: "true" if kv.get(k, "0") != "0" else "false"
+        if name == "gemm_f32_kernel":
+            key = f"{name}<{b('A_KC')}, {b('B_KC')}, {kv['NTW']}, {kv['BK']}, {kv['WG']}, {kv['MODE']}, {b('BNS')}, {b('A16')}, {b('B16M')}>"
+        else:
+            key = f"{name}<{b('A_KC')}, {b('B_KC')}, {b('BNS')}"
+        e = alg.setdefault(key, [0.0, 0.0])
+        e[0] += it["algorithmic_bytes_per_launch"] * it["launches_per_step"]
+        e[1] += it["launches_per_step"]
+except Exception as e:      # the table is printed without the column
+    print(f"(no algorithmic bytes: {e!r})", file=sys.stderr)
 print(f"# {tag} PMC summary (rocprofv3 --pmc, three separate passes over `bench.py --steps 2 --warmup 1 --graph 0`; counters "
       f"summed per kernel family over the {steps:.0f} steps run, divided by {steps:.0f})\n")
 print(__doc__.split("\n\n", 1)[1] + "\n")
@@ -50,12 +77,15 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             icnt[k][r["Counter_Name"]] += 1
 if inst:
     print("\nContraction family by instantiation (fabric-side MB per LAUNCH: 2 x FETCH_SIZE + WRITE_SIZE):\n")
-    print("| instantiation | launches/step | read MB/launch | write MB/launch |")
-    print("|---|---|---|---|")
+    print("| instantiation | launches/step | read MB/launch | write MB/launch | algorithmic MB/launch (operands + result, each once) | fabric / algorithmic |")
+    print("|---|---|---|---|---|---|")
     for k in sorted(inst, key=lambda k: -(2 * inst[k].get("FETCH_SIZE", 0) + inst[k].get("WRITE_SIZE", 0))):
         n = max(1, icnt[k].get("FETCH_SIZE", 0))
-        print(f"| {k} | {n / steps:.0f} | {2 * inst[k].get('FETCH_SIZE', 0) / 1024 / n:.1f} | "
-              f"{inst[k].get('WRITE_SIZE', 0) / 1024 / max(1, icnt[k].get('WRITE_SIZE', 0)):.1f} |")
+        rd = 2 * inst[k].get('FETCH_SIZE', 0) / 1024 / n
+        wr = inst[k].get('WRITE_SIZE', 0) / 1024 / max(1, icnt[k].get('WRITE_SIZE', 0))
+        a = next((v for kk, v in alg.items() if k.startswith(kk) or kk.startswith(k)), None)
+        am = a[0] / max(1e-9, a[1]) / 1e6 if a else None
+        print(f"| {k} | {n / steps:.0f} | {rd:.1f} | {wr:.1f} | " + (f"{am:.1f} | {(rd + wr) / am:.2f} |" if am else "- | - |"))
 g = acc.get("gemm_f32_kernel")
 if g and g.get("FETCH_SIZE") and g.get("WRITE_SIZE"):
     launches = cnt["gemm_f32_kernel"]["FETCH_SIZE"] / steps

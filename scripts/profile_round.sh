@@ -25,11 +25,13 @@ rocprofv3 --kernel-trace --stats -f csv rocpd -d "$OUT/kt16" -o kt16 -- python3 
 DB16=$(find "$OUT/kt16" -name '*results.db' | head -1)
 if [ -n "$DB16" ]; then python3 scripts/rocpd_stats.py "$DB16" "$SUM/${TAG}_bf16_kernel_stats.csv" 40 > "$SUM/${TAG}_bf16_last_step.txt" 2>&1; fi
 tail -1 "$OUT/kt16.json" > "$SUM/${TAG}_bf16_bench_under_profiler.json"
+# algorithmic bytes per instantiation (bench.py's own tags), for the fabric / algorithmic column of the PMC summary
+python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$OUT/alg.json" 2> "$OUT/alg.err"
 EAGER="bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-other-configs --no-roofline"
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   D="$OUT/pmc_$(echo $C | tr ' ' '_')"
   rocprofv3 --pmc $C --kernel-trace -f csv -d "$D" -o pmc -- python3 $EAGER > "$D.json" 2> "$D.err"
 done
-python3 scripts/pmc_summary.py "$OUT" 3 "$TAG" "$SUM/pmc_traffic.json" > "$SUM/${TAG}_pmc_summary.md" 2> "$OUT/pmc_summary.err"
+python3 scripts/pmc_summary.py "$OUT" 5 "$TAG" "$SUM/pmc_traffic.json" > "$SUM/${TAG}_pmc_summary.md" 2> "$OUT/pmc_summary.err"
 ls -la "$SUM"
 # gpurun merges gpurun_out/ back: copy $SUM/* into profiles/ (tracked) afterwards
