@@ -98,6 +98,13 @@ class VariationalBaseModelVAE:
                 bool(ops.LSTM_PERSISTENT), bool(ops.deterministic()))
 
     def _eager_train_step(self, data1, data2):
+        from .. import ops
+        if getattr(self, "_zero_arena", None) is None:
+            self._zero_arena = ops.ZeroArena()
+        with self._zero_arena:       # the step's split-k outputs: one clear launch instead of eight
+            return self._train_step_body(data1, data2)
+
+    def _train_step_body(self, data1, data2):
         self.optimizer.zero_grad()
         if hasattr(self, "losses_vector_full") and hasattr(self.model, "forward_full"):
             # the eight scalars as one vector (fused loss kernels) on the UNSPLIT outputs; backward is seeded with the

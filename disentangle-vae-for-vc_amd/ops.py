@@ -254,11 +254,65 @@ def gemm_batched(As, Bs, Cs, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi=EPI_ATOMIC,
                                       split_k, _mflags(m, As[0], Bs[0], Cs[0]) | flags, stream()), "dvae_gemm_f32_batched")
 
 
+class ZeroArena:
+    """The zero-initialised outputs that split-k contractions accumulate into atomically (eight Linear outputs and data
+    gradients per train step), handed out as views of ONE buffer that ONE `dvae_zero_f32` launch clears at the start of the
+    step — instead of one clear launch in front of each.  Owned by a trainer and active only inside its train step
+    (`with arena:`): outside, and while the arena is still learning how much a step needs (its first step), `zeros()`
+    clears each tensor on its own.  Views are valid until the owner's NEXT step begins — the step's own forward / backward
+    use them, nothing that outlives the step may.
+    (Round 3 tried this together with an Adam-side clear and dropped it for 1e-5 deviations that turned out to be the
+    persistent launches' flag clear under graph replay, DESIGN_HISTORY.md; tests/test_hip_determinism.py now compares the
+    replayed and the eager step bit for bit with the arena in.)"""
+
+    def __init__(self):
+        self.buf = None          # fp32, persistent (allocated outside any capture)
+        self.need = 0            # elements one step takes (learned from the steps so far)
+        self.off = 0
+        self.ready = False       # this step's views come from `buf` (already cleared)
+        self._prev = None
+
+    def __enter__(self):
+        global _arena
+        self._prev, _arena = _arena, self
+        self.off = 0
+        self.ready = self.buf is not None and self.need > 0 and self.buf.numel() >= self.need
+        if self.ready:
+            check(lib().dvae_zero_f32(ptr(self.buf), self.need, stream()), "dvae_zero_f32")
+        return self
+
+    def __exit__(self, *exc):
+        global _arena
+        _arena = self._prev
+        if self.off > self.need:
+            self.need = self.off
+        if (self.buf is None or self.buf.numel() < self.need) and self.need > 0 and not torch.cuda.is_current_stream_capturing():
+            self.buf = torch.empty(self.need, device=self._dev, dtype=torch.float32)
+        return False
+
+    def take(self, shape, dev):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64                       # 256-byte aligned views
+        self._dev = dev
+        o = self.off
+        self.off += n_al
+        if self.ready and self.buf.device == torch.device(dev) and o + n_al <= self.need:
+            return self.buf[o:o + n].view(shape)
+        return None
+
+
+_arena = None
+
+
 def zeros(shape, dev):
-    """fp32 zeros written by dvae_zero_f32 (a launch of its own right in front of the atomic accumulation into it).
-    (One arena for all split-k outputs of a step, cleared by the step's Adam launch, was tried and dropped: with two
-    trainers in one process — an eager one and a graph-replayed one using the same arena addresses back to back — the
-    replayed step's decoder outputs came out 1e-5 off every other run; DESIGN.md, tried and dropped.)"""
+    """fp32 zeros for a launch that accumulates into them atomically: a view of the active ZeroArena (cleared by one launch at
+    the start of the train step), else a tensor of its own cleared by a dvae_zero_f32 launch right here."""
+    if _arena is not None:
+        t = _arena.take(tuple(shape), dev)
+        if t is not None:
+            return t
     t = torch.empty(shape, device=dev, dtype=torch.float32)
     check(lib().dvae_zero_f32(ptr(t), t.numel(), stream()), "dvae_zero_f32")
     return t
