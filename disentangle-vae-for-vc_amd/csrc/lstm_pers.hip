@@ -121,7 +121,7 @@ constexpr int NWV = 4;
 #define PERS_RD_F32 8
 #endif
 #ifndef PERS_PD_FWD2
-#define PERS_PD_FWD2 8
+#define PERS_PD_FWD2 8      // (lstm_pers_fwd_bf16<1024, 2, 2> spills 5 VGPRs with 8; the spill-free 7 measured SLOWER: 4.68 vs 4.57 us per frame at N = 256)
 #endif
 #ifndef PERS_PD_BWD2
 #define PERS_PD_BWD2 6
@@ -607,22 +607,29 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
 // planes 0 and 1 of its slice in registers (256 at H = 1024), plane 2 (used by one product of six) mostly in LDS.
 // Group = the H/16 workgroups of a row block (64 at H = 1024: one poller lane each).
 // ======================================================================================================================
-template <int KW, int K2L>
+// MT = row tiles of 16 segments per workgroup: 2 (32 rows; H = 1024 at N = 128 fills the chip with 64 x 4 workgroups) or 1 (16
+// rows: H = 512 at N = 128 would leave half the CUs idle at 32 rows — 32 x 8 workgroups of 16 rows use all of them)
+template <int MT>
+struct x3_own { typedef f32x2 type; };
+template <>
+struct x3_own<1> { typedef float type; };
+
+template <int KW, int K2L, int MT = 2>
 struct X3Lds {
   bf16x8 w2[K2L > 0 ? NWV : 1][4][K2L > 0 ? K2L : 1][64];   // plane 2 of chunks KW-K2L .. KW-1: [wave][g][k][lane]
-  f32x2 red[NWV][NWV - 1][4][64];        // partial gate sums FOR wave w's elements FROM the three other waves: [w][slot][g][lane]
-  __bf16 hx[3][2][16][24];               // h planes in A-fragment order [plane][mt][row][16 units + pad]
+  typename x3_own<MT>::type red[NWV][NWV - 1][4][64];   // partial gate sums FOR wave w's elements FROM the three other waves
+  __bf16 hx[3][MT][16][24];              // h planes in A-fragment order [plane][mt][row][16 units + pad]
   int dead;
 };
 
-template <int H, int K2L>
+template <int H, int K2L, int MT = 2>
 __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a) {
-  constexpr int MT = 2;
   constexpr int NCH = H / 32;           // 32-deep k-chunks of h
   constexpr int NPR = H / 16;           // producers of a row group
   constexpr int KW = NCH / NWV;         // chunks per wave
   constexpr int K2R = KW - K2L;         // chunks whose plane 2 stays in registers
-  constexpr int NEL = 2;
+  constexpr int NEL = MT;               // elements per thread: 16 MT rows x 16 units over 256 threads
+  typedef typename x3_own<MT>::type own_t;
   constexpr int RD = PERS_RD_X3;        // (chunk, row tile) units of h[t-1] in flight, three 1-KiB loads per lane each
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
   const int r = lane & 15, q = lane >> 4;
 
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  X3Lds<KW, K2L>& L = *reinterpret_cast<X3Lds<KW, K2L>*>(lds_raw);
+  X3Lds<KW, K2L, MT>& L = *reinterpret_cast<X3Lds<KW, K2L, MT>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
 
@@ -654,15 +661,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
   // this wave owns the elements (row tile emt, accumulator registers e0, e0+1) of every lane: rows emt*16 + q*4 + e0 + {0,1},
   // unit r.  Its accumulators START from those elements' pre-activations (the other positions from zero), so the sum over
   // the four waves' partial tiles IS the gate pre-activation and no operand of the epilogue stays live under the MFMAs.
-  const int emt = wave >> 1, e0 = (wave & 1) * 2;
+  // (MT = 1: one element per thread — accumulator register e0 = wave of the one row tile)
+  const int emt = MT == 2 ? (wave >> 1) : 0, e0 = MT == 2 ? (wave & 1) * 2 : wave;
   const int erow0 = emt * 16 + q * 4 + e0;
   int el_n[NEL];
   bool el_ok[NEL];
   float creg[NEL];
 #pragma unroll
   for (int i = 0; i < NEL; ++i) {
-    el_ok[i] = rb * 32 + erow0 + i < N;
-    el_n[i] = min(rb * 32 + erow0 + i, N - 1);
+    el_ok[i] = rb * 16 * MT + erow0 + i < N;
+    el_n[i] = min(rb * 16 * MT + erow0 + i, N - 1);
     creg[i] = 0.f;
   }
   const int j0 = jb * 16;
@@ -694,9 +702,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 own = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (e0) { own[2] = x[0][g]; own[3] = x[1][g]; } else { own[0] = x[0][g]; own[1] = x[1][g]; }
-      acc[0][g] = emt ? f32x4{0.f, 0.f, 0.f, 0.f} : own;
-      acc[1][g] = emt ? own : f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (MT == 2) {
+        if (e0) { own[2] = x[0][g]; own[3] = x[1][g]; } else { own[0] = x[0][g]; own[1] = x[1][g]; }
+        acc[0][g] = emt ? f32x4{0.f, 0.f, 0.f, 0.f} : own;
+        acc[1][g] = emt ? own : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) own[e] = (e == e0) ? x[0][g] : 0.f;
+        acc[0][g] = own;
+      }
     }
 
     PERS_STAMP(0);
@@ -755,8 +769,13 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
       const int slot = (wave - o - 1) & (NWV - 1);               // 0..2
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 v = acc[o >> 1][g];
-        L.red[o][slot][g][lane] = (o & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+        if constexpr (MT == 2) {
+          const f32x4 v = acc[o >> 1][g];
+          L.red[o][slot][g][lane] = (o & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+        } else {
+          const f32x4 v = acc[0][g];
+          L.red[o][slot][g][lane] = o == 0 ? v[0] : o == 1 ? v[1] : o == 2 ? v[2] : v[3];
+        }
       }
     }
     PERS_STAMP(2);
@@ -766,15 +785,21 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
 
     float go_[NEL][4], co_[NEL], ho_[NEL];
     {
-      f32x2 gs[4];
+      float gs[4][NEL];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        f32x4 own = acc[0][g];
-        if (emt) own = acc[1][g];
-        f32x2 sacc = e0 ? f32x2{own[2], own[3]} : f32x2{own[0], own[1]};
+        own_t sacc;
+        if constexpr (MT == 2) {
+          f32x4 own = acc[0][g];
+          if (emt) own = acc[1][g];
+          sacc = e0 ? f32x2{own[2], own[3]} : f32x2{own[0], own[1]};
+        } else {
+          const f32x4 own = acc[0][g];
+          sacc = e0 == 0 ? own[0] : e0 == 1 ? own[1] : e0 == 2 ? own[2] : own[3];
+        }
 #pragma unroll
         for (int sl = 0; sl < NWV - 1; ++sl) sacc += L.red[wave][sl][g][lane];
-        gs[g] = sacc;
+        if constexpr (MT == 2) { gs[g][0] = sacc[0]; gs[g][1] = sacc[1]; } else { gs[g][0] = sacc; }
       }
 #pragma unroll
       for (int i = 0; i < NEL; ++i) {
@@ -1065,24 +1090,24 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
 // into three planes BY THE CONSUMER (each value is split by the 64 workgroups that read it: the split is VALU work in the
 // shadow of the MFMAs, 44 operations per 8 values against six 16-cycle MFMAs).  fp32 results, 6/16 of the fp32-MFMA cycles.
 // ======================================================================================================================
-template <int K2L>
+template <int K2L, int MT = 2>
 struct X3BwdLds {
   bf16x8 w2[K2L > 0 ? NWV : 1][4][K2L > 0 ? K2L : 1][64];   // plane 2: [wave][g][k - K2R][lane]
-  f32x4 red[NWV][2][64];
-  float gx[4 * 2][16][20];               // dG[t] (fp32) [(g, mt)][row][16 units + pad]
+  f32x4 red[NWV][MT][64];
+  float gx[4 * MT][16][20];              // dG[t] (fp32) [(g, mt)][row][16 units + pad]
   float bsum[4][16];
   int dead;
 };
 
-template <int H, int K2L>
+template <int H, int K2L, int MT = 2>      // MT: see lstm_pers_fwd_x3
 __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a) {
-  constexpr int MT = 2, NEL = 2;
+  constexpr int NEL = MT;
   constexpr int NCH = H / 32;           // 32-deep k-chunks per gate
   constexpr int NPR = H / 16;           // producers of a row group
   constexpr int KW = NCH / NWV;         // chunks per gate and wave
   constexpr int K2R = KW - K2L;
   constexpr int NU = 4 * KW * MT;       // (gate, chunk, row tile) units a wave contracts per frame
-  constexpr int RD = 8;                 // units in flight (two 1-KiB loads per lane each)
+  constexpr int RD = NU < 8 ? NU : 8;   // units in flight (two 1-KiB loads per lane each)
   const int T = a.T, N = a.N;
   const int bid = blockIdx.x;
   const int rb = bid % a.n_rb, jb = bid / a.n_rb;
@@ -1091,7 +1116,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
   const int r = lane & 15, q = lane >> 4;
 
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
-  X3BwdLds<K2L>& L = *reinterpret_cast<X3BwdLds<K2L>*>(lds_raw);
+  X3BwdLds<K2L, MT>& L = *reinterpret_cast<X3BwdLds<K2L, MT>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
   if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
@@ -1112,15 +1137,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
         else L.w2[wave][g][k >= K2R ? k - K2R : 0][lane] = w;
       }
 
-  const int emt = wave >> 1, e0 = (wave & 1) * 2;
+  const int emt = MT == 2 ? (wave >> 1) : 0, e0 = MT == 2 ? (wave & 1) * 2 : wave;
   const int erow0 = emt * 16 + q * 4 + e0;
   int el_n[NEL];
   bool el_ok[NEL];
   float dcreg[NEL], ccreg[NEL];
 #pragma unroll
   for (int i = 0; i < NEL; ++i) {
-    el_ok[i] = rb * 32 + erow0 + i < N;
-    el_n[i] = min(rb * 32 + erow0 + i, N - 1);
+    el_ok[i] = rb * 16 * MT + erow0 + i < N;
+    el_n[i] = min(rb * 16 * MT + erow0 + i, N - 1);
     dcreg[i] = 0.f;
   }
   const int j0 = jb * 16;
@@ -1153,7 +1178,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
   auto frame = [&](int step, Ops& cur, Ops& nxt) __attribute__((always_inline)) -> bool {
     const int fstep = T - 1 - step;
     const int t = frame_t(step);
-    f32x4 acc[MT] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     PERS_STAMP(0);
     if (step > 0) {
@@ -1213,18 +1240,21 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
     } else {
       fetch(min(step + 1, T - 1), nxt);
     }
-    L.red[wave][0][lane] = acc[0];
-    L.red[wave][1][lane] = acc[1];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) L.red[wave][mt][lane] = acc[mt];
     PERS_STAMP(2);
     __syncthreads();                                               // barrier B
     PERS_STAMP(3);
     if (*dead) return false;
 
     {
-      f32x2 rec = *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.red[0][emt][lane]) + e0);
+      float rec[NEL];
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) rec[i] = reinterpret_cast<const float*>(&L.red[0][emt][lane])[e0 + i];
 #pragma unroll
       for (int w = 1; w < NWV; ++w)
-        rec += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(&L.red[w][emt][lane]) + e0);
+#pragma unroll
+        for (int i = 0; i < NEL; ++i) rec[i] += reinterpret_cast<const float*>(&L.red[w][emt][lane])[e0 + i];
 #pragma unroll
       for (int i = 0; i < NEL; ++i) {
         const float dh = cur.dho[i] + rec[i];
@@ -1272,7 +1302,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
     } else {
       for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
         const int g = f / MT, mt = f - g * MT;
-        const int n = rb * 32 + mt * 16 + r;
+        const int n = rb * 16 * MT + mt * 16 + r;
         if (n < N)
           *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.dgates) + ((int64_t)t * N + n) * H4 + g * H + j0 + q * 4) =
               *reinterpret_cast<const f32x4*>(&L.gx[f][r][q * 4]);
@@ -1707,6 +1737,7 @@ int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStrea
       return pers_go(lstm_pers_bwd_bf16<512, 2, 0>, (int)sizeof(BwdLds<2, 0>), a, grid, s);
     case 2:
       if (H == 1024) return pers_go(lstm_pers_fwd_x3<1024, 8>, (int)sizeof(X3Lds<8, 8>), a, grid, s);
+      if (mt == 1) return pers_go(lstm_pers_fwd_x3<512, 0, 1>, (int)sizeof(X3Lds<4, 0, 1>), a, grid, s);
       return pers_go(lstm_pers_fwd_x3<512, 0>, (int)sizeof(X3Lds<4, 0>), a, grid, s);
     case 3:
       if (H == 1024) return pers_go(lstm_pers_bwd_f32<1024, 8>, (int)sizeof(F32BwdLds<8>), a, grid, s);
@@ -1716,6 +1747,7 @@ int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStrea
       return pers_go(lstm_pers_bwd_x3k<512>, (int)sizeof(X3KLds), a, grid, s);
     default:
       if (H == 1024) return pers_go(lstm_pers_bwd_x3<1024, 8>, (int)sizeof(X3BwdLds<8>), a, grid, s);
+      if (mt == 1) return pers_go(lstm_pers_bwd_x3<512, 0, 1>, (int)sizeof(X3BwdLds<0, 1>), a, grid, s);
       return pers_go(lstm_pers_bwd_x3<512, 0>, (int)sizeof(X3BwdLds<0>), a, grid, s);
   }
 }
@@ -1732,11 +1764,11 @@ int64_t pers_slot_bytes(int kind, int N, int H, int mt) {
   switch (kind) {
     case 0: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * (H / 32) * mt * 1024;
     case 1: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * 4 * (H / 32) * mt * 1024;
-    case 2: return (int64_t)((N + 31) / 32) * (H / 32) * 2 * 3 * 1024;
+    case 2: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * (H / 32) * mt * 3 * 1024;
     case 3: return (int64_t)((N + 31) / 32) * 4 * (H / 16) * 2 * 1024;
     case 5: return (int64_t)((N + 31) / 32) * 4 * (H / 32) * 2 * 2048 +            // dG fragments
                    (int64_t)((N + 31) / 32) * (H / 16) * 4 * 2 * 1024;             // + every workgroup's inbox of partial tiles
-    default: return (int64_t)((N + 31) / 32) * 4 * (H / 32) * 2 * 2048;
+    default: return (int64_t)((N + 16 * mt - 1) / (16 * mt)) * 4 * (H / 32) * mt * 2048;
   }
 }
 
@@ -1793,6 +1825,13 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     if (d.packed_mode == DVAE_MODE_F32X3) kind = bwd ? (ks ? 5 : 4) : 2;
     else if (d.packed_mode == DVAE_MODE_F32 && bwd) kind = 3;
     else return DVAE_EINVAL;
+    // 16-row tiles where 32-row tiles would leave CUs idle (H = 512, N <= 128: 32 x 8 workgroups instead of 32 x 4);
+    // DVAE_PERS_X3_MT1=0 (dev build) keeps 32 rows
+    static const int mt1 = dvae_dev_knob("DVAE_PERS_X3_MT1", 1);
+    const int n_rb16 = (N + 15) / 16;
+    if (mt1 && (kind == 2 || kind == 4) && H == 512 && (H / 16) * ((N + 31) / 32) * 2 <= cus && n_rb16 <= 8 &&
+        (H / 16) * n_rb16 <= cus)
+      mt = 1;
   }
   PersArgs a{};
   a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
@@ -1801,7 +1840,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   char* ws = (char*)d.pers_ws;
   a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
   a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = d.state_bf16 ? 1 : 0;
-  a.n_rb = kind < 2 ? (N + 16 * mt - 1) / (16 * mt) : (N + 31) / 32;
+  a.n_rb = (N + 16 * mt - 1) / (16 * mt);      // (mt = 2 for every fp32x3 / fp32 kernel except the 16-row forms above)
   const unsigned us = d.pers_timeout_us ? d.pers_timeout_us : 2000000u;
   a.timeout = us > 40000000u ? 4000000000u : us * 100u;
   const int64_t slot = pers_slot_bytes(kind, N, H, mt);
