@@ -169,6 +169,76 @@ def test_persistent_fp32x3_forward_fp32_backward_match_frame_kernels(env, H, T, 
             assert err <= 1e-4 * float(want.abs().max()), f"bias gradient {k} ({which}): {err:.3e}"
 
 
+def _x3_pass(env, H, T, N, pers, seed=0):
+    """forward + backward of one layer in the default arithmetic (fp32x3) through the C ABI; pers: the W_hh-resident
+    launches (H = 1024 backward: the k-split kernel with its second, partial-tile hand-off; H = 512: 16-row tiles)."""
+    _lib, ops, lstm_local = env
+    L, st, ptr = _lib.lib(), _lib.stream(), _lib.ptr
+    X3 = _lib.MODE_F32X3
+    g = torch.Generator(device="cuda").manual_seed(1000 + seed)
+    f = dict(device="cuda", dtype=torch.float32)
+    w_hh = (torch.rand(4 * H, H, generator=g, **f) * 2 - 1) / H ** 0.5
+    der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), X3)
+    gates = torch.rand(T * N, 4 * H, generator=g, **f) * 2 - 1
+    dh = (torch.rand(T * N, H, generator=g, **f) * 2 - 1) * 0.1
+    h, c = torch.full((T * N, H), float("nan"), **f), torch.empty(T * N, H, **f)
+    dg, dc, db = torch.full((T * N, 4 * H), float("nan"), **f), torch.empty(N, H, **f), torch.zeros(2, 4 * H, **f)
+    ws = ops.lstm_pers_workspace("cuda")
+    d = (_lib.LstmDir * 1)()
+    d[0].gates, d[0].c_all, d[0].h_out, d[0].w_hh, d[0].w_packed = ptr(gates), ptr(c), ptr(h), ptr(w_hh), ptr(der.pack_f)
+    d[0].packed_mode = X3
+    b = (_lib.LstmDir * 1)()
+    b[0].gates, b[0].c_all, b[0].w_hh, b[0].w_packed = ptr(gates), ptr(c), ptr(der.w_hh_t), ptr(der.pack_b)
+    b[0].dh_out, b[0].dgates, b[0].dc_ws, b[0].packed_mode = ptr(dh), ptr(dg), ptr(dc), X3
+    if pers:
+        d[0].pers_ws = b[0].pers_ws = ptr(ws)
+        b[0].dbias_ih, b[0].dbias_hh = ptr(db[0]), ptr(db[1])
+    _lib.check(L.dvae_lstm_seq_fwd(d, 1, T, N, H, H, st), "fwd")
+    _lib.check(L.dvae_lstm_seq_bwd(b, 1, T, N, H, H, st), "bwd")
+    if pers:
+        ops.lstm_pers_check()
+    return gates, c, h, dg
+
+
+@pytest.mark.parametrize("H,T,N", [(1024, 96, 128), (512, 96, 128), (1024, 64, 97)])
+def test_fp32x3_handoffs_under_uneven_load(env, H, T, N):
+    """The default-arithmetic recurrences — at H = 1024 the k-split backward kernel with TWO hand-offs per frame (dG fragments,
+    then the partial dh tiles between the four k-quarter workgroups of a block), at H = 512 the 16-row tiles — while a second
+    stream streams 0 .. 4 GiB through HBM: every output word against the per-frame kernels, every round; then twice more
+    bit-for-bit against the first persistent run (the partial tiles are summed in a fixed order: no run-to-run noise)."""
+    ref = _x3_pass(env, H, T, N, pers=False)
+    side = torch.cuda.Stream()
+    a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
+    b = torch.empty_like(a)
+    first = None
+    for rnd in range(5):
+        with torch.cuda.stream(side):
+            for _ in range(rnd):
+                b.copy_(a)
+        got = _x3_pass(env, H, T, N, pers=True)
+        for name, x, y in zip(("gates", "c", "h", "dgates"), got, ref):
+            assert torch.isfinite(x).all(), (name, rnd)
+            err = float((x - y).abs().max())
+            assert err <= 2e-5 * float(y.abs().max()), f"{name}, round {rnd}: max |diff| {err:.3e}"
+        if first is None:
+            first = [t.clone() for t in got]
+        else:
+            for name, x, y in zip(("gates", "c", "h", "dgates"), got, first):
+                assert torch.equal(x, y), f"{name}, round {rnd}: persistent runs differ bitwise"
+    torch.cuda.synchronize()
+
+
+def test_fp32x3_soak_3000_frames(env):
+    """3 000 frames of the H = 1024 layer in one launch per pass (6 000 partial-tile exchanges per workgroup in the backward
+    pass): no hang, no drift against the per-frame kernels."""
+    T, N, H = 3000, 32, 1024
+    ref = _x3_pass(env, H, T, N, pers=False, seed=4)
+    got = _x3_pass(env, H, T, N, pers=True, seed=4)
+    for name, x, y in zip(("gates", "c", "h", "dgates"), got, ref):
+        assert torch.isfinite(x).all(), name
+        assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max()), name
+
+
 def test_persistent_handoffs_under_uneven_load(env):
     """A second stream streams 1 GiB copies through HBM while the persistent launches run: hand-offs must not depend on
     timing.  Every output word is compared with the per-frame kernels' each round."""
