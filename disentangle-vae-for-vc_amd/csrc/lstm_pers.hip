@@ -1737,7 +1737,10 @@ int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStrea
       return pers_go(lstm_pers_bwd_bf16<512, 2, 0>, (int)sizeof(BwdLds<2, 0>), a, grid, s);
     case 2:
       if (H == 1024) return pers_go(lstm_pers_fwd_x3<1024, 8>, (int)sizeof(X3Lds<8, 8>), a, grid, s);
+#ifdef DVAE_DEV      // (the 16-row forward form is not in the product library: see dvae_pers_launch)
       if (mt == 1) return pers_go(lstm_pers_fwd_x3<512, 0, 1>, (int)sizeof(X3Lds<4, 0, 1>), a, grid, s);
+#endif
+      if (mt == 1) return DVAE_EINVAL;
       return pers_go(lstm_pers_fwd_x3<512, 0>, (int)sizeof(X3Lds<4, 0>), a, grid, s);
     case 3:
       if (H == 1024) return pers_go(lstm_pers_bwd_f32<1024, 8>, (int)sizeof(F32BwdLds<8>), a, grid, s);
@@ -1827,10 +1830,16 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     else return DVAE_EINVAL;
     // 16-row tiles where 32-row tiles would leave CUs idle (H = 512, N <= 128: 32 x 8 workgroups instead of 32 x 4);
     // DVAE_PERS_X3_MT1=0 (dev build) keeps 32 rows
-    static const int mt1 = dvae_dev_knob("DVAE_PERS_X3_MT1", 1);
+    // bit 1: backward (measured 6.75 -> 4.66 us per frame; 0 failures in 300 rounds of scripts/x3_handoff_stress.py), bit 0:
+    // forward — DEV BUILD ONLY: 4.43 -> 3.41 us per frame, but 5-17 % of the stress rounds (a second stream streaming GiBs
+    // through HBM meanwhile) came back with rows 12..15 of one row group wrong in ALL columns from a frame around the 80th
+    // microsecond on.  Not the hand-off protocol (a release fence in front of the flag, an agent-scope acquire in front of
+    // the loads, sc0 sc1 loads, four ring slots, row groups spread over XCDs, a full vmcnt(0) after the loads: each still
+    // failed) and not found by reading the ISA; the 32-row forward kernel and every other persistent kernel: 0 of 200.
+    static const int mt1 = dvae_dev_knob("DVAE_PERS_X3_MT1", 2);
     const int n_rb16 = (N + 15) / 16;
-    if (mt1 && (kind == 2 || kind == 4) && H == 512 && (H / 16) * ((N + 31) / 32) * 2 <= cus && n_rb16 <= 8 &&
-        (H / 16) * n_rb16 <= cus)
+    if ((kind == 2 ? (mt1 & 1) : (mt1 & 2)) && (kind == 2 || kind == 4) && H == 512 &&
+        (H / 16) * ((N + 31) / 32) * 2 <= cus && n_rb16 <= 8 && (H / 16) * n_rb16 <= cus)
       mt = 1;
   }
   PersArgs a{};

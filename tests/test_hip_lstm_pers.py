@@ -204,16 +204,18 @@ def _x3_pass(env, H, T, N, pers, seed=0):
 def test_fp32x3_handoffs_under_uneven_load(env, H, T, N):
     """The default-arithmetic recurrences — at H = 1024 the k-split backward kernel with TWO hand-offs per frame (dG fragments,
     then the partial dh tiles between the four k-quarter workgroups of a block), at H = 512 the 16-row tiles — while a second
-    stream streams 0 .. 4 GiB through HBM: every output word against the per-frame kernels, every round; then twice more
-    bit-for-bit against the first persistent run (the partial tiles are summed in a fixed order: no run-to-run noise)."""
+    stream streams 0 .. 4 GiB through HBM: every output word against the per-frame kernels, every round, and bit-for-bit
+    against the first persistent run (the partial tiles are summed in a fixed order: no run-to-run noise).
+    (scripts/x3_handoff_stress.py is the long form: hundreds of rounds, and it says which frame / rows went wrong.  It is what
+    showed the 16-row FORWARD form failing 5-17 % of its rounds — that form is not in the product library.)"""
     ref = _x3_pass(env, H, T, N, pers=False)
     side = torch.cuda.Stream()
     a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
     b = torch.empty_like(a)
     first = None
-    for rnd in range(5):
+    for rnd in range(15):
         with torch.cuda.stream(side):
-            for _ in range(rnd):
+            for _ in range(rnd % 5):
                 b.copy_(a)
         got = _x3_pass(env, H, T, N, pers=True)
         for name, x, y in zip(("gates", "c", "h", "dgates"), got, ref):
