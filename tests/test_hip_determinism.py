@@ -98,6 +98,38 @@ def test_gradients_are_bitwise_reproducible_at_the_benchmark_shape(det):
     assert torch.equal(g0, w.optimizer.flat_g), float((g0 - w.optimizer.flat_g).abs().max())
 
 
+def test_step_does_not_depend_on_foreign_hbm_traffic(det):
+    """configs[1] (B = 64, T = 128), graph replay, 12 training steps with inputs cycled: alone, and again while a second stream
+    streams GiBs through HBM (what an overlapped RCCL all-reduce does to the memory system; the persistent recurrences'
+    hand-offs are the part that could care).  Losses of every step, parameters and moments: bit for bit.
+    scripts/step_stress.py is the long form."""
+    B, T, steps = 64, 128, 12
+    data = [tuple(t.cuda() for t in synthetic_pair(B, T, 300 + i)) for i in range(3)]
+    noise = [synthetic_eps(B, seed=310 + i) for i in range(3)]
+
+    def run(load):
+        w = make(B, T)
+        w.enable_graph(True)
+        side = torch.cuda.Stream()
+        a = torch.empty(1 << 27, device="cuda", dtype=torch.float32)
+        b = torch.empty_like(a)
+        out = []
+        for i in range(steps):
+            if load:
+                with torch.cuda.stream(side):
+                    for _ in range(1 + i % 3):
+                        b.copy_(a)
+            x1, x2 = data[i % 3]
+            w.model.eps_override = noise[(2 * i) % 3]
+            out.append(w.step(x1, x2, None, train=True))
+        torch.cuda.synchronize()
+        return out, w.optimizer.flat_p.clone(), w.optimizer.exp_avg_sq.clone()
+
+    ref, got = run(False), run(True)
+    assert ref[0] == got[0]
+    assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
