@@ -36,10 +36,12 @@ Rank 0 prints ONE JSON line.  Extra objects:
   cpu_baseline the CPU oracle (oracle/dvae_ref.py, the verified restatement of the reference's PyTorch-CPU step)
                timed on this box's host cores on the same workload, rank 0, N=1 only: once with 64 threads and once
                with all physical cores; `value` is the FASTER of the two, both samples listed.
-  N > 1        the EAGER data-parallel step is timed first (ms_per_step_eager); then the step with the RCCL
-               all-reduces captured inside the hipGraph is attempted in the same process (ms_per_step_graph, or
-               graph_error); the headline is the best one that completed.  Diagnostics: rccl_ranks, visible devices,
-               per-rank ms, buckets, allreduce_exposed_ms (step minus the same step with the reducer detached).
+  N > 1        the EAGER data-parallel step, timed once per exchange variant — bucketed all-reduce or reduce-scatter +
+               sharded Adam + all-gather, collectives issued from the backward hooks or after backward — each over exactly
+               --steps steps (ddp_variants_ms_per_step); the headline is the fastest (no multi-GPU box has been available to
+               choose in advance).  The step with the collectives captured inside the hipGraph is attempted only with
+               DVAE_BENCH_DDP_GRAPH=1.  Diagnostics: rccl_ranks, visible devices, per-rank ms, buckets,
+               allreduce_exposed_ms (step minus the same step with the reducer detached).
   other_configs  (N=1 only) BASELINE configs[2] (bf16, B=128, T=256) and the per-GPU shape of configs[4] (bf16, B=64,
                T=512), each timed here over a few graph-replayed steps, with its step-level fraction of the bf16 peak.
 """
@@ -513,7 +515,37 @@ def main():
                                   "launched_from_backward_hooks": red.stats["hook"], "left_for_finish": red.stats["finish"],
                                   "steps": red.stats["steps"]}})
         log(f"rank {rank}: eager data-parallel step {ms_eager:.2f} ms")
-        elapsed, launch = el_e, "eager (bucketed RCCL all-reduce launched from backward hooks)"
+        elapsed, launch = el_e, f"eager ({red.mode}, collectives issued from {red.issue})"
+        # No multi-GPU box has ever been available to choose between the exchange variants, so the first one that is measures
+        # them all: bucketed all-reduce or reduce-scatter + sharded Adam + all-gather, each with its collectives issued from the
+        # backward hooks (overlap) or after backward (nothing beside the W_hh-resident recurrences).  Every variant computes
+        # the same update, so the replicas stay in step; each is timed over EXACTLY --steps steps like the first; the headline
+        # is the fastest, all are listed.  DVAE_BENCH_DDP_VARIANTS="" keeps only the configured one.
+        variants = {f"{red.mode}:{red.issue}": ms_eager}
+        want = os.environ.get("DVAE_BENCH_DDP_VARIANTS", "all_reduce:hook,all_reduce:finish,rs_ag:hook,rs_ag:finish")
+        from dvae_amd import ddp as _ddp
+        for v in [x for x in want.split(",") if x and x not in variants]:
+            try:
+                mode_v, issue_v = v.split(":")
+                r2 = red if mode_v == red.mode else _ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params,
+                                                                       w.optimizer.offsets, mode=mode_v, issue=issue_v)
+                r2.issue, r2.force = issue_v, red.force
+                w.attach_reducer(r2)
+                for _ in range(2):
+                    w.step_async(x1, x2, spk)
+                el_v, last_v, _ = timed(args.steps)
+                variants[v] = 1e3 * el_v / args.steps
+                log(f"rank {rank}: {v}: {variants[v]:.2f} ms")
+                if el_v < elapsed:
+                    elapsed, last, launch = el_v, tuple(last_v.tolist()), f"eager ({mode_v}, collectives issued from {issue_v})"
+                    extra["ddp_mode"], extra["ddp_issue"] = mode_v, issue_v
+            except Exception as e:      # a variant that fails must not cost the line
+                variants[v] = "failed: " + repr(e)[:160]
+        extra["ddp_variants_ms_per_step"] = variants
+        red.issue = os.environ.get("DVAE_DDP_ISSUE", "hook")
+        w.attach_reducer(red)
+        if red.mode != "rs_ag":
+            w.optimizer.fold_zero_grad = True
         # graph attempt, guarded three ways: try/except around the capture, agreement of all ranks, and a watchdog that
         # prints the eager-only line and ends the process if the attempt hangs
         # OPT-IN (DVAE_BENCH_DDP_GRAPH=1): no multi-rank run has shown the captured step equal to the eager one, so it is
