@@ -80,6 +80,7 @@ struct GemmParams {
   // on A + a_boff[b] ... (byte offsets) — several small under-filled launches become one that fills the chip
   int batch;
   int64_t a_boff[4], b_boff[4], c_boff[4];
+  int c_vec;             // 128 x 128 kernel: C rows can be stored / accumulated 16 bytes at a time (N, ldc multiples of 4, aligned)
 };
 
 // BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
@@ -558,6 +559,40 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
       const float bias_v = add_bias ? p.bias[col] : 0.f;
       const int row0 = m0 + wm * 64 + mt * 32 + 4 * kh;
       float* cbase = C + (int64_t)row0 * p.ldc + col;
+      if constexpr (!BNS) {
+        if (p.c_vec && epi != DVAE_EPI_ATOMIC) {
+          // 16-byte stores (as in the 256 x 128 kernels): the accumulator holds 4 consecutive ROWS of one column per lane; a
+          // 4 x 4 transpose inside each quad of lanes (two DPP butterfly stages) turns them into 4 consecutive COLUMNS of one
+          // row.  64 single-dword stores per lane made the short-K launches (K = 128 projections and outer products: 8
+          // k-steps in front of a 64 KB tile) store-issue-bound.  Same values, wider stores: results are bit-identical.
+          const int q4 = lane & 3;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float x[4], y[4], z[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = act_apply(acc[mt][nt][4 * g + e] + bias_v, act);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
+              y[e] = ((q4 ^ e) & 1) ? o : x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
+              z[e] = ((q4 ^ e) & 2) ? o : y[e];
+            }
+            // this lane now holds row (8 g + 4 kh + q4) of the tile, columns 4 (l31 >> 2) .. + 3
+            const int row = row0 + 8 * g + q4;
+            if (row < p.M) {
+              f32x4* dst = reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4));
+              f32x4 o4 = {z[0], z[1], z[2], z[3]};
+              if (epi == DVAE_EPI_ACCUM) o4 += *dst;
+              *dst = o4;
+            }
+          }
+          continue;
+        }
+      }
       if (epi == DVAE_EPI_STORE && p.c16) {       // bf16 output (bf16 mode: the consumer is another contraction)
         __bf16* cb = (__bf16*)pC + (int64_t)row0 * p.ldc + col;
 #pragma unroll
@@ -1562,6 +1597,9 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     p.map_nstr = tiles_n / gn;
   }
   const int nb = p.batch > 1 ? p.batch : 1;
+  p.c_vec = (!p.c16 && (p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.c_tap_stride % 4 == 0)) ? 1 : 0;
+  if (p.batch > 1)
+    for (int b = 0; b < p.batch; ++b) p.c_vec &= ((p.c_boff[b] & 15) == 0) ? 1 : 0;
   dim3 grid(p.tiles_m * tiles_n, 1, zdim * nb);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
   const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
