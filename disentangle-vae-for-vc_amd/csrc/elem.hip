@@ -742,7 +742,10 @@ DVAE_API int dvae_adam_flat_dev(float* p, float* g, float* m, float* v, int64_t 
   }
   hipStream_t s = (hipStream_t)stream;
   if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, state, beta1, beta2, skip_if_nonzero);
-  constexpr int U = 2;
+#ifndef DVAE_ADAM_U
+#define DVAE_ADAM_U 2
+#endif
+  constexpr int U = DVAE_ADAM_U;
   const int64_t n4 = n >> 2;
   hipLaunchKernelGGL(adam_dev_kernel<U>, dim3(nblk((n4 + U - 1) / U, 256, 2048)), dim3(256), 0, s, p, g, m, v, n4, beta1,
                      beta2, eps, state, skip_if_nonzero, c);
