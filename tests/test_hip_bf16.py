@@ -316,26 +316,50 @@ def test_model_bf16_stage_by_stage(ops):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("det", [True, False])
 @pytest.mark.parametrize("B,T", [(2, 64), (2, 256)])
-def test_model_bf16_losses_and_gradients(ops, B, T):
+def test_model_bf16_losses_and_gradients(ops, B, T, det):
     """BASELINE configs[2] semantics at test size (T = 256 is configs[2]'s frame count).  End to end the comparison is
     statistical (see test_model_bf16_stage_by_stage): the 8 loss scalars — sums over 1e4..1e5 elements — agree with the
     bf16 oracle to 2e-3 relative; every gradient tensor is no further from the bf16 oracle than bf16 rounding itself
-    moves the oracle (distance bf16 oracle <-> fp32 oracle), and points the same way (cosine >= 0.9)."""
-    from oracle.bf16_ref import RefDVAEBf16
-    from oracle.dvae_ref import RefDVAE, loss_gvae2
-    from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
-    x1, x2 = synthetic_pair(B, T, 21)
-    eps = synthetic_eps(B, seed=22)
-    ref, grads = {}, {}
-    for name, cls in (("bf16", RefDVAEBf16), ("fp32", RefDVAE)):
-        m = cls(4, 32, T)
-        m.load_state_dict(fill_state_dict(m.state_dict()))
-        m.train()
-        losses = loss_gvae2(x1, x2, m(x1, x2, eps), B)
-        losses[0].backward()
-        grads[name] = {k: p.grad for k, p in m.named_parameters()}
-        ref[name] = [float(l.detach()) for l in losses]
+    moves the oracle (distance bf16 oracle <-> fp32 oracle), and points the same way (cosine >= 0.9).
+    det: in the deterministic test mode the step is ONE fixed realisation of the roundings (bit-identical run to run), held
+    to the tight limits; with the atomics' run-to-run summation order the ratios scatter (T = 256, 6 runs: 2.20-2.47 for
+    the 8-element style bias, 1.53-1.61 for the rest) and the limits leave room for that scatter."""
+    ops.set_deterministic(det)
+    try:
+        _bf16_losses_and_gradients(ops, B, T, det)
+    finally:
+        ops.set_deterministic(False)
+
+
+_ORACLE_CACHE = {}
+
+
+def _bf16_oracle_step(B, T):
+    """losses and gradients of the bf16 and the fp32 oracle on the test's inputs (once per shape: both `det` cases)"""
+    if (B, T) not in _ORACLE_CACHE:
+        from oracle.bf16_ref import RefDVAEBf16
+        from oracle.dvae_ref import RefDVAE, loss_gvae2
+        from oracle.fill import fill_state_dict, synthetic_eps, synthetic_pair
+        x1, x2 = synthetic_pair(B, T, 21)
+        eps = synthetic_eps(B, seed=22)
+        ref, grads = {}, {}
+        for name, cls in (("bf16", RefDVAEBf16), ("fp32", RefDVAE)):
+            m = cls(4, 32, T)
+            m.load_state_dict(fill_state_dict(m.state_dict()))
+            m.train()
+            losses = loss_gvae2(x1, x2, m(x1, x2, eps), B)
+            losses[0].backward()
+            grads[name] = {k: p.grad for k, p in m.named_parameters()}
+            ref[name] = [float(l.detach()) for l in losses]
+        _ORACLE_CACHE.clear()            # (one shape at a time: the T = 256 gradients are ~1.3 GB)
+        _ORACLE_CACHE[(B, T)] = (x1, x2, eps, ref, grads)
+    return _ORACLE_CACHE[(B, T)]
+
+
+def _bf16_losses_and_gradients(ops, B, T, det):
+    x1, x2, eps, ref, grads = _bf16_oracle_step(B, T)
     w = _make(B, T)
     w.model.eps_override = eps
     w.optimizer.zero_grad()
@@ -356,7 +380,7 @@ def test_model_bf16_losses_and_gradients(ops, B, T):
         # measured (6 runs, scripts history) 1.16-1.37 for most tensors, 1.59-1.61 for the first encoder layer's reverse
         # biases, 1.70-1.76 / 2.18-2.26 for the style head's weight / bias — the smallest gradient at the end of the
         # longest chain — since the H = 64 encoder recurrence runs on rounded operands too
-        lim = 2.4 if k.startswith("style.") else 1.75
+        lim = (2.4 if det else 3.2) if k.startswith("style.") else (1.75 if det else 2.0)
         assert _dist(gh, g16) <= max(3e-2, lim * noise), (k, _dist(gh, g16), noise)
         cos = float((gh.double() * g16.double()).sum() / (gh.double().norm() * g16.double().norm()))
         assert cos >= 0.9, (k, cos)
