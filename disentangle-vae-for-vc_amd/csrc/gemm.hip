@@ -37,12 +37,14 @@
 int g_dvae_compute_mode = 0;   // process default of the contraction mode (DVAE_MODE_*, dvae_set_compute_mode)
 int g_dvae_deterministic = 0;  // dvae_set_deterministic: every accumulated output element gets ONE writer in a fixed order
 
-#ifdef DVAE_GEMM_TS
+#if defined(DVAE_GEMM_TS) || defined(DVAE_GEMM_TS2)
 // Development probe (build with -DDVAE_GEMM_TS): wave 0 of every workgroup measures the s_memtime cycles of its whole
 // k-loop (two stamps only: stamps inside the loop serialise it and change what they measure).
 __device__ unsigned long long g_gemm_ts[1024 * 8];
 #define TS_NOW() __builtin_amdgcn_s_memtime()
 #endif
+// -DDVAE_GEMM_TS2: the ENDS of the tall kernel — four s_memrealtime stamps (100 MHz, one clock for the whole chip) per
+// wave: kernel entry, k loop entered, k loop left, epilogue stores drained (scripts/gemm_ends.py); nothing inside the loop
 
 __device__ __attribute__((aligned(16))) float g_gemm_zero[4] = {0.f, 0.f, 0.f, 0.f};   // what masked lanes load
 
@@ -711,6 +713,9 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, kh = lane >> 5;
+#ifdef DVAE_GEMM_TS2
+  const unsigned long long t2_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   int tile_m, tile_n;
   gemm_tile_of(p, tile_m, tile_n);
@@ -954,6 +959,9 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
     tap_n = wrap ? 0 : tap_n + 1;
     kit_n += wrap ? 1 : 0;
   };
+#ifdef DVAE_GEMM_TS2
+  const unsigned long long t2_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int it0 = 0; it0 < n_iters; it0 += 2) {
     next_tile_offsets();
     all_steps(std::integral_constant<int, 0>{});
@@ -964,6 +972,9 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
     __syncthreads();
     TALL_LAP(ts_bar);
   }
+#ifdef DVAE_GEMM_TS2
+  const unsigned long long t2_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef DVAE_GEMM_TS
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && blockIdx.z == 0) {
     unsigned long long* o = g_gemm_ts + (blockIdx.x * 4 + wave) * 8;
@@ -1108,6 +1119,17 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   else if (p.act == DVAE_ACT_NONE) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
   else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
   else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_TANH>{});
+#ifdef DVAE_GEMM_TS2
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store / atomic of this wave acknowledged
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && blockIdx.z == 0) {
+    unsigned long long* o = g_gemm_ts + (blockIdx.x * 4 + wave) * 8;
+    o[0] = t2_entry; o[1] = t2_loop0; o[2] = t2_loop1; o[3] = __builtin_amdgcn_s_memrealtime();
+    o[4] = (unsigned long long)n_iters;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[5] = xcc & 0xf;
+  }
+#endif
 }
 
 
@@ -1648,7 +1670,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
 
 }  // namespace
 
-#ifdef DVAE_GEMM_TS
+#if defined(DVAE_GEMM_TS) || defined(DVAE_GEMM_TS2)
 DVAE_API int dvae_probe_gemm_timeline(unsigned long long* host_out, int n_words) {
   if (hipDeviceSynchronize() != hipSuccess) return DVAE_ELAUNCH;
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_gemm_ts), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : DVAE_ELAUNCH;
