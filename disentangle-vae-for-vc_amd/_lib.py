@@ -52,7 +52,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 303     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 304     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
@@ -71,6 +71,7 @@ SIGNATURES = {
     "dvae_bn_stats_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, vp]),
     "dvae_bn_apply_fwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_bn_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "dvae_bn_bwd_from_y": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_lstm_pack_w": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_bf16": (i32, [vp, vp, vp, i32, vp]),
     "dvae_lstm_pack_w_x3": (i32, [vp, vp, vp, i32, vp]),

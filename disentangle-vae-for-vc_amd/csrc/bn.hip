@@ -18,11 +18,15 @@ __host__ __device__ inline int n_chunks(int R) { return (R + ROWS_PER_CHUNK - 1)
 // partial[chunk][g][c][2] (fp64): sum and sum of squares (MODE 0), or sum(dU) and sum(dU*yhat) (MODE 1)
 // 64 channel-quads x 4 row lanes per workgroup, 16-byte loads; fp64 accumulation per thread.
 // ZB16: Z (the block's output, needed for the activation derivative) is stored as bf16 (bf16 compute mode)
-template <int MODE, bool ZB16 = false>
+// ZRE (MODE 1, ReLU / no activation): Z is not read — the activation's derivative is recomputed from Y with the forward
+// pass's own expression (bn_apply_kernel), 8 instead of 12 bytes per element
+template <int MODE, bool ZB16 = false, bool ZRE = false>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ Y, const float* __restrict__ dZ,
                                                          const void* __restrict__ Z, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, double* __restrict__ part,
-                                                         int R, int N, int C, int G, int act) {
+                                                         int R, int N, int C, int G, int act,
+                                                         const float* __restrict__ gamma = nullptr,
+                                                         const float* __restrict__ beta = nullptr) {
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = (blockIdx.x * 64 + cl) * 4;       // C % 4 == 0
   const int r0 = blockIdx.y * ROWS_PER_CHUNK;
@@ -45,13 +49,18 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
         rs1 = *reinterpret_cast<const f32x4*>(rstd + C + c);
       }
     }
+    f32x4 ga = rs0, be = mu0;
+    if constexpr (ZRE) {
+      ga = *reinterpret_cast<const f32x4*>(gamma + c);
+      be = *reinterpret_cast<const f32x4*>(beta + c);
+    }
     for (int r = r0 + rl; r < r1; r += 4) {
       const bool g1 = ((r % N) / per) != 0;
       const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (int64_t)r * C + c);
       f32x4 dz = y, z = y;
       if (MODE == 1) {
         dz = *reinterpret_cast<const f32x4*>(dZ + (int64_t)r * C + c);
-        z = ld4<ZB16>(Z, ((int64_t)r * C + c) >> 2);
+        if constexpr (!ZRE) z = ld4<ZB16>(Z, ((int64_t)r * C + c) >> 2);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -60,8 +69,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
           v0 = (double)y[k];
           v1 = (double)y[k] * (double)y[k];
         } else {
-          const float du = dz[k] * act_grad_from_out(z[k], act);
           const float yh = (y[k] - (g1 ? mu1[k] : mu0[k])) * (g1 ? rs1[k] : rs0[k]);
+          const float du = dz[k] * act_grad_from_out(ZRE ? act_apply(yh * ga[k] + be[k], act) : z[k], act);
           v0 = (double)du;
           v1 = (double)du * (double)yh;
         }
@@ -229,13 +238,14 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __re
   if (dbeta) dbeta[c] += (float)tb;
 }
 
-template <bool ZB16, bool DYB16>
+template <bool ZB16, bool DYB16, bool ZRE = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dZ, const float* __restrict__ Y,
                                                            const void* __restrict__ Z, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ s12, void* dY,
-                                                           int64_t total4, int R, int N, int C, int G, int act) {
+                                                           int64_t total4, int R, int N, int C, int G, int act,
+                                                           const float* __restrict__ beta = nullptr) {
   const int c4n = C >> 2;
   const int per = N / G;
   const float inv_cnt = 1.f / ((float)(R / N) * (float)per);
@@ -245,15 +255,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dZ, cons
     const int g = (int)(r % N) / per;
     const f32x4 dz = *reinterpret_cast<const f32x4*>(dZ + i * 4);
     const f32x4 y = *reinterpret_cast<const f32x4*>(Y + i * 4);
-    const f32x4 z = ld4<ZB16>(Z, i);
+    f32x4 z = y, be = y;
+    if constexpr (ZRE) be = *reinterpret_cast<const f32x4*>(beta + c);
+    else z = ld4<ZB16>(Z, i);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + g * C + c);
     const f32x4 rs = *reinterpret_cast<const f32x4*>(rstd + g * C + c);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float du = dz[k] * act_grad_from_out(z[k], act);
       const float yh = (y[k] - mu[k]) * rs[k];
+      const float du = dz[k] * act_grad_from_out(ZRE ? act_apply(yh * ga[k] + be[k], act) : z[k], act);
       const float s1 = s12[(g * C + c + k) * 2], s2 = s12[(g * C + c + k) * 2 + 1];
       o[k] = ga[k] * rs[k] * (du - s1 * inv_cnt - yh * s2 * inv_cnt);
     }
@@ -314,24 +326,45 @@ DVAE_API int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* r
   return dvae_check_launch();
 }
 
-DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const void* Z, const float* mean, const float* rstd,
-                         const float* gamma, void* dY, float* dgamma, float* dbeta, void* ws, int R, int N, int C,
-                         int G, int act, int dtypes, void* stream) {
-  const bool zb = dtypes & 1, dyb = dtypes & 2;
-  if (check(R, N, C, G) || !dZ || !Y || !Z || !mean || !rstd || !gamma || !dY || !ws) return DVAE_EINVAL;
+namespace {
+int bn_bwd_launch(const float* dZ, const float* Y, const void* Z, const float* mean, const float* rstd,
+                  const float* gamma, const float* beta, void* dY, float* dgamma, float* dbeta, void* ws, int R, int N,
+                  int C, int G, int act, int dtypes, void* stream) {
+  const bool zb = dtypes & 1, dyb = dtypes & 2, zre = (Z == nullptr);
+  if (check(R, N, C, G) || !dZ || !Y || !mean || !rstd || !gamma || !dY || !ws) return DVAE_EINVAL;
+  // without Z the activation's derivative is recomputed from Y: ReLU (a compare) or none — not tanh (a libm call per
+  // element costs these HBM-bound passes more than the 4 bytes it saves)
+  if (zre && (!beta || (act != DVAE_ACT_RELU && act != DVAE_ACT_NONE))) return DVAE_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ch = n_chunks(R);
   double* part = (double*)ws;
   float* s12 = (float*)((char*)ws + (int64_t)ch * G * C * 2 * sizeof(double));
   dim3 grid((C + 255) / 256, ch);
-  if (zb) hipLaunchKernelGGL((bn_partial_kernel<1, true>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
+  if (zre) hipLaunchKernelGGL((bn_partial_kernel<1, false, true>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act, gamma, beta);
+  else if (zb) hipLaunchKernelGGL((bn_partial_kernel<1, true>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
   else hipLaunchKernelGGL((bn_partial_kernel<1, false>), grid, dim3(256), 0, s, Y, dZ, Z, mean, rstd, part, R, N, C, G, act);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, s, part, s12, dgamma, dbeta, ch, C,
                      G);
   const int64_t total4 = (int64_t)R * C / 4;
   const int blocks = (int)((total4 + 255) / 256 < 2048 ? (total4 + 255) / 256 : 2048);
-#define BWDA(ZB_, DYB_) hipLaunchKernelGGL((bn_bwd_apply_kernel<ZB_, DYB_>), dim3(blocks), dim3(256), 0, s, dZ, Y, Z, mean, rstd, gamma, s12, dY, total4, R, N, C, G, act)
-  if (zb && dyb) BWDA(true, true); else if (zb) BWDA(true, false); else if (dyb) BWDA(false, true); else BWDA(false, false);
+#define BWDA(ZB_, DYB_, ZRE_) hipLaunchKernelGGL((bn_bwd_apply_kernel<ZB_, DYB_, ZRE_>), dim3(blocks), dim3(256), 0, s, dZ, Y, Z, mean, rstd, gamma, s12, dY, total4, R, N, C, G, act, beta)
+  if (zre) { if (dyb) BWDA(false, true, true); else BWDA(false, false, true); }
+  else if (zb && dyb) BWDA(true, true, false); else if (zb) BWDA(true, false, false);
+  else if (dyb) BWDA(false, true, false); else BWDA(false, false, false);
 #undef BWDA
   return dvae_check_launch();
+}
+}  // namespace
+
+DVAE_API int dvae_bn_bwd(const float* dZ, const float* Y, const void* Z, const float* mean, const float* rstd,
+                         const float* gamma, void* dY, float* dgamma, float* dbeta, void* ws, int R, int N, int C,
+                         int G, int act, int dtypes, void* stream) {
+  if (!Z) return DVAE_EINVAL;
+  return bn_bwd_launch(dZ, Y, Z, mean, rstd, gamma, nullptr, dY, dgamma, dbeta, ws, R, N, C, G, act, dtypes, stream);
+}
+DVAE_API int dvae_bn_bwd_from_y(const float* dZ, const float* Y, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, void* dY, float* dgamma, float* dbeta, void* ws,
+                                int R, int N, int C, int G, int act, int dtypes, void* stream) {
+  if (!beta) return DVAE_EINVAL;
+  return bn_bwd_launch(dZ, Y, nullptr, mean, rstd, gamma, beta, dY, dgamma, dbeta, ws, R, N, C, G, act, dtypes, stream);
 }

@@ -516,9 +516,15 @@ class ConvBnActFn(torch.autograd.Function):
             raise RuntimeError("residual is only supported with ACT_NONE")
         ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
         dy = torch.empty((R, Cout), device=dev, dtype=act_storage(mode))     # operand of the data / weight gradient
-        check(L.dvae_bn_bwd(ptr(dz), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(bn_w), ptr(dy),
-                            ptr(_grad_buf(bn_w)), ptr(_grad_buf(bn_b)), ptr(ws), R, n_seg, Cout, G, act,
-                            _b16(z) | (_b16(dy) << 1), st), "dvae_bn_bwd")
+        if act in (ACT_RELU, ACT_NONE):
+            # the mask of a ReLU block is recomputed from Y: the pass does not read Z
+            check(L.dvae_bn_bwd_from_y(ptr(dz), ptr(y), ptr(mean), ptr(rstd), ptr(bn_w), ptr(bn_b), ptr(dy),
+                                       ptr(_grad_buf(bn_w)), ptr(_grad_buf(bn_b)), ptr(ws), R, n_seg, Cout, G, act,
+                                       _b16(dy) << 1, st), "dvae_bn_bwd_from_y")
+        else:
+            check(L.dvae_bn_bwd(ptr(dz), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(bn_w), ptr(dy),
+                                ptr(_grad_buf(bn_w)), ptr(_grad_buf(bn_b)), ptr(ws), R, n_seg, Cout, G, act,
+                                _b16(z) | (_b16(dy) << 1), st), "dvae_bn_bwd")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, Cin), device=dev, dtype=torch.float32)

@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 303
+#define DVAE_ABI_VERSION 304
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -156,6 +156,12 @@ int dvae_bn_apply_fwd(const float* Y, const float* mean, const float* rstd, cons
 int dvae_bn_bwd(const float* dZ, const float* Y, const void* Z, const float* mean, const float* rstd,
                 const float* gamma, void* dY, float* dgamma, float* dbeta, void* ws,
                 int R, int N, int C, int G, int act, int dtypes, void* stream);
+/* the same without reading Z, for act = ReLU or none: the activation's derivative is recomputed from Y with the forward
+ * pass's expression (act((Y-mean)*rstd*gamma + beta) > 0) — 20 instead of 28 bytes per element over the two passes.
+ * (tanh blocks keep dvae_bn_bwd: recomputing tanh costs these HBM-bound passes more than the bytes it saves.) */
+int dvae_bn_bwd_from_y(const float* dZ, const float* Y, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, void* dY, float* dgamma, float* dbeta, void* ws,
+                       int R, int N, int C, int G, int act, int dtypes, void* stream);
 
 /* ---- LSTM recurrence, frame-major, one launch per frame (nn.LSTM at disentangled_vae.py:163,172,193) ----
  * One dvae_lstm_dir_t per direction (1 or 2).  Gate order i,f,g,o (torch).

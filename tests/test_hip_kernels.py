@@ -245,6 +245,42 @@ def test_bn_residual(ops):
     close(from_frames(xf.grad.cpu(), N, T), ref_in.grad, rel=5e-4, name="residual_dx")
 
 
+@pytest.mark.parametrize("act,G,dy16", [(1, 2, False), (0, 1, False), (1, 2, True)])
+def test_bn_bwd_from_y_equals_bn_bwd(ops, act, G, dy16):
+    """dvae_bn_bwd_from_y (ReLU mask recomputed from Y, Z never read) against dvae_bn_bwd fed the Z of dvae_bn_apply_fwd:
+    the same dY, dgamma, dbeta bit for bit (the mask is the sign of the forward pass's own expression); tanh is refused."""
+    from dvae_amd._lib import check, lib, ptr, stream
+    L = lib()
+    R, N, C = 64 * 24, 24, 512
+    y = dev(rnd(R, C, seed=1) * 2.0)
+    dz = dev(rnd(R, C, seed=2))
+    ga, be = dev(rnd(C, seed=3, lo=0.5, hi=1.5)), dev(rnd(C, seed=4) * 0.3)
+    mean, rstd = torch.empty(G, C, device="cuda"), torch.empty(G, C, device="cuda")
+    ws = torch.empty(L.dvae_bn_ws_bytes(R, C, G), dtype=torch.uint8, device="cuda")
+    check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), None, None, None, ptr(ws), R, N, C, G, 1e-5, 0.1, stream()), "stats")
+    z = torch.empty(R, C, device="cuda")
+    check(L.dvae_bn_apply_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(ga), ptr(be), None, ptr(z), R, N, C, G, act, 0, stream()), "apply")
+    if act == 1:
+        assert 0.2 < float((z > 0).float().mean()) < 0.8      # the mask matters
+    dt = torch.bfloat16 if dy16 else torch.float32
+    out = []
+    for from_y in (False, True):
+        dy = torch.empty(R, C, device="cuda", dtype=dt)
+        dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        if from_y:
+            check(L.dvae_bn_bwd_from_y(ptr(dz), ptr(y), ptr(mean), ptr(rstd), ptr(ga), ptr(be), ptr(dy), ptr(dg), ptr(db),
+                                       ptr(ws), R, N, C, G, act, 2 if dy16 else 0, stream()), "from_y")
+        else:
+            check(L.dvae_bn_bwd(ptr(dz), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(ga), ptr(dy), ptr(dg), ptr(db),
+                                ptr(ws), R, N, C, G, act, 2 if dy16 else 0, stream()), "bwd")
+        out.append((dy.float().cpu(), dg.cpu(), db.cpu()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    dy = torch.empty(R, C, device="cuda")
+    assert L.dvae_bn_bwd_from_y(ptr(dz), ptr(y), ptr(mean), ptr(rstd), ptr(ga), ptr(be), ptr(dy), None, None, ptr(ws),
+                                R, N, C, G, 2, 0, stream()) != 0
+
+
 # ------------------------------------------------------------------ LSTM
 # (128, 4, ., 1024) / (128, 4, ., 512): N >= 97 selects the 32-row eight-wave tiles the benchmark runs (lstm.hip
 # plan_seq: n_j * ceil(N/32) >= 256); H = 128 / 256 reach the generic LDS-staged frame kernels
