@@ -27,7 +27,7 @@ class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
                 ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_mode", i32),
-                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint), ("dbias_ih", vp), ("dbias_hh", vp)]
+                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint), ("dbias_ih", vp), ("dbias_hh", vp), ("gate_ld", i64)]
 
 
 class RepackDesc(C.Structure):
@@ -44,7 +44,7 @@ class LossDesc(C.Structure):
                 ("mse_cof", f32), ("kl_cof", f32)]
 
 
-REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2, REPACK_CAST_BF16 = 0, 1, 2, 3, 4
+REPACK_CONV_T, REPACK_LSTM_PACK, REPACK_TRANSPOSE, REPACK_ADD2, REPACK_CAST_BF16, REPACK_COPY_F32 = 0, 1, 2, 3, 4, 5
 
 # DVAE_MODE_* of include/dvae_hip.h
 MODE_F32, MODE_BF16, MODE_F32X3 = 0, 1, 2
@@ -52,7 +52,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 304     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 305     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {

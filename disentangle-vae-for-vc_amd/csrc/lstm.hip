@@ -64,6 +64,7 @@ struct StepArgs {
   int64_t ldh;
   int st16;  // bf16 mode: h_out (forward) / dgates (backward) are stored as bf16
   int pm;    // precision mode of the packed weights: 0 fp32 fragments, 1 bf16 (dvae_lstm_pack_w_bf16), 2 three bf16 planes (.._x3)
+  int64_t ldg;   // row stride of gates / dgates (4H unless the H = 64 directions share one [T*N, 8H] tensor)
 };
 
 constexpr int KC = 64;   // k-chunk
@@ -850,15 +851,15 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_fwd_h64(const StepAr
   for (int e = 0; e < NE; ++e) nrow[e] = min(m0 + erow[e], N - 1);
   auto fetch = [&](int step_, float (&x)[NE][4]) {
     const int t_ = d.reverse ? (T - 1 - step_) : step_;
-    const float* __restrict__ G_ = d.gates + (int64_t)t_ * N * 4 * H;
+    const float* __restrict__ G_ = d.gates + (int64_t)t_ * N * a.ldg;
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) x[e][g] = G_[(int64_t)nrow[e] * 4 * H + g * H + ej[e]];
+      for (int g = 0; g < 4; ++g) x[e][g] = G_[(int64_t)nrow[e] * a.ldg + g * H + ej[e]];
   };
   auto frame = [&](int step, float (&xp)[NE][4], float (&xn)[NE][4]) {
     const int t = d.reverse ? (T - 1 - step) : step;
-    float* __restrict__ G = d.gates + (int64_t)t * N * 4 * H;
+    float* __restrict__ G = d.gates + (int64_t)t * N * a.ldg;
     fetch(min(step + 1, T - 1), xn);
 
     f32x4 acc[NT];
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_fwd_h64(const StepAr
       }
       if (eok[e]) {
         const int64_t n = m0 + row;
-        float* g = G + n * 4 * H + j;
+        float* g = G + n * a.ldg + j;
         g[0] = gi;
         g[H] = gf;
         g[2 * H] = gg;
@@ -1022,7 +1023,7 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_bwd_h64(const StepAr
       const int64_t n = nrow[e];
       const int j = ej[e];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) o.gt[e][g] = d.gates[((int64_t)t_ * N + n) * 4 * H + g * H + j];
+      for (int g = 0; g < 4; ++g) o.gt[e][g] = d.gates[((int64_t)t_ * N + n) * a.ldg + g * H + j];
       o.cc[e] = d.c_all[((int64_t)t_ * N + n) * H + j];
       const float cpv = d.c_all[((int64_t)tp_ * N + n) * H + j];
       o.cp[e] = fs > 0 ? cpv : 0.f;
@@ -1095,7 +1096,7 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_bwd_h64(const StepAr
         dgs[row][3 * H + j] = eok[e] ? o3 : 0.f;
       }
       if (eok[e]) {
-        float* o = d.dgates + ((int64_t)t * N + m0 + row) * 4 * H + j;
+        float* o = d.dgates + ((int64_t)t * N + m0 + row) * a.ldg + j;
         o[0] = o0;
         o[H] = o1;
         o[2 * H] = o2;
@@ -1138,6 +1139,11 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
     if ((dirs[i].state_bf16 ? 1 : 0) != a.st16) return DVAE_EINVAL;
   if (a.st16 && a.pm != DVAE_MODE_BF16) return DVAE_EINVAL;
   a.T = T; a.N = N; a.H = H; a.ldh = ldh;
+  a.ldg = dirs[0].gate_ld ? dirs[0].gate_ld : 4 * H;
+  for (int i = 0; i < ndir; ++i)
+    if ((dirs[i].gate_ld ? dirs[i].gate_ld : 4 * H) != a.ldg) return DVAE_EINVAL;
+  // (only the whole-sequence kernels of H = 64 take a stride; 16-byte rows)
+  if (a.ldg != 4 * H && (H != 64 || a.ldg < 4 * H || (a.ldg & 3))) return DVAE_EINVAL;
   return DVAE_OK;
 }
 

@@ -11,6 +11,7 @@
 //   TRANSPOSE  W[R][C] -> W^T[C][R]   (W_ih^T for the input-projection data gradients, W_hh^T for the H = 64 and
 //              generic backward recurrences);
 //   ADD2       b_ih + b_hh (nn.LSTM keeps two bias vectors; the kernels add one);
+//   COPY_F32   fp32 copies (W_ih of the two directions of a BiLSTM layer side by side: one input projection for both);
 //   CAST_BF16  bf16 copies of weights (bf16 compute mode: the B operands of the forward / data-gradient contractions);
 //              CONV_T and TRANSPOSE can write bf16 as well.
 // All of it is HBM-bound byte shuffling: 32x32 tiles through LDS so both sides move whole 128-B lines.
@@ -35,7 +36,8 @@ struct Table {
 
 // [R][C] -> [C][R], tiles lb, lb + nb, ...; out16: the destination is bf16
 __device__ __forceinline__ void transpose_tiles(const float* __restrict__ in, float* __restrict__ out, int R, int C,
-                                                int lb, int nb, float (*tile)[33], bool out16 = false) {
+                                                int lb, int nb, float (*tile)[33], bool out16 = false, int ldo = 0) {
+  if (ldo == 0) ldo = R;      // (ldo > R: the transposes of several sources side by side in one destination)
   const int tc = (C + 31) / 32, tr = (R + 31) / 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int t = lb; t < tc * tr; t += nb) {
@@ -49,8 +51,8 @@ __device__ __forceinline__ void transpose_tiles(const float* __restrict__ in, fl
     for (int k = ty; k < 32; k += 8) {
       const int c = c0 + k, r = r0 + tx;
       if (c < C && r < R) {
-        if (out16) reinterpret_cast<__bf16*>(out)[(int64_t)c * R + r] = (__bf16)tile[tx][k];
-        else out[(int64_t)c * R + r] = tile[tx][k];
+        if (out16) reinterpret_cast<__bf16*>(out)[(int64_t)c * ldo + r] = (__bf16)tile[tx][k];
+        else out[(int64_t)c * ldo + r] = tile[tx][k];
       }
     }
   }
@@ -201,9 +203,15 @@ __global__ __launch_bounds__(256) void repack_all_kernel(const Table t) {
       }
       break;
     }
-    case DVAE_REPACK_TRANSPOSE:   // d0 = R, d1 = C, d2: bf16 destination
-      transpose_tiles(d.src, d.dst, d.d0, d.d1, lb, nb, tile, d.d2 != 0);
+    case DVAE_REPACK_TRANSPOSE:   // d0 = R, d1 = C, d2 & 1: bf16 destination, d2 >> 1: row stride of the destination
+      transpose_tiles(d.src, d.dst, d.d0, d.d1, lb, nb, tile, (d.d2 & 1) != 0, d.d2 >> 1);
       break;
+    case DVAE_REPACK_COPY_F32: {  // n = d0 elements, a multiple of 4
+      const int64_t n4 = (int64_t)d.d0 >> 2;
+      for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256)
+        reinterpret_cast<f32x4*>(d.dst)[i] = reinterpret_cast<const f32x4*>(d.src)[i];
+      break;
+    }
     case DVAE_REPACK_CAST_BF16: { // n = d0 * d1 elements (d1 >= 1), a multiple of 4
       const int64_t n4 = ((int64_t)d.d0 * d.d1) >> 2;
       for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256)
@@ -270,8 +278,12 @@ DVAE_API int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* strea
         elems = (int64_t)4 * s.d0 * s.d0;
         break;
       case DVAE_REPACK_TRANSPOSE:
-        if (!s.src || !s.dst || s.d0 < 1 || s.d1 < 1) return DVAE_EINVAL;
+        if (!s.src || !s.dst || s.d0 < 1 || s.d1 < 1 || s.d2 < 0 || ((s.d2 >> 1) && (s.d2 >> 1) < s.d0)) return DVAE_EINVAL;
         elems = (int64_t)s.d0 * s.d1;
+        break;
+      case DVAE_REPACK_COPY_F32:
+        if (!s.src || !s.dst || s.d0 < 4 || (s.d0 & 3) || ((((uintptr_t)s.src) | ((uintptr_t)s.dst)) & 15)) return DVAE_EINVAL;
+        elems = s.d0;
         break;
       case DVAE_REPACK_ADD2:
         if (!s.src || !s.src2 || !s.dst || s.d0 < 1) return DVAE_EINVAL;

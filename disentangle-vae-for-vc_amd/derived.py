@@ -23,7 +23,11 @@ from . import _lib
 from ._lib import check, lib, stream
 
 # w_ih_t: W_ih^T (fp32, or bf16 in the bf16 compute mode); w_ih16: bf16 copy of W_ih (bf16 mode only, else None)
-LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b w_ih16", defaults=(None,))
+LstmDerived = namedtuple("LstmDerived", "bias w_ih_t w_hh_t pack_f pack_b w_ih16 cat", defaults=(None, None))
+# The two directions of a narrow BiLSTM layer (H = 64: the encoder) side by side, so that ONE contraction serves both:
+# w_ih [8H, In] (fp32, or bf16 in the bf16 mode) for the input projections (N = 8H), bias [8H], w_ih_t [In, 8H] for the
+# data gradient (K = 8H).  Shared by the two directions' LstmDerived entries (whose bias / w_ih16 are views into it).
+BiCat = namedtuple("BiCat", "w_ih bias w_ih_t")
 
 
 def lstm_pack_modes(mode: int, H: int):
@@ -82,6 +86,29 @@ def lstm_local(w_ih, w_hh, b_ih, b_hh, mode: int) -> LstmDerived:
     return LstmDerived(bias, wit, wht, pf, pb)
 
 
+def lstm_local_pair(params, mode: int):
+    """Both directions of a narrow (H = 64) bidirectional layer, computed on the spot, with the side-by-side buffers
+    (BiCat) the layer's merged contractions read.  params: [(w_ih, w_hh, b_ih, b_hh)] x 2."""
+    H, In = params[0][1].shape[1], params[0][0].shape[1]
+    dev = params[0][1].device
+    f = dict(device=dev, dtype=torch.float32)
+    b16 = mode == _lib.MODE_BF16
+    wdt = torch.bfloat16 if b16 else torch.float32
+    cat = BiCat(torch.empty((8 * H, In), device=dev, dtype=wdt), torch.empty(8 * H, **f),
+                torch.empty((In, 8 * H), device=dev, dtype=wdt))
+    out, descs = [], []
+    for dn, (w_ih, w_hh, b_ih, b_hh) in enumerate(params):
+        rows = slice(dn * 4 * H, (dn + 1) * 4 * H)
+        d = LstmDerived(cat.bias[rows], None, torch.empty((H, 4 * H), **f), None, None, cat.w_ih[rows] if b16 else None, cat)
+        descs += [_desc(_lib.REPACK_ADD2, b_ih, d.bias, 4 * H, src2=b_hh),
+                  _desc(_lib.REPACK_TRANSPOSE, w_ih, cat.w_ih_t[:, rows], 4 * H, In, d2=int(b16) | ((8 * H) << 1)),
+                  _desc(_lib.REPACK_CAST_BF16 if b16 else _lib.REPACK_COPY_F32, w_ih, cat.w_ih[rows], 4 * H * In, 1),
+                  _desc(_lib.REPACK_TRANSPOSE, w_hh, d.w_hh_t, 4 * H, H)]
+        out.append(d)
+    run_descs(descs)
+    return out
+
+
 class DerivedWeights:
     def __init__(self, convs: Dict[str, torch.nn.Parameter], lstms: Dict[str, tuple],
                  casts: Optional[Dict[str, torch.nn.Parameter]] = None):
@@ -116,10 +143,29 @@ class DerivedWeights:
             for name, w in self._casts.items():
                 self.w16[name] = torch.empty(w.shape, device=w.device, dtype=torch.bfloat16)
                 descs.append(_desc(_lib.REPACK_CAST_BF16, w, self.w16[name], w.numel(), 1))
+        cats = {}
         for name, (w_ih, w_hh, b_ih, b_hh) in self._lstms.items():
             H, In = w_hh.shape[1], w_ih.shape[1]
             f = dict(device=w_hh.device, dtype=torch.float32)
             big = H % 512 == 0
+            stem, dno = name.rsplit(".", 1)
+            if H == 64 and f"{stem}.1" in self._lstms:
+                # a direction of a narrow bidirectional layer: its bias / W_ih copy / W_ih^T are the halves of the pair's
+                # side-by-side buffers
+                if stem not in cats:
+                    cats[stem] = BiCat(torch.empty((8 * H, In), device=w_hh.device, dtype=wdt), torch.empty(8 * H, **f),
+                                       torch.empty((In, 8 * H), device=w_hh.device, dtype=wdt))
+                cat, dn = cats[stem], int(dno)
+                rows = slice(dn * 4 * H, (dn + 1) * 4 * H)
+                d = LstmDerived(cat.bias[rows], None, torch.empty((H, 4 * H), **f), None, None,
+                                cat.w_ih[rows] if b16 else None, cat)
+                self.lstm[name] = d
+                descs.append(_desc(_lib.REPACK_ADD2, b_ih, d.bias, 4 * H, src2=b_hh))
+                descs.append(_desc(_lib.REPACK_TRANSPOSE, w_ih, cat.w_ih_t[:, rows], 4 * H, In, d2=int(b16) | ((8 * H) << 1)))
+                descs.append(_desc(_lib.REPACK_CAST_BF16 if b16 else _lib.REPACK_COPY_F32, w_ih, cat.w_ih[rows],
+                                   4 * H * In, 1))
+                descs.append(_desc(_lib.REPACK_TRANSPOSE, w_hh, d.w_hh_t, 4 * H, H))
+                continue
             d = LstmDerived(torch.empty(4 * H, **f), torch.empty((In, 4 * H), device=w_hh.device, dtype=wdt),
                             torch.empty((H, 4 * H), **f),
                             torch.empty(6 * H * H, **f) if big else None,     # up to 3 bf16 planes

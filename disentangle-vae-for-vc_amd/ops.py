@@ -636,7 +636,9 @@ def _lstm_derived(derived, params, mode):
     computed on the spot (stand-alone use)."""
     if derived is not None:
         return list(derived)
-    from .derived import lstm_local
+    from .derived import lstm_local, lstm_local_pair
+    if len(params) == 2 and params[0][1].shape[1] == 64:
+        return lstm_local_pair(params, int(mode))
     return [lstm_local(wi, wh, bi, bh, int(mode)) for (wi, wh, bi, bh) in params]
 
 
@@ -672,13 +674,23 @@ class LstmLayerFn(torch.autograd.Function):
         bf, bfb = lstm_pack_modes(mode, H)      # (forward, backward) precision of the recurrent product
         der = _lstm_derived(derived, params, mode)
         gates, cells = [], []
+        # the two directions of a narrow layer (H = 64): ONE input projection with N = 8H into gates kept side by side
+        cat = der[0].cat if (ndir == 2 and der[0].cat is not None and der[1].cat is der[0].cat) else None
+        ldg = 8 * H if cat is not None else 4 * H
+        if cat is not None:
+            gall = torch.empty((R, ldg), device=dev, dtype=torch.float32)
+            gemm(x, cat.w_ih, gall, cat.bias, R, ldg, In, In, In, ldg, True, True, mode=mode)
         for d, (wi, wh, bi, bh) in enumerate(params):
-            g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
-            gemm(x, wi if der[d].w_ih16 is None else der[d].w_ih16, g, der[d].bias, R, 4 * H, In, In, In, 4 * H, True, True,
-                 mode=mode)
+            if cat is not None:
+                g = gall[:, d * 4 * H:(d + 1) * 4 * H]
+            else:
+                g = torch.empty((R, 4 * H), device=dev, dtype=torch.float32)
+                gemm(x, wi if der[d].w_ih16 is None else der[d].w_ih16, g, der[d].bias, R, 4 * H, In, In, In, 4 * H, True,
+                     True, mode=mode)
             c = torch.empty((R, H), device=dev, dtype=torch.float32)
             gates.append(g)
             cells.append(c)
+            dirs[d].gate_ld = ldg
             dirs[d].gates = ptr(g)
             dirs[d].w_hh = ptr(wh)
             dirs[d].w_packed = ptr(der[d].pack_f)
@@ -694,6 +706,7 @@ class LstmLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, h_out, *gates, *cells, *[p for ps in params for p in ps])
         ctx.der = der
         ctx.cfg = (T, N, H, ndir, bfb, mode, s16)
+        ctx.cat = cat
         if not s16:
             return (h_out, None) if emit16 else h_out
         if emit16:
@@ -726,11 +739,19 @@ class LstmLayerFn(torch.autograd.Function):
         dirs = (_lib.LstmDir * ndir)()
         keep = []
         dgs = []
+        cat = getattr(ctx, "cat", None)
+        ldg = 8 * H if cat is not None else 4 * H
+        if cat is not None:        # (H = 64: fp32 gate gradients) both directions side by side, like the gates
+            dgall = torch.empty((R, ldg), device=dev, dtype=torch.float32)
         for d in range(ndir):
-            dg = torch.empty((R, 4 * H), device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
+            if cat is not None:
+                dg = dgall[:, d * 4 * H:(d + 1) * 4 * H]
+            else:
+                dg = torch.empty((R, 4 * H), device=dev, dtype=torch.bfloat16 if s16 else torch.float32)
             dc = torch.empty((N, H), device=dev, dtype=torch.float32)
             keep.append(dc)
             dgs.append(dg)
+            dirs[d].gate_ld = ldg
             dirs[d].gates = ptr(gates[d])
             dirs[d].w_hh = ptr(der[d].w_hh_t)       # [H, 4H]
             dirs[d].w_packed = ptr(der[d].pack_b)
@@ -752,7 +773,10 @@ class LstmLayerFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), device=dev, dtype=torch.float32)
-            for d in range(ndir):
+            if cat is not None:
+                # both directions' data gradients are ONE contraction over K = 8H
+                gemm(dgall, cat.w_ih_t, dx, None, R, In, ldg, ldg, ldg, In, True, True, ACT_NONE, EPI_STORE, mode=mode)
+            for d in range(ndir if cat is None else 0):
                 # dx = dgates @ W_ih contracts over 4H: against W_ih^T both operands are k-contiguous
                 gemm(dgs[d], der[d].w_ih_t, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
                      EPI_STORE if d == 0 else EPI_ACCUM, mode=mode)
@@ -763,19 +787,19 @@ class LstmLayerFn(torch.autograd.Function):
                 Nout, K = params[0][0].shape
                 sk = _split_k(2 * _tiles(Nout, K), R)
                 epi = EPI_ATOMIC if sk > 1 else EPI_ACCUM
-                gemm_batched(dgs, [x, x], [_grad_buf(params[0][0]), _grad_buf(params[1][0])], Nout, K, R, 4 * H, In, K,
+                gemm_batched(dgs, [x, x], [_grad_buf(params[0][0]), _grad_buf(params[1][0])], Nout, K, R, ldg, In, K,
                              False, False, epi, sk, mode)
                 gws = [_grad_buf(params[0][1]), _grad_buf(params[1][1])]
                 if T > 1:
                     rows = R - N
                     sk = _split_k(2 * _tiles(4 * H, H), rows)
-                    gemm_batched([dgs[0].data_ptr() + esz * N * 4 * H, dgs[1].data_ptr()],
-                                 [h_out.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)], gws, 4 * H, H, rows, 4 * H, ldh, H,
+                    gemm_batched([dgs[0].data_ptr() + esz * N * ldg, dgs[1].data_ptr()],
+                                 [h_out.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)], gws, 4 * H, H, rows, ldg, ldh, H,
                                  False, False, EPI_ATOMIC if sk > 1 else EPI_ACCUM, sk, mode,
                                  flags=(A_BF16 | B_BF16) if s16 else 0)
                 for d, (wi, wh, bi, bh) in enumerate(params):
                     if not pers_bias:
-                        colsum_add(dgs[d], _grad_buf(bi), _grad_buf(bh))
+                        colsum_add(dgs[d], _grad_buf(bi), _grad_buf(bh), rows=R, cols=4 * H, ld=ldg)
             else:
               for d, (wi, wh, bi, bh) in enumerate(params):
                 dg = dgs[d]

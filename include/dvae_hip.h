@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 304
+#define DVAE_ABI_VERSION 305
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -203,6 +203,10 @@ typedef struct {
   float* dbias_hh;    /* column sums of dgates over all frames and rows are ADDED to these [4H] vectors (the gradients of
                          b_ih and b_hh, nn.LSTM keeps two): the caller then skips its dvae_colsum_add pass over dgates.
                          Ignored (and the caller must run dvae_colsum_add) when the per-frame kernels are used */
+  int64_t gate_ld;    /* row stride, in elements, of gates and dgates (0: 4H, the dense layout).  H = 64 only: the two
+                         directions of the encoder BiLSTM keep their gates side by side in ONE [T*N, 8H] tensor, so that both
+                         input projections are one contraction with N = 8H (and both data gradients one with K = 8H);
+                         every direction of a call must name the same stride */
 } dvae_lstm_dir_t;
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
@@ -216,8 +220,10 @@ int dvae_lstm_pack_w_x3(const float* w_hh, void* packed_fwd, void* packed_bwd, i
  *                                                              (either pointer may be null; DVAE_MODE_F32 / _BF16 /
  *                                                              _F32X3, the last two only where H % 512 == 0): see
  *                                                              dvae_lstm_pack_w / _bf16 / _x3
- *      TRANSPOSE src W[d0][d1]                              -> dst W^T[d1][d0]         (bf16 destination when d2 != 0;
- *                                                                                       CONV_T likewise)
+ *      TRANSPOSE src W[d0][d1]                              -> dst W^T[d1][d0]         (bf16 destination when d2 & 1;
+ *                                                                                       CONV_T likewise); d2 >> 1 = row
+ *                                                                                       stride of dst in elements (0: d0)
+ *      COPY_F32  src [d0] fp32                              -> dst, same layout        (weights of two directions side by side)
  *      ADD2      src, src2 [d0]                             -> dst = src + src2        (b_ih + b_hh)
  *      CAST_BF16 src [d0*d1] fp32                           -> dst bf16, same layout   (bf16 mode: weight operands)
  * `descs` is a HOST array of n <= 72 entries (copied into the launch); the device buffers are the caller's. */
@@ -226,6 +232,7 @@ int dvae_lstm_pack_w_x3(const float* w_hh, void* packed_fwd, void* packed_bwd, i
 #define DVAE_REPACK_TRANSPOSE 2
 #define DVAE_REPACK_ADD2 3
 #define DVAE_REPACK_CAST_BF16 4
+#define DVAE_REPACK_COPY_F32 5
 typedef struct {
   int kind, d0, d1, d2;
   const void* src;
