@@ -1723,6 +1723,36 @@ DVAE_API int dvae_gemm_f32_batched(const void* const* A, const void* const* B, v
 
 // conv forward that also leaves the BatchNorm partial statistics of Y in `bn_ws` (>= dvae_bn_ws_bytes(R, Cout, G) bytes,
 // the layout dvae_bn_stats_finalize reads); G = statistics groups (1 or 2)
+DVAE_API int dvae_zero_f32(float* x, int64_t n, void* stream);   // elem.hip
+
+namespace {
+// A conv (tap mode 1) with FEW output columns (the 80 mel channels: postnet's last conv forward, the data gradient of the
+// convs that read the mel) has R / 256 = 64 tall tiles and nothing to fill the chip with: 115 us at 58 TFLOP/s on the
+// 128 x 64 tiles.  In the split arithmetic it is cut along k instead (each workgroup all five taps of a quarter of the
+// input channels) and accumulated atomically into a result this call clears first: 256 tall workgroups of 40 k-steps.
+// Not in the deterministic mode (one writer per element there).
+void narrow_conv_split(GemmParams& p, int mode, hipStream_t s) {
+  int m = mode;
+  if (m >= 0) m &= 0xff;
+  if (m == DVAE_MODE_DEFAULT) m = g_dvae_compute_mode;
+  if (m != DVAE_MODE_F32X3 || g_dvae_deterministic || (mode >= 0 && (mode & ~0xff))) return;
+  if (p.N <= 64 || p.N > 128 || (p.N & 3) || p.M < 256 || (((uintptr_t)p.C) & 15)) return;
+  const int tiles = (p.M + 255) / 256;
+  if (tiles >= 192) return;
+  for (int sk = 2; sk <= 8; sk *= 2) {
+    if (p.K % (16 * sk)) return;
+    const int steps = (p.K / sk / 16) * p.taps;
+    if (steps < 24) return;
+    if (tiles * sk >= 192) {
+      if (dvae_zero_f32((float*)p.C, (int64_t)p.M * p.ldc, s) != DVAE_OK) return;
+      p.split_k = sk;
+      p.epi = DVAE_EPI_ATOMIC;
+      return;
+    }
+  }
+}
+}  // namespace
+
 DVAE_API int dvae_conv5_fwd_stats(const void* X, const void* Wp, const float* bias, float* Y, int R, int N, int Cin,
                                   int Cout, int mode, int G, void* bn_ws, void* stream) {
   if (!bn_ws || G < 1 || G > 2 || N < 1 || (N % G) || (R % N)) return DVAE_EINVAL;
@@ -1746,6 +1776,7 @@ DVAE_API int dvae_conv5_fwd(const void* X, const void* Wp, const float* bias, fl
   p.taps = 5; p.tap_mode = 1;
   p.a_row_shift = N; p.b_tap_stride = (int64_t)Cout * Cin;
   p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
+  narrow_conv_split(p, mode, (hipStream_t)stream);
   return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 
@@ -1759,6 +1790,7 @@ DVAE_API int dvae_conv5_dgrad_t(const void* dY, const void* Wpt, float* dX, int 
   p.taps = 5; p.tap_mode = 1;
   p.a_row_shift = -(int64_t)N; p.b_tap_stride = (int64_t)Cout * Cin;
   p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
+  narrow_conv_split(p, mode, (hipStream_t)stream);
   return launch_gemm(p, true, true, mode, (hipStream_t)stream);
 }
 

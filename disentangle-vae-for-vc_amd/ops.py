@@ -475,10 +475,18 @@ class ConvBnActFn(torch.autograd.Function):
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             rstd = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
-            check(L.dvae_conv5_fwd_stats(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, G, ptr(ws),
-                                         st), "dvae_conv5_fwd_stats")
-            check(L.dvae_bn_stats_finalize(ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(ws),
-                                           R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_finalize")
+            if 64 < Cout <= 128 and R >= 4096 and mode == MODE_F32X3 and not _DETERMINISTIC:
+                # few output columns (postnet's last conv: 80 mel channels): dvae_conv5_fwd cuts such a conv along k and
+                # accumulates atomically (csrc/gemm.hip narrow_conv_split) — no statistics in that epilogue: one pass over
+                # the [R, 80] result instead
+                check(L.dvae_conv5_fwd(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, st), "dvae_conv5_fwd")
+                check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt),
+                                          ptr(ws), R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_fwd")
+            else:
+                check(L.dvae_conv5_fwd_stats(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, G,
+                                             ptr(ws), st), "dvae_conv5_fwd_stats")
+                check(L.dvae_bn_stats_finalize(ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt),
+                                               ptr(ws), R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_finalize")
         else:
             check(L.dvae_conv5_fwd(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, st),
                   "dvae_conv5_fwd")

@@ -148,7 +148,10 @@ def from_frames(y, N, T):  # [T*N, C] -> [N,C,T]
     return y.reshape(T, N, -1).permute(1, 2, 0).contiguous()
 
 
-@pytest.mark.parametrize("N,T,Cin,Cout", [(8, 64, 80, 512), (6, 32, 512, 80), (128, 16, 512, 512), (3, 5, 80, 80)])
+# (128, 128, 512, 80) / (128, 128, 80, 512): R = 16 384 rows and 80 output columns of the forward pass / the data gradient:
+# the k-split, atomically accumulated form of csrc/gemm.hip narrow_conv_split (the benchmark's postnet shapes)
+@pytest.mark.parametrize("N,T,Cin,Cout", [(8, 64, 80, 512), (6, 32, 512, 80), (128, 16, 512, 512), (3, 5, 80, 80),
+                                          (128, 128, 512, 80), (128, 128, 80, 512)])
 def test_conv5_fwd_dgrad_wgrad(ops, N, T, Cin, Cout):
     from dvae_amd._lib import check, lib, ptr, stream
     L = lib()
