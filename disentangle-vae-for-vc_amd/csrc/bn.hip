@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
       ga = *reinterpret_cast<const f32x4*>(gamma + c);
       be = *reinterpret_cast<const f32x4*>(beta + c);
     }
+    // (four rows' loads in flight per thread: with one row per trip the pass is bound by the load latency, not by HBM)
+#pragma unroll 4
     for (int r = r0 + rl; r < r1; r += 4) {
       const bool g1 = ((r % N) / per) != 0;
       const f32x4 y = *reinterpret_cast<const f32x4*>(Y + (int64_t)r * C + c);

@@ -1559,9 +1559,10 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
       zdim = p.split_k * (p.tap_mode == 2 ? p.taps : 1);
     }
     // one workgroup per CU: nothing hides a tile's prologue (cold loads) and epilogue (128 KB of C per CU), so the tile
-    // must be long: >= 24 k-steps (measured: 24 and 12 equal, 60 slower by 0.1 ms per step; shorter ones stay
-    // on the 128 x 128 kernel, whose two workgroups per CU cover each other's ends)
-    static const int tall_min = dvae_dev_knob("DVAE_GEMM_TALL_MIN", 24);
+    // should be long.  Round 3 measured 24 and 12 k-steps equal and 60 slower by 0.1 ms per step; with the 16-byte store
+    // epilogues of round 4 the short ones gain a little too (scripts/small_shapes.py, 17 short shapes of the step: 873 us
+    // at 24, 846 at 8, 843 at 4): from 8 k-steps on
+    static const int tall_min = dvae_dev_knob("DVAE_GEMM_TALL_MIN", 8);
     const int steps_per_tile = (kps / 16) * (p.tap_mode == 1 ? p.taps : 1);
     tall = (t2 * zdim >= 192 && steps_per_tile >= tall_min) || tall_env == 1;
   }
