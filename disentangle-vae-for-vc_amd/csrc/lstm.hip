@@ -777,15 +777,19 @@ __device__ __forceinline__ void split3s(float x, __bf16 (&p)[3]) {
 // Waves: PM = 0: 8 (gate, n-half: two 16-unit n-tiles each); PM != 0: 16 (gate, n-tile) and ONE element per thread in
 // the gate arithmetic — with the MFMAs cheap, a frame is a chain of latencies (fragment reads, MFMAs, the gs round
 // trip, ten transcendentals per element, two barriers), and sixteen waves halve the per-wave serial parts of it.
-template <int PM>
-__global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_fwd_h64(const StepArgs a) {
+// ROWS (PM != 0): segments per workgroup.  The MFMA tile has 16 rows whatever ROWS is (24 MFMAs per (gate, n-tile) pair and
+// frame in the split arithmetic: 768 cycles per SIMD), but the gate arithmetic — ten transcendentals per element — is per
+// row: with N = 128 segments, 8 (4) rows per workgroup spread it over 32 (64) CUs instead of 16.
+template <int PM, int ROWS = 16>
+__global__ __launch_bounds__(PM ? 64 * ROWS : 512) void lstm_seq_fwd_h64(const StepArgs a) {
   constexpr int H = 64;
   constexpr bool B16 = PM != 0;
   constexpr int NP = PM == 2 ? 3 : 1;
-  constexpr int NTHR = PM ? 1024 : 512, NE = 1024 / NTHR, NT = PM ? 1 : 2;
+  constexpr int NTHR = PM ? 64 * ROWS : 512, NE = ROWS * 64 / NTHR, NT = 16 / (NTHR / 64);
+  static_assert(PM != 0 || ROWS == 16, "the fp32-MFMA form keeps 16 rows");
   const StepDir& d = a.d[blockIdx.y];
   const int N = a.N, T = a.T;
-  const int m0 = blockIdx.x * 16;
+  const int m0 = blockIdx.x * ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gate = wave & 3, part = wave >> 2;        // n-tiles part * NT .. + NT - 1
   const int r = lane & 15, kq = lane >> 4;
@@ -839,6 +843,11 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_fwd_h64(const StepAr
     } else {
       hs[erow[e]][ej[e]] = 0.f;
     }
+  }
+  if constexpr (B16 && ROWS < 16) {      // the tile's unused rows: zero for the whole sequence
+    for (int idx = tid + ROWS * 64; idx < 16 * 64; idx += NTHR)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) hs16[q][idx >> 6][idx & 63] = (__bf16)0.f;
   }
   __syncthreads();
 
@@ -939,15 +948,17 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_fwd_h64(const StepAr
 // PM = 1 / 2: dG[t+1] and W_hh as one / three bf16 planes for the recurrent product (see lstm_seq_fwd_h64).  Waves: (n-tile of
 // 16 hidden units, k-part of the 256 gate columns): PM = 0: 8 waves, k-halves; PM != 0: 16 waves, k-quarters, one element
 // per thread in the gate arithmetic.
-template <int PM>
-__global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_bwd_h64(const StepArgs a) {
+// ROWS: segments per workgroup (PM != 0; see lstm_seq_fwd_h64): 4 ROWS / 16 waves = k-parts of the 256 gate columns.
+template <int PM, int ROWS = 16>
+__global__ __launch_bounds__(PM ? 64 * ROWS : 512) void lstm_seq_bwd_h64(const StepArgs a) {
   constexpr int H = 64;
   constexpr bool B16 = PM != 0;
   constexpr int NP = PM == 2 ? 3 : 1;
-  constexpr int NTHR = PM ? 1024 : 512, NE = 1024 / NTHR, KP = PM ? 4 : 2, KW = 256 / KP;   // k-parts, their width
+  constexpr int NTHR = PM ? 64 * ROWS : 512, NE = ROWS * 64 / NTHR, KP = NTHR / 256, KW = 256 / KP;   // k-parts, their width
+  static_assert(PM != 0 || ROWS == 16, "the fp32-MFMA form keeps 16 rows");
   const StepDir& d = a.d[blockIdx.y];   // d.w = W_hh^T [H][4H]
   const int N = a.N, T = a.T;
-  const int m0 = blockIdx.x * 16;
+  const int m0 = blockIdx.x * ROWS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 3, kp = wave >> 2;
   const int r = lane & 15, kq = lane >> 4;
@@ -1003,6 +1014,13 @@ __global__ __launch_bounds__(PM ? 1024 : 512) void lstm_seq_bwd_h64(const StepAr
         dgs[erow[e]][g * H + ej[e]] = 0.f;
       }
     }
+  }
+  if constexpr (B16 && ROWS < 16) {      // the tile's unused rows: zero for the whole sequence
+    for (int idx = tid + ROWS * 64; idx < 16 * 64; idx += NTHR)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) dgs16[q][idx >> 6][g * H + (idx & 63)] = (__bf16)0.f;
   }
   __syncthreads();
 
@@ -1227,9 +1245,19 @@ int lstm_seq_fwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], false, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_fwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
-    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_fwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
+    // rows per workgroup: as few as still leave <= 64 workgroups (N = 128 segments x 2 directions: 4 rows)
+    static const int rows_env = dvae_dev_knob("DVAE_LSTM_H64_ROWS", 0);
+    int rows = 16;
+    if (a.pm) {
+      if (((N + 7) / 8) * ndir <= 64) rows = 8;
+      if (((N + 3) / 4) * ndir <= 64) rows = 4;
+      if (rows_env == 16 || rows_env == 8 || rows_env == 4) rows = rows_env;
+    }
+#define H64F(PM_, R_) hipLaunchKernelGGL((lstm_seq_fwd_h64<PM_, R_>), dim3((N + R_ - 1) / R_, ndir), dim3(64 * R_), 0, s, a)
+    if (a.pm == DVAE_MODE_BF16) { if (rows == 4) H64F(1, 4); else if (rows == 8) H64F(1, 8); else H64F(1, 16); }
+    else if (a.pm == DVAE_MODE_F32X3) { if (rows == 4) H64F(2, 4); else if (rows == 8) H64F(2, 8); else H64F(2, 16); }
     else hipLaunchKernelGGL(lstm_seq_fwd_h64<0>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+#undef H64F
     return dvae_check_launch();
   }
   if (H % 512 == 0) {
@@ -1286,9 +1314,18 @@ int lstm_seq_bwd_range(const dvae_lstm_dir_t* dirs, int ndir, int T, int N, int 
   if (pers) return dvae_pers_launch(dirs[0], true, T, N, H, ldh, -1, s);
   if (H == 64) {
     if (!p.whole) return DVAE_EINVAL;
-    if (a.pm == DVAE_MODE_BF16) hipLaunchKernelGGL(lstm_seq_bwd_h64<1>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
-    else if (a.pm == DVAE_MODE_F32X3) hipLaunchKernelGGL(lstm_seq_bwd_h64<2>, dim3((N + 15) / 16, ndir), dim3(1024), 0, s, a);
+    static const int rows_env = dvae_dev_knob("DVAE_LSTM_H64_ROWS", 0);
+    int rows = 16;
+    if (a.pm) {
+      if (((N + 7) / 8) * ndir <= 64) rows = 8;
+      if (((N + 3) / 4) * ndir <= 64) rows = 4;
+      if (rows_env == 16 || rows_env == 8 || rows_env == 4) rows = rows_env;
+    }
+#define H64B(PM_, R_) hipLaunchKernelGGL((lstm_seq_bwd_h64<PM_, R_>), dim3((N + R_ - 1) / R_, ndir), dim3(64 * R_), 0, s, a)
+    if (a.pm == DVAE_MODE_BF16) { if (rows == 4) H64B(1, 4); else if (rows == 8) H64B(1, 8); else H64B(1, 16); }
+    else if (a.pm == DVAE_MODE_F32X3) { if (rows == 4) H64B(2, 4); else if (rows == 8) H64B(2, 8); else H64B(2, 16); }
     else hipLaunchKernelGGL(lstm_seq_bwd_h64<0>, dim3((N + 15) / 16, ndir), dim3(512), 0, s, a);
+#undef H64B
     return dvae_check_launch();
   }
   if (H % 512 == 0) {

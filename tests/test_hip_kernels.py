@@ -289,7 +289,9 @@ def test_bn_bwd_from_y_equals_bn_bwd(ops, act, G, dy16):
 # plan_seq: n_j * ceil(N/32) >= 256); H = 128 / 256 reach the generic LDS-staged frame kernels
 @pytest.mark.parametrize("N,T,In,H,bidir", [(8, 12, 512, 64, True), (128, 6, 128, 512, False), (6, 5, 512, 1024, False),
                                             (20, 9, 128, 64, True), (128, 4, 512, 1024, False), (128, 4, 128, 512, True),
-                                            (20, 5, 64, 128, False), (20, 5, 96, 256, True), (33, 3, 512, 1024, False)])
+                                            (20, 5, 64, 128, False), (20, 5, 96, 256, True), (33, 3, 512, 1024, False),
+                                            # H = 64: 4 / 8 / 16 segments per workgroup (N <= 128 / <= 256 / more, two directions)
+                                            (160, 3, 128, 64, True), (300, 3, 128, 64, True)])
 @pytest.mark.parametrize("persistent", [True, False])
 def test_lstm_layer(ops, N, T, In, H, bidir, persistent):
     with persistent_lstm(ops, persistent):
