@@ -1121,8 +1121,9 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_TANH>{});
 #ifdef DVAE_GEMM_TS2
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store / atomic of this wave acknowledged
-  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && blockIdx.z == 0) {
-    unsigned long long* o = g_gemm_ts + (blockIdx.x * 4 + wave) * 8;
+  const unsigned flat_wg = blockIdx.z * gridDim.x + blockIdx.x;
+  if ((threadIdx.x & 63) == 0 && flat_wg < 256) {
+    unsigned long long* o = g_gemm_ts + (flat_wg * 4 + wave) * 8;
     o[0] = t2_entry; o[1] = t2_loop0; o[2] = t2_loop1; o[3] = __builtin_amdgcn_s_memrealtime();
     o[4] = (unsigned long long)n_iters;
     unsigned xcc;

@@ -1,6 +1,6 @@
 """GPU box (dev library built with `csrc/build.sh dev -DDVAE_GEMM_TS2`): where a tall-kernel launch spends the time that is
 NOT its k loop.  Four s_memrealtime stamps (100 MHz, chip-wide) per wave: entry, loop entered, loop left, stores drained.
-usage: gemm_ends.py conv|proj|wgrad"""
+usage: gemm_ends.py conv|proj|wgrad|dgrad"""
 import ctypes, os, sys
 os.environ.setdefault("DVAE_LIB_PATH", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                     "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
@@ -20,8 +20,14 @@ if kind == "conv":
 elif kind == "proj":
     x, w, y = t(R, 1024), t(4096, 1024), torch.empty(R, 4096, device="cuda")
     fn = lambda: ops.gemm(x, w, y, None, R, 4096, 1024, 1024, 1024, 4096, True, True)
+elif kind == "wgrad":     # conv weight gradient: 5 taps x 6 k-splits x 8 tiles, atomically accumulated
+    dy, x, dw = t(R, 512), t(R, 512), torch.zeros(5, 512, 512, device="cuda")
+    fn = lambda: check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(dw), R, N, 512, 512, 6, -1, stream()), "")
+elif kind == "dgrad":
+    dy, wpt, dx = t(R, 512), t(5, 512, 512), torch.empty(R, 512, device="cuda")
+    fn = lambda: check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, N, 512, 512, -1, stream()), "")
 else:
-    raise SystemExit("conv|proj")
+    raise SystemExit("conv|proj|wgrad|dgrad")
 for _ in range(30):
     fn()
 torch.cuda.synchronize()
