@@ -1836,6 +1836,10 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     // microsecond on.  Not the hand-off protocol (a release fence in front of the flag, an agent-scope acquire in front of
     // the loads, sc0 sc1 loads, four ring slots, row groups spread over XCDs, a full vmcnt(0) after the loads: each still
     // failed) and not found by reading the ISA; the 32-row forward kernel and every other persistent kernel: 0 of 200.
+    // scripts/x3_fwd16_diag.py: the stored h[t-1] of the bad rows is right and the bad gates match NO candidate input (h of
+    // another frame, another row, zeros) — in 3 of 4 cases they are off by more than any |h| < 1 could move them: the
+    // consumers' fragments held foreign bits in the 64-byte pieces of rows 12..15 (a fragment row group = lanes 12..15 of
+    // each 16-lane quarter), e.g. words an earlier launch left in the ring; once they were merely slightly off (1e-2).
     static const int mt1 = dvae_dev_knob("DVAE_PERS_X3_MT1", 2);
     const int n_rb16 = (N + 15) / 16;
     if ((kind == 2 ? (mt1 & 1) : (mt1 & 2)) && (kind == 2 || kind == 4) && H == 512 &&
