@@ -78,6 +78,20 @@ def test_gemm_nt_splitk_atomic(ops, M, N, K, sk):
     close(y, x.double() @ w.double().t() + b.double(), name="gemm_splitk")
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(128, 2048, 16384, 32), (128, 16384, 2048, 4), (80, 1024, 16384, 64),
+                                      (100, 2048, 16384, 32), (128, 4096, 4096, 4)])
+@pytest.mark.parametrize("b_kc", [True, False])
+def test_gemm_few_rows_splitk(ops, M, N, K, sk, b_kc):
+    """k-split products with <= 128 rows against a large weight (the Linear layers over the flattened frames: enc_linear /
+    dec_pre_linear2 forward and data gradient, dec_linear2's weight gradient) at the benchmark's sizes: bias, ragged row
+    counts, both weight layouts."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    y = torch.zeros(M, N, device="cuda")
+    wd = dev(w) if b_kc else dev(w.t().contiguous())
+    ops.gemm(dev(x), wd, y, dev(b), M, N, K, K, K if b_kc else N, N, True, b_kc, 0, ops.EPI_ATOMIC, sk)
+    close(y, x.double() @ w.double().t() + b.double(), name="gemm_few_rows")
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 80, 512), (16384, 128, 256)])
 def test_gemm_nn_dgrad(ops, M, N, K):
     dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5)
