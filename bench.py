@@ -524,7 +524,24 @@ def main():
         variants = {f"{red.mode}:{red.issue}": ms_eager}
         want = os.environ.get("DVAE_BENCH_DDP_VARIANTS", "all_reduce:hook,all_reduce:finish,rs_ag:hook,rs_ag:finish")
         from dvae_amd import ddp as _ddp
+        # A variant that WEDGES (a collective some rank never enters) must not cost the line either: from here on a watchdog
+        # per rank ends the process once the remaining measurements have taken DVAE_BENCH_VARIANT_TIMEOUT seconds; rank 0
+        # first prints the line of what has been measured (a complete timed region of at least the first variant), marked.
+        import threading
+        wd = {"elapsed": elapsed, "last": last, "launch": launch, "now": "setup"}
+
+        def variants_wedged():
+            if rank == 0:
+                ex = dict(extra, ddp_variants_ms_per_step=dict(variants),
+                          variant_watchdog=f"fired during {wd['now']}: the line is the fastest variant measured until then")
+                print(json.dumps(_result(args, world, B, T, dtype, n_params, wd["elapsed"], wd["last"], wd["launch"], ex, None)),
+                      flush=True)
+            os._exit(0)      # (every rank: the line says what happened; a non-zero rank must not void it)
+        vdog = threading.Timer(float(os.environ.get("DVAE_BENCH_VARIANT_TIMEOUT", "300")), variants_wedged)
+        vdog.daemon = True
+        vdog.start()
         for v in [x for x in want.split(",") if x and x not in variants]:
+            wd["now"] = v
             try:
                 mode_v, issue_v = v.split(":")
                 r2 = red if mode_v == red.mode else _ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params,
@@ -539,8 +556,10 @@ def main():
                 if el_v < elapsed:
                     elapsed, last, launch = el_v, tuple(last_v.tolist()), f"eager ({mode_v}, collectives issued from {issue_v})"
                     extra["ddp_mode"], extra["ddp_issue"] = mode_v, issue_v
+                    wd.update(elapsed=elapsed, last=last, launch=launch)
             except Exception as e:      # a variant that fails must not cost the line
                 variants[v] = "failed: " + repr(e)[:160]
+        wd["now"] = "the measurements after the variants"
         extra["ddp_variants_ms_per_step"] = variants
         red.issue = os.environ.get("DVAE_DDP_ISSUE", "hook")
         w.attach_reducer(red)
@@ -600,6 +619,7 @@ def main():
         extra["ms_per_step_no_allreduce"] = 1e3 * el_nr / n_nr
         extra["allreduce_exposed_ms"] = ms_eager - 1e3 * el_nr / n_nr
         ops.lstm_pers_check()
+        vdog.cancel()
 
     roof = roof_lstm = None
     if not args.no_roofline and rank == 0 and not dp:

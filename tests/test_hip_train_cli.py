@@ -64,3 +64,37 @@ def test_train_cli_gpus_2_launches_two_sharded_ranks(tmp_path):
     osd = torch.load(log_dir / "checkpoints" / "DisentangledVAE_VCTK_2.opt", map_location="cpu")
     # 16 pairs over 2 ranks x batch 4 = 2 steps per epoch per rank, 2 epochs
     assert osd["t"] == 4, osd["t"]
+
+
+def _bench_two_ranks(env_extra, frames="64", batch="4"):
+    """`bench.py --gpus 2` as the driver starts it for N = 1 (no rendezvous in the environment: bench.py launches the two
+    ranks itself); the box has one GPU, so the ranks share it and exchange through gloo — a functional check of the N > 1
+    line, not a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", DVAE_ALLOW_SHARED_GPU="1", DVAE_DIST_BACKEND="gloo",
+               **env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", batch, "--frames", frames], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                       # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_line_lists_every_exchange_variant():
+    out = _bench_two_ranks({})
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    v = out["ddp_variants_ms_per_step"]
+    assert set(v) == {"all_reduce:hook", "all_reduce:finish", "rs_ag:hook", "rs_ag:finish"}, v
+    assert all(isinstance(x, float) and x > 0 for x in v.values()), v
+    assert abs(out["ms_per_step"] - min(v.values())) < 1e-6 * out["ms_per_step"]       # the headline is the fastest
+    assert "variant_watchdog" not in out
+
+
+def test_bench_gpus_2_a_wedged_variant_does_not_cost_the_line():
+    """DVAE_BENCH_VARIANT_TIMEOUT = 0.05 s: the watchdog fires while the second exchange variant is being set up or timed;
+    rank 0 must still print the (marked) line of the first variant's complete timed region, every rank must exit 0."""
+    out = _bench_two_ranks({"DVAE_BENCH_VARIANT_TIMEOUT": "0.05"})
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert "fired during" in out["variant_watchdog"]
+    assert "all_reduce:hook" in out["ddp_variants_ms_per_step"]
