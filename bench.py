@@ -268,7 +268,10 @@ def build_trainer(dev, B, T, dtype, world=1, rank=0, force_ddp=False):
         ddp.broadcast_parameters(w.optimizer.flat_p, [b for b in w.model.buffers()])
         red = ddp.GradReducer(w.optimizer.flat_g, w.optimizer.names, w.optimizer.params, w.optimizer.offsets,
                               mode=os.environ.get("DVAE_DDP_MODE", "all_reduce"),      # or "rs_ag": sharded Adam
-                              issue=os.environ.get("DVAE_DDP_ISSUE", "hook"))          # or "finish": no overlap
+                              # measured FIRST: the form with nothing beside the W_hh-resident recurrences ("finish":
+                              # collectives after backward) — should an overlapped variant wedge later, the watchdog has
+                              # this one's line; the overlapped form ("hook") is one of the variants timed after it
+                              issue=os.environ.get("DVAE_DDP_ISSUE", "finish"))
         red.force = force_ddp
         w.attach_reducer(red)
     return w
@@ -561,7 +564,7 @@ def main():
                 variants[v] = "failed: " + repr(e)[:160]
         wd["now"] = "the measurements after the variants"
         extra["ddp_variants_ms_per_step"] = variants
-        red.issue = os.environ.get("DVAE_DDP_ISSUE", "hook")
+        red.issue = os.environ.get("DVAE_DDP_ISSUE", "finish")
         w.attach_reducer(red)
         if red.mode != "rs_ag":
             w.optimizer.fold_zero_grad = True
@@ -618,6 +621,7 @@ def main():
         w.attach_reducer(red)
         extra["ms_per_step_no_allreduce"] = 1e3 * el_nr / n_nr
         extra["allreduce_exposed_ms"] = ms_eager - 1e3 * el_nr / n_nr
+        extra["allreduce_exposed_variant"] = next(iter(variants))          # the first variant measured (ms_eager)
         ops.lstm_pers_check()
         vdog.cancel()
 
