@@ -174,16 +174,41 @@ def _free_port():
         return so.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process's children will see, WITHOUT touching the HIP runtime (the launcher never does): the KFD
+    topology's nodes with SIMDs (CPUs have simd_count 0), cut down by HIP_/ROCR_/CUDA_VISIBLE_DEVICES lists.  None when
+    the topology cannot be read (then --gpus is trusted and the ranks themselves check)."""
+    import glob
+    n = 0
+    paths = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not paths:
+        return None
+    for path in paths:
+        try:
+            for line in open(path):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+                    break
+        except OSError:
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n, argv, dry=False):
     """`--gpus n` without a rendezvous in the environment: start n fresh rank processes of this script (one per GPU) and
-    relay rank 0's stdout.  Runs BEFORE anything in this process touches the GPU (torch is imported, HIP is not
-    initialised: torch.cuda.device_count() does not initialise it on this image) and never replaces this process with
-    another program.  Returns the exit code: 0 only if every rank exited 0."""
+    relay rank 0's stdout.  Runs BEFORE anything in this process touches the GPU — the device count comes from the KFD
+    topology in sysfs (visible_gpu_count), not from the HIP runtime — and never replaces this process with another
+    program.  Returns the exit code: 0 only if every rank exited 0."""
     import subprocess
     import threading
     if not dry:
-        n_dev = torch.cuda.device_count()
-        if n_dev < n and os.environ.get("DVAE_ALLOW_SHARED_GPU", "0") != "1":
+        n_dev = visible_gpu_count()
+        if n_dev is not None and n_dev < n and os.environ.get("DVAE_ALLOW_SHARED_GPU", "0") != "1":
             log(f"--gpus {n} but only {n_dev} GPU(s) are visible: one process per GPU is the design")
             return 2
     port = _free_port()
@@ -277,6 +302,7 @@ def build_trainer(dev, B, T, dtype, world=1, rank=0, force_ddp=False):
     return w
 
 
+WATCHDOG_RC = 5      # exit code of every rank when the watchdog over the exchange variants fired (a wedged collective)
 L2_CU_TBPS = (17.0, 18.8)     # XCD L2 -> CU delivery, chip-wide (256 CUs x 66-73 GB/s, MI355X_MICROARCH.md)
 LSTM_KINDS = {0: "frame launches, forward", 1: "frame launches, backward", 2: "W_hh-resident persistent launch, forward",
               3: "W_hh-resident persistent launch, backward", 4: "H=64 whole-sequence launch, forward",
@@ -534,12 +560,19 @@ def main():
         wd = {"elapsed": elapsed, "last": last, "launch": launch, "now": "setup"}
 
         def variants_wedged():
+            # A wedged GPU process is NOT rc 0: rank 0 prints the marked line of what was measured (a complete timed region
+            # of at least the first variant), then every rank leaves with WATCHDOG_RC.  The other ranks wait a moment
+            # first, so that neither this repository's launcher nor torch.distributed.run (both stop the remaining ranks
+            # at the first non-zero exit) can take rank 0 down before its line is out.
             if rank == 0:
-                ex = dict(extra, ddp_variants_ms_per_step=dict(variants),
-                          variant_watchdog=f"fired during {wd['now']}: the line is the fastest variant measured until then")
+                ex = dict(extra, ddp_variants_ms_per_step=dict(variants), variant_watchdog_rc=WATCHDOG_RC,
+                          variant_watchdog=f"fired during {wd['now']}: the line is the fastest variant measured until then; "
+                                           f"every rank exits {WATCHDOG_RC}")
                 print(json.dumps(_result(args, world, B, T, dtype, n_params, wd["elapsed"], wd["last"], wd["launch"], ex, None)),
                       flush=True)
-            os._exit(0)      # (every rank: the line says what happened; a non-zero rank must not void it)
+            else:
+                time.sleep(3.0)
+            os._exit(WATCHDOG_RC)
         vdog = threading.Timer(float(os.environ.get("DVAE_BENCH_VARIANT_TIMEOUT", "300")), variants_wedged)
         vdog.daemon = True
         vdog.start()
@@ -554,6 +587,9 @@ def main():
                 for _ in range(2):
                     w.step_async(x1, x2, spk)
                 el_v, last_v, _ = timed(args.steps)
+                # a sharded step leaves every rank with current Adam moments for its own slices only: collect them, or the
+                # full-Adam variants and measurements that follow would run on replicas that drift apart
+                r2.gather_moments(w.optimizer)
                 variants[v] = 1e3 * el_v / args.steps
                 log(f"rank {rank}: {v}: {variants[v]:.2f} ms")
                 if el_v < elapsed:
@@ -565,9 +601,7 @@ def main():
         wd["now"] = "the measurements after the variants"
         extra["ddp_variants_ms_per_step"] = variants
         red.issue = os.environ.get("DVAE_DDP_ISSUE", "finish")
-        w.attach_reducer(red)
-        if red.mode != "rs_ag":
-            w.optimizer.fold_zero_grad = True
+        w.attach_reducer(red)            # (sets fold_zero_grad for the reducer's mode, both directions)
         # graph attempt, guarded three ways: try/except around the capture, agreement of all ranks, and a watchdog that
         # prints the eager-only line and ends the process if the attempt hangs
         # OPT-IN (DVAE_BENCH_DDP_GRAPH=1): no multi-rank run has shown the captured step equal to the eager one, so it is
@@ -622,12 +656,39 @@ def main():
         extra["ms_per_step_no_allreduce"] = 1e3 * el_nr / n_nr
         extra["allreduce_exposed_ms"] = ms_eager - 1e3 * el_nr / n_nr
         extra["allreduce_exposed_variant"] = next(iter(variants))          # the first variant measured (ms_eager)
+        # the single-rank product step (hipGraph replay, no reducer) in THIS process, every rank at once on its own GPU: what
+        # `value` is to be held against (the driver computes the efficiency itself from its own N = 1 run; DVAE_BENCH_N1_MS
+        # supplies a number measured elsewhere instead)
+        n1_ms, n1_src = None, None
+        if os.environ.get("DVAE_BENCH_N1_MS"):
+            n1_ms, n1_src = float(os.environ["DVAE_BENCH_N1_MS"]), "DVAE_BENCH_N1_MS (supplied)"
+        elif args.graph:
+            try:
+                w.attach_reducer(None)
+                w.enable_graph(True)
+                for _ in range(3):
+                    w.step_async(x1, x2, spk)
+                el_1, _, _ = timed(n_nr)
+                n1_ms = 1e3 * el_1 / n_nr
+                n1_src = (f"in-process: {n_nr} graph-replayed steps with the reducer detached, all {world} ranks at once "
+                          "(max over ranks)")
+            except Exception as e:
+                extra["scaling_vs_n1_error"] = repr(e)[:200]
+            w.enable_graph(False)
+            w.attach_reducer(red)
+        if n1_ms:
+            n1_value = B / (n1_ms * 1e-3)
+            extra["scaling_vs_n1"] = {"n1_ms_per_step": n1_ms, "n1_value": n1_value, "source": n1_src,
+                                      "speedup": (world * B * args.steps / elapsed) / n1_value, "ideal": world}
         ops.lstm_pers_check()
         vdog.cancel()
 
     roof = roof_lstm = None
-    if not args.no_roofline and rank == 0 and not dp:
+    if dp:
+        w.attach_reducer(None)           # the roofline pass below runs on rank 0 alone: no collective in it
+    if not args.no_roofline and rank == 0:
         # the SAME kernels, timed with HIP events around every launch over eager steps right after the timed region
+        # (N > 1: rank 0's, with the reducer detached; the other ranks wait in the final barrier)
         prof_steps = min(args.steps, 3)
         tags, (ms, launches, flops), tags2, tot2 = profile_families(w, x1, x2, spk, ops, prof_steps)
         roof_lstm = lstm_roofline(tags2, tot2, prof_steps)
@@ -683,17 +744,18 @@ def main():
                 except Exception as e:      # never lose the headline line to a side measurement
                     others.append({"config": name, "error": repr(e)[:300]})
             out["other_configs"] = others
-        if not dp and not args.no_cpu_baseline:
+    if dp:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            # (N > 1: after the process group is gone — the other ranks have left, the host cores are free)
             log("timing the CPU oracle on the host cores (child processes, bounded)")
             cb = cpu_baseline(B, T)
             out["cpu_baseline"] = cb
             if cb.get("value"):
                 out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
         final_line = json.dumps(out)
-    if dp:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
         # RCCL writes a banner through C stdio, which sits in libc's buffer until exit: flush it first so that the
         # JSON line is the LAST line of stdout
         try:

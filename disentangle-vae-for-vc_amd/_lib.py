@@ -133,6 +133,8 @@ DEV_SIGNATURES = {
     "dvae_probe_mfma_bf16": (i32, [i32, i32, i32, vp, vp, vp]),
     "dvae_probe_coissue": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "dvae_lstm_pers_set_ts": (i32, [vp, i32]),
+    "dvae_lstm_pers_set_dbg": (i32, [vp, vp, i32, i32]),
+    "dvae_lstm_pers_ws_bytes_slots": (i64, [i32, i32, i32]),
 }
 
 
@@ -144,7 +146,9 @@ def build(force: bool = False) -> str:
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
-    subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")])
+    # force: every object is recompiled (FORCE=1), not just relinked from objects a previous build left behind
+    env = dict(os.environ, FORCE="1") if force else None
+    subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")], env=env)
     return LIB_PATH
 
 

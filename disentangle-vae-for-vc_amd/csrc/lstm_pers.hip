@@ -71,6 +71,13 @@ struct PersArgs {
   unsigned long long* ts;   // dev build: [frame][wave][8] s_memrealtime stamps of workgroup ts_bid (scripts/lstm_pers_timeline.py)
   int ts_bid;
 #endif
+#ifdef DVAE_DEV
+  // dev build, fp32x3 forward only (scripts/x3_fwd16_diag2.py): what every consumer had in its registers, frame by frame
+  unsigned* dbg;            // [frame][workgroup][thread][12]: xor-fold of the loaded fragments (4), pre-activations used (4), gate sums (4)
+  unsigned* dbg_frag;       // [frame][row group][wave][unit*3 + plane][lane][4]: the raw fragments of workgroups with jb == dbg_jb
+  int dbg_jb;
+  int nslot;                // ring slots (2; T = one per frame: no address is reused inside a launch)
+#endif
 };
 
 #ifdef DVAE_PERS_TS
@@ -713,6 +720,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
       }
     }
 
+#ifdef DVAE_DEV
+    if (a.dbg) *reinterpret_cast<f32x4*>(a.dbg + (((int64_t)step * gridDim.x + bid) * 256 + tid) * 12 + 4) = f32x4{x[0][0], x[0][1], x[0][2], x[0][3]};
+#endif
     PERS_STAMP(0);
     if (step > 0) {
       if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
@@ -722,7 +732,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
       __syncthreads();                                             // barrier A
       PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef DVAE_DEV
+      const int so = ((step - 1) % a.nslot) * slot_bytes;
+      u32x4v dbg_ck = {0u, 0u, 0u, 0u};
+#else
       const int so = ((step - 1) & 1) * slot_bytes;
+#endif
       // unit u = (chunk k, row tile mt) = three 1-KiB fragments (the planes of h); RD units in flight
       bf16x8 av[RD][3];
       auto load = [&](int u) {
@@ -753,12 +768,26 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], w2[g], acc[mt][g], 0, 0, 0);
           acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][2], W01[g][k][0], acc[mt][g], 0, 0, 0);
         }
+#ifdef DVAE_DEV
+        if (a.dbg) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const u32x4v raw = __builtin_bit_cast(u32x4v, av[u % RD][p]);
+            dbg_ck ^= raw;
+            if (a.dbg_frag && jb == a.dbg_jb)
+              *reinterpret_cast<u32x4v*>(a.dbg_frag + (((((int64_t)step * a.n_rb + rb) * NWV + wave) * (KW * MT * 3) + u * 3 + p) * 64 + lane) * 4) = raw;
+          }
+        }
+#endif
         if (u + RD < KW * MT) {
           __builtin_amdgcn_sched_barrier(0);
           load(u + RD);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+#ifdef DVAE_DEV
+      if (a.dbg) *reinterpret_cast<u32x4v*>(a.dbg + (((int64_t)step * gridDim.x + bid) * 256 + tid) * 12) = dbg_ck;
+#endif
     } else {
       fetch(min(step + 1, T - 1), x);
     }
@@ -801,6 +830,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
         for (int sl = 0; sl < NWV - 1; ++sl) sacc += L.red[wave][sl][g][lane];
         if constexpr (MT == 2) { gs[g][0] = sacc[0]; gs[g][1] = sacc[1]; } else { gs[g][0] = sacc; }
       }
+#ifdef DVAE_DEV
+      if (a.dbg) *reinterpret_cast<f32x4*>(a.dbg + (((int64_t)step * gridDim.x + bid) * 256 + tid) * 12 + 8) = f32x4{gs[0][0], gs[1][0], gs[2][0], gs[3][0]};
+#endif
 #pragma unroll
       for (int i = 0; i < NEL; ++i) {
         const float gi = gate_sigmoid(gs[0][i]);
@@ -828,7 +860,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
     PERS_STAMP(5);
     if (wave == 0) {
       if ((step + 1 < T) && (bid != a.drop_bid)) {
+#ifdef DVAE_DEV
+        const int so = (step % a.nslot) * slot_bytes;
+#else
         const int so = (step & 1) * slot_bytes;
+#endif
         if (lane < 32) {                // lane (r, q' in {0,1}): units 8q'..8q'+7 of row r
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
@@ -1682,6 +1718,11 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
 unsigned long long* g_pers_ts = nullptr;
 int g_pers_ts_bid = 0;
 #endif
+#ifdef DVAE_DEV
+unsigned* g_pers_dbg = nullptr;
+unsigned* g_pers_dbg_frag = nullptr;
+int g_pers_dbg_jb = 0, g_pers_nslot = 2;
+#endif
 int g_pers_cus = -1;
 int pers_cu_count() {
   if (g_pers_cus < 0) {
@@ -1858,6 +1899,14 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   a.timeout = us > 40000000u ? 4000000000u : us * 100u;
   const int64_t slot = pers_slot_bytes(kind, N, H, mt);
   a.xch_bytes = (int)(2 * slot);
+#ifdef DVAE_DEV
+  a.nslot = 2;
+  if (kind == 2) {      // diagnostics of the fp32x3 forward kernel (dvae_lstm_pers_set_dbg)
+    a.dbg = g_pers_dbg; a.dbg_frag = g_pers_dbg_frag; a.dbg_jb = g_pers_dbg_jb;
+    a.nslot = g_pers_nslot > 2 ? g_pers_nslot : 2;
+    a.xch_bytes = (int)(a.nslot * slot);     // (the caller sized the workspace: dvae_lstm_pers_ws_bytes_slots)
+  }
+#endif
   a.drop_bid = drop_bid;
 #ifdef DVAE_PERS_TS
   a.ts = g_pers_ts;
@@ -1904,6 +1953,18 @@ DVAE_API int dvae_lstm_pers_selftest(const dvae_lstm_dir_t* dir, int T, int N, i
   if (!dir) return DVAE_EINVAL;
   return dvae_pers_launch(*dir, false, T, N, H, ldh, drop_bid, (hipStream_t)stream);
 }
+
+#ifdef DVAE_DEV
+// dev build only (scripts/x3_fwd16_diag2.py): register dumps of the fp32x3 forward kernel, ring with `nslot` slots
+DVAE_API int dvae_lstm_pers_set_dbg(void* dbg, void* dbg_frag, int dbg_jb, int nslot) {
+  g_pers_dbg = (unsigned*)dbg;
+  g_pers_dbg_frag = (unsigned*)dbg_frag;
+  g_pers_dbg_jb = dbg_jb;
+  g_pers_nslot = nslot;
+  return DVAE_OK;
+}
+DVAE_API int64_t dvae_lstm_pers_ws_bytes_slots(int N, int H, int nslot) { return pers_ws_need(nslot, N, H); }
+#endif
 
 #ifdef DVAE_PERS_TS
 // dev build only (scripts/lstm_pers_timeline.py): stamps of workgroup `bid` go to buf[frame][wave][8]

@@ -64,10 +64,13 @@ class VariationalBaseModelVAE:
     # ---- data parallel (new functionality: the reference is single-device)
     def attach_reducer(self, reducer):
         self.reducer = reducer
-        if reducer is not None and getattr(reducer, "mode", "all_reduce") == "rs_ag" and self.optimizer is not None:
-            # a sharded step reads (and could clear) only this rank's slices of the gradient buffer: zero_grad launches
-            self.optimizer.fold_zero_grad = False
-            self.optimizer._clean = False
+        if self.optimizer is not None:
+            # a sharded step (rs_ag) reads — and could clear — only this rank's slices of the gradient buffer: zero_grad
+            # launches every step then; any other reducer (or none) lets the Adam launch clear what it has read
+            sharded = reducer is not None and getattr(reducer, "mode", "all_reduce") == "rs_ag"
+            if self.optimizer.fold_zero_grad == sharded:
+                self.optimizer.fold_zero_grad = not sharded
+                self.optimizer._clean = False
 
     def enable_graph(self, flag: bool = True, ddp=None):
         """Capture the train step into a hipGraph on its second call and replay it afterwards.  The first call runs

@@ -566,10 +566,14 @@ LSTM_PERSISTENT = os.environ.get("DVAE_LSTM_PERSISTENT", "1") != "0"
 
 
 def _ranks_share_a_gpu() -> bool:
-    """More ranks on this node than visible GPUs (a functional check, never the product set-up): two persistent grids
-    each want every CU of the device, neither becomes resident, both run into their bounded waits."""
+    """More ranks on this NODE than visible GPUs (a functional check, never the product set-up): two persistent grids
+    each want every CU of the device, neither becomes resident, both run into their bounded waits.  Decided from
+    LOCAL_WORLD_SIZE only (torch.distributed.run and this repository's launchers export it): WORLD_SIZE counts the ranks of
+    every node, and a multi-node job must not lose its persistent recurrences to it."""
     try:
-        n_local = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        if "LOCAL_WORLD_SIZE" not in os.environ:
+            return False
+        n_local = int(os.environ["LOCAL_WORLD_SIZE"])
         n_dev = torch.cuda.device_count()          # does not initialise HIP
         return n_dev > 0 and n_local > n_dev
     except Exception:
@@ -577,6 +581,10 @@ def _ranks_share_a_gpu() -> bool:
 
 
 if _ranks_share_a_gpu():
+    import warnings
+    warnings.warn(f"dvae_amd: LOCAL_WORLD_SIZE={os.environ.get('LOCAL_WORLD_SIZE')} ranks share {torch.cuda.device_count()} "
+                  "visible GPU(s): the W_hh-resident persistent recurrences are switched OFF (one launch per frame, much "
+                  "slower) — a functional check, not the product set-up")
     LSTM_PERSISTENT = False
 LSTM_PERS_TIMEOUT_US = 0                    # 0: the library's default bound (2 s) on every cross-workgroup wait
 _PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the workspace any supported (N, H) needs

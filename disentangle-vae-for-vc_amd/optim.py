@@ -67,6 +67,7 @@ class FlatAdam:
         # [t, 1-b1^t, sqrt(1-b2^t), -, lr, grad_scale, -, -]
         self.dev_state = torch.zeros(8, device=dev, dtype=torch.float32)
         self._dev_scalars = None           # (lr, grad_scale) as last written to dev_state[4:6]
+        self._pin, self._pin_ev, self._pin_i = None, None, 0      # pinned staging slots of sync_scalars
         # True: the zero_grad ranges of flat_g are known to be zero (the last Adam launch cleared them after reading and no
         # backward kernel has accumulated since: ops._grad_buf resets it) — zero_grad() is then free
         self._clean = False
@@ -105,6 +106,11 @@ class FlatAdam:
 
     def zero_grad(self, set_to_none: bool = False):
         # gradients are accumulated by the HIP backward kernels directly into flat_g
+        # a step starts here: the written-exactly-once count of the store-first gradients starts from zero, whatever an
+        # abandoned attempt (a capture that failed after backward, an exception between backward and step) left behind
+        for p in self.params:
+            if getattr(p, "_dvae_grad_store_first", False):
+                p._dvae_sf_writes = 0
         if self._clean:
             return      # the previous step's Adam launch cleared these ranges and nothing has accumulated since
         for lo, hi in self._zero_ranges:
@@ -120,7 +126,22 @@ class FlatAdam:
         lr = float(self.param_groups[0]["lr"])
         gs = float(self._dev_scalars[1] if (grad_scale is None and self._dev_scalars) else (grad_scale or 1.0))
         if self._dev_scalars != (lr, gs):
-            self.dev_state[4:6].copy_(torch.tensor([lr, gs], dtype=torch.float32), non_blocking=False)
+            if self.dev_state.is_cuda:
+                # staged through a small ring of PINNED slots, asynchronously: a per-step schedule must not stall the host
+                # behind a pageable copy every step; a slot is reused only after the copy that read it has completed
+                if self._pin is None:
+                    self._pin = torch.empty(16, 2, dtype=torch.float32, pin_memory=True)
+                    self._pin_ev = [None] * 16
+                i = self._pin_i = (self._pin_i + 1) % 16
+                if self._pin_ev[i] is not None:
+                    self._pin_ev[i].synchronize()
+                self._pin[i, 0], self._pin[i, 1] = lr, gs
+                self.dev_state[4:6].copy_(self._pin[i], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pin_ev[i] = ev
+            else:
+                self.dev_state[4:6].copy_(torch.tensor([lr, gs], dtype=torch.float32))
             self._dev_scalars = (lr, gs)
 
     def _store_first_guard(self):

@@ -125,6 +125,31 @@ def setup_data_parallel(vsc, seed):
     return rank, world
 
 
+def _abort_process_group():
+    """Best effort, never blocks: abort the communicators of a failing rank (no collective, no barrier)."""
+    try:
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return
+        pg = dist.distributed_c10d._get_default_group()
+        be = None
+        try:
+            be = pg._get_backend(torch.device("cuda"))
+        except Exception:
+            pass
+        for obj in (be, pg):
+            for name in ("abort", "_abort", "_shutdown"):
+                fn = getattr(obj, name, None)
+                if callable(fn):
+                    try:
+                        fn()
+                        return
+                    except Exception:
+                        pass
+    except Exception:
+        pass
+
+
 def main(argv=None):
     args = get_parse().parse_args(argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,12 +205,19 @@ def main(argv=None):
                                     estimation_dir=os.path.join(args.log_dir, "images", "estimation"))
         if args.convert:
             raise SystemExit("--convert (mel conversion + vocoder) is outside the training hot path (SURVEY.md §8f-3)")
-    finally:
+    except BaseException:
+        # A rank that FAILS must not enter a barrier: its peers are inside an all-reduce / reduce-scatter, not a barrier, and
+        # the mismatched collective would hold this rank (and its traceback) until the RCCL timeout.  Tear the group down
+        # without synchronising and leave with the exception: the non-zero exit makes the launcher (launch_ranks /
+        # torch.distributed.run) stop the other ranks.
         if dp:
-            import torch.distributed as dist
-            if dist.is_initialized():
-                dist.barrier()
-                dist.destroy_process_group()
+            _abort_process_group()
+        raise
+    if dp:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
     return hist
 
 

@@ -21,6 +21,11 @@ int dvae_probe_coissue(int blocks, int iters, int which, int prio, float* out, u
 int dvae_probe_mfma_bf16(int blocks, int iters, int pattern, float* out, unsigned long long* out2, void* stream);
 /* stamps of workgroup `bid` of the persistent LSTM launches go to buf[frame][wave 0..7][8] (s_memrealtime, 100 MHz) */
 int dvae_lstm_pers_set_ts(void* buf, int bid);
+/* fp32x3 forward persistent kernel: register dumps (dbg[frame][workgroup][thread][12 words]: xor-fold of the loaded h fragments,
+ * the pre-activations used, the gate sums; dbg_frag[frame][row group][wave][unit*3+plane][lane][4 words]: raw fragments of the
+ * workgroups with jb == dbg_jb) and a ring of nslot slots instead of two (scripts/x3_fwd16_diag2.py); NULL / 2 switch it off */
+int dvae_lstm_pers_set_dbg(void* dbg, void* dbg_frag, int dbg_jb, int nslot);
+int64_t dvae_lstm_pers_ws_bytes_slots(int N, int H, int nslot);
 #ifdef __cplusplus
 }
 #endif

@@ -66,7 +66,7 @@ def test_train_cli_gpus_2_launches_two_sharded_ranks(tmp_path):
     assert osd["t"] == 4, osd["t"]
 
 
-def _bench_two_ranks(env_extra, frames="64", batch="4"):
+def _bench_two_ranks(env_extra, frames="64", batch="4", rc=0):
     """`bench.py --gpus 2` as the driver starts it for N = 1 (no rendezvous in the environment: bench.py launches the two
     ranks itself); the box has one GPU, so the ranks share it and exchange through gloo — a functional check of the N > 1
     line, not a measurement."""
@@ -75,7 +75,7 @@ def _bench_two_ranks(env_extra, frames="64", batch="4"):
                **env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--batch", batch, "--frames", frames], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode == rc, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # ONE JSON line, from rank 0
     return json.loads(lines[0])
@@ -89,12 +89,26 @@ def test_bench_gpus_2_line_lists_every_exchange_variant():
     assert all(isinstance(x, float) and x > 0 for x in v.values()), v
     assert abs(out["ms_per_step"] - min(v.values())) < 1e-6 * out["ms_per_step"]       # the headline is the fastest
     assert "variant_watchdog" not in out
+    # the N > 1 line carries everything the N = 1 line does: the contraction family's roofline (rank 0,
+    # reducer detached), the recurrence family's, the CPU baseline (after the process group is gone), and the single-rank
+    # step of the same process to hold `value` against
+    rl = out["roofline"]
+    assert rl["bound"] == "mfma" and rl["achieved"] > 0 and 0 < rl["frac"] < 1 and rl["launches_per_step"] > 10
+    assert out["roofline_lstm"]["kernel_ms_per_step"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    sv = out["scaling_vs_n1"]
+    assert sv["n1_ms_per_step"] > 0 and sv["ideal"] == 2 and 0 < sv["speedup"] < 2.5, sv
+    n1_keys = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"}
+    assert n1_keys <= set(out), n1_keys - set(out)
 
 
 def test_bench_gpus_2_a_wedged_variant_does_not_cost_the_line():
     """DVAE_BENCH_VARIANT_TIMEOUT = 0.05 s: the watchdog fires while the second exchange variant is being set up or timed;
-    rank 0 must still print the (marked) line of the first variant's complete timed region, every rank must exit 0."""
-    out = _bench_two_ranks({"DVAE_BENCH_VARIANT_TIMEOUT": "0.05"})
+    rank 0 must still print the (marked) line of the first variant's complete timed region — and every rank must then
+    leave with the watchdog's exit code, which the launcher hands on: a wedged GPU process is not rc 0."""
+    out = _bench_two_ranks({"DVAE_BENCH_VARIANT_TIMEOUT": "0.05"}, rc=5)
     assert out["n_gpus"] == 2 and out["value"] > 0
-    assert "fired during" in out["variant_watchdog"]
+    assert "fired during" in out["variant_watchdog"] and out["variant_watchdog_rc"] == 5
     assert "all_reduce:finish" in out["ddp_variants_ms_per_step"]      # the first one measured

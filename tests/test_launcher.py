@@ -53,3 +53,28 @@ def test_train_cli_has_the_data_parallel_flags():
     a = train.get_parse().parse_args(["--gpus", "4", "--batch-size", "8"])
     assert a.gpus == 4 and a.gpu_loader == -1
     assert callable(train.launch_ranks) and callable(train.setup_data_parallel)
+
+
+def test_launcher_counts_gpus_without_the_hip_runtime(tmp_path, monkeypatch):
+    """The launcher process never touches the HIP runtime: the device count comes from the KFD topology in sysfs (nodes with
+    SIMDs), cut down by the *_VISIBLE_DEVICES lists; None (then --gpus is trusted) where there is no topology."""
+    sys.path.insert(0, ROOT)
+    import bench
+    src = open(BENCH).read()
+    body = src[src.index("def launch_ranks("):src.index("def dry_launch(")]
+    assert "torch.cuda" not in body                      # nothing of the runtime in the launcher
+    import glob as _glob
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 256, 256, 256)):   # two CPU nodes, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real = _glob.glob
+    monkeypatch.setattr(_glob, "glob", lambda pat: real(str(nodes / "*" / "properties")) if "kfd" in pat else real(pat))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count() == 2
+    monkeypatch.setattr(_glob, "glob", lambda pat: [] if "kfd" in pat else real(pat))
+    assert bench.visible_gpu_count() is None
