@@ -87,15 +87,35 @@ struct PersArgs {
 #endif
 
 // wave-level bounded poll: lanes with `active` re-read their word until every one of them has reached `target`
+// (flags count frames over ALL launches — see pers_epoch — so the comparison is the wrap-safe one)
 __device__ __forceinline__ bool poll_ge(const unsigned* p, bool active, unsigned target, unsigned timeout) {
   unsigned v = active ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-  if (__all(v >= target)) return true;
+  if (__all((int)(v - target) >= 0)) return true;
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   for (unsigned it = 1;; ++it) {
     __builtin_amdgcn_s_sleep(1);
     v = active ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-    if (__all(v >= target)) return true;
+    if (__all((int)(v - target) >= 0)) return true;
     if ((it & 15) == 0 && (__builtin_amdgcn_s_memrealtime() - t0) > timeout) return false;
+  }
+}
+
+// EPOCH of the flags (round 5: no clearing launch in front of a persistent launch).  A flag holds `epoch + frames published`,
+// where `epoch` (word 8 of the error record) is what every workgroup reads when it starts and what the LAST workgroup to
+// finish (word 9 counts them) advances by T + 1 — not workgroup 0: a workgroup of another row group may not even have started
+// when workgroup 0 is done.  Whatever an earlier launch left in a flag is below the epoch of every later launch.
+constexpr int PERS_EPOCH_WORD = 8, PERS_DONE_WORD = 9;
+__device__ __forceinline__ unsigned pers_epoch(const PersArgs& a) {
+  return __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.err + PERS_EPOCH_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void pers_finish(const PersArgs& a) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned d = atomicAdd(a.err + PERS_DONE_WORD, 1u);
+    if (d == gridDim.x - 1) {
+      __hip_atomic_store(a.err + PERS_DONE_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(a.err + PERS_EPOCH_WORD, (unsigned)a.T + 1u);
+    }
   }
 }
 
@@ -169,6 +189,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
   FwdLds<MT, KL>& L = *reinterpret_cast<FwdLds<MT, KL>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
 
   // resident W_hh fragments: gate g, 16-unit tile u, chunk k of this wave's k-quarter
   bf16x8 W[4][2][KR];
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 1, bid, step, wave);
         *dead = 1;
       }
@@ -318,7 +339,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through payload has left before the flag does
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else if (wave == 1 && s16) {
 #pragma unroll
@@ -355,6 +376,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
     if (!frame(step, xa, xb)) break;
     if (step + 1 < T && !frame(step + 1, xb, xa)) break;
   }
+  pers_finish(a);
 }
 
 // ======================================================================================================================
@@ -391,6 +413,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   BwdLds<MT, KL>& L = *reinterpret_cast<BwdLds<MT, KL>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
   if (tid < 128) L.bsum[tid >> 5][tid & 31] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the bias gradient: its elements' dG over all frames
 
@@ -456,7 +479,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
@@ -554,7 +577,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
           }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else if (s16) {
       // waves 1..3 archive dG[t] (bf16, whole 64-byte row pieces) for the weight-gradient / dx contractions
@@ -604,6 +627,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
       if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
     }
   }
+  pers_finish(a);
 }
 
 // ======================================================================================================================
@@ -649,6 +673,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
   X3Lds<KW, K2L, MT>& L = *reinterpret_cast<X3Lds<KW, K2L, MT>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
 
   // resident W_hh fragments: [(g*(H/16) + jb)][chunk][plane][lane][8]
   bf16x8 W01[4][KW][2], W2[4][K2R > 0 ? K2R : 1];
@@ -725,7 +750,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
 #endif
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 1, bid, step, wave);
         *dead = 1;
       }
@@ -876,7 +901,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     // the frame's outputs (activated gates, c, h), after the hand-off has left
@@ -893,7 +918,351 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
       }
     }
   }
+  pers_finish(a);
 }
+
+#ifdef DVAE_DEV
+// ======================================================================================================================
+// SENTINEL hand-off (round 5; DEV BUILD ONLY — measured slower than the flag protocol, kept as the reproducer of the 16-row
+// forward form's stale reads): the payload is its own flag.  Every ring word that is not yet this frame's data holds a
+// POISON no payload can contain (0xFFFFFFFF: two bf16 NaNs / an fp32 NaN with all mantissa bits set); a consumer loads
+// the fragments it needs straight into MFMA operand registers as before and looks at them: poison in any dword = not there
+// yet, load again.  No flag, no drain in front of it, no poll, no barrier between poll and loads — and a wave may ask for
+// the next frame's fragments BEFORE anybody has said they exist (speculative prefetch under the epilogue: for the slowest
+// workgroup of a row group, the one that sets the frame time, nearly everything is already there).
+//   ring   : FOUR slots; frame s lives in slot s & 3.
+//   publish: (wave 0, after barrier C of step s)  s_waitcnt vmcnt(0)  ->  data(s) into slot s & 3 (write-through, no drain)
+//            ->  poison into its own piece of slot (s+2) & 3.
+//   why that is enough: slot (s+2)&3 held frame s-2, whose last readers finished before they published frame s-1, and this
+//   workgroup has checked ALL of frame s-1 during step s: nobody reads those words any more.  A consumer asks for
+//   frame s+2 of this producer only after it has SEEN the producer's data(s+1), which was issued behind the vmcnt(0) that
+//   waited for the poison stores of step s: the poison is in memory before anybody can look for frame s+2 there, so a
+//   consumer sees poison or frame s+2, never frame s-2.  Slots 0 and 1 are poisoned by a small launch in front (every
+//   other slot by the producers themselves: step 0 poisons slot 2, step 1 slot 3, step 2 slot 0 ...).
+//   check  : every dword of every 16-byte piece (a torn 16-byte store would show as poison in some dword).
+//   waiting: the first lane that still sees poison re-reads ITS three pieces alone (one lane: no bandwidth) until they carry
+//            data, then the wave loads the unit again; bounded like every wait here.
+// The unit order of the wave that owns this workgroup's own chunk is rotated so that the own chunk comes LAST: it is never
+// part of the speculative prefetch (which runs before the workgroup has published).
+// ======================================================================================================================
+constexpr unsigned PERS_POISON = 0xFFFFFFFFu;
+constexpr int PERS_NSLOT_S = 4;
+
+__device__ __forceinline__ unsigned umax4(const u32x4v& v) {
+  const unsigned a = v[0] > v[1] ? v[0] : v[1], b = v[2] > v[3] ? v[2] : v[3];
+  return a > b ? a : b;
+}
+
+// wave-level: (re)load the NP pieces of one unit until none of them holds poison; `ld(p)` loads piece p for every active lane
+template <int NP, class LD>
+__device__ __forceinline__ bool sent_wait(u32x4v (&v)[NP], LD ld, int lane, unsigned timeout) {
+  auto poisoned = [&]() {
+    unsigned m = umax4(v[0]);
+#pragma unroll
+    for (int p = 1; p < NP; ++p) {
+      const unsigned x = umax4(v[p]);
+      m = x > m ? x : m;
+    }
+    return m == PERS_POISON;
+  };
+  bool bad = poisoned();
+  if (__builtin_expect(!__any(bad), 1)) return true;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const uint64_t mask = __ballot(bad);
+    if (!mask) return true;
+    const int first = __builtin_ctzll(mask);
+    bool gave_up = false;
+    if (lane == first) {
+      for (unsigned it = 1;; ++it) {
+        __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = ld(p);
+        if (!poisoned()) break;
+        if ((it & 15) == 0 && (__builtin_amdgcn_s_memrealtime() - t0) > timeout) { gave_up = true; break; }
+      }
+    }
+    if (__any(gave_up)) return false;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) v[p] = ld(p);
+    bad = poisoned();
+  }
+}
+
+template <int H, int K2L, int MT = 2>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3s(const PersArgs a) {
+  constexpr int NCH = H / 32;           // 32-deep k-chunks of h
+  constexpr int KW = NCH / NWV;         // chunks per wave
+  constexpr int K2R = KW - K2L;         // chunks whose plane 2 stays in registers
+  constexpr int NEL = MT;
+  typedef typename x3_own<MT>::type own_t;
+  constexpr int NU = KW * MT;           // (chunk, row tile) units per wave and frame
+  constexpr int RD = PERS_RD_X3 < NU ? PERS_RD_X3 : NU;
+  constexpr int NPRE = RD < NU - MT ? RD : NU - MT;    // units asked for speculatively (never the last chunk: see above)
+  static_assert(NPRE >= 1, "speculative prefetch needs two chunks per wave");
+  const int T = a.T, N = a.N;
+  const int bid = blockIdx.x;
+  const int rb = bid % a.n_rb, jb = bid / a.n_rb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  X3Lds<KW, K2L, MT>& L = *reinterpret_cast<X3Lds<KW, K2L, MT>*>(lds_raw);
+  volatile int* dead = &L.dead;
+  if (tid == 0) *dead = 0;
+
+  // position kk of this wave's order is chunk wave*KW + (kk + koff) % KW: the workgroup's own chunk (jb >> 1) comes last
+  const int c_own = jb >> 1;
+  const int koff = (c_own / KW == wave) ? (c_own % KW + 1) % KW : 0;
+  auto chunk_of = [&](int kk) { return wave * KW + (kk + koff) % KW; };
+
+  bf16x8 W01[4][KW][2], W2[4][K2R > 0 ? K2R : 1];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const bf16x8 w = *reinterpret_cast<const bf16x8*>(
+            a.wp + (((((int64_t)(g * (H / 16) + jb)) * NCH + chunk_of(k)) * 3 + p) * 64 + lane) * 16);
+        if (p < 2) W01[g][k][p < 2 ? p : 0] = w;
+        else if (k < K2R) W2[g][k < K2R ? k : 0] = w;
+        else L.w2[wave][g][k >= K2R ? k - K2R : 0][lane] = w;
+      }
+
+  const int emt = MT == 2 ? (wave >> 1) : 0, e0 = MT == 2 ? (wave & 1) * 2 : wave;
+  const int erow0 = emt * 16 + q * 4 + e0;
+  int el_n[NEL];
+  bool el_ok[NEL];
+  float creg[NEL];
+#pragma unroll
+  for (int i = 0; i < NEL; ++i) {
+    el_ok[i] = rb * 16 * MT + erow0 + i < N;
+    el_n[i] = min(rb * 16 * MT + erow0 + i, N - 1);
+    creg[i] = 0.f;
+  }
+  const int j0 = jb * 16;
+  const int64_t H4 = 4 * (int64_t)H;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, a.xch_bytes, 0x00020000);
+  const int slot_bytes = a.n_rb * NCH * MT * 3 * 1024;          // fragment (chunk, mt, plane) = 1 KiB
+  const int xrow = rb * NCH * MT * 3 * 1024 + lane * 16;        // + (chunk * MT + mt) * 3072 + plane * 1024
+  int xoff[KW];                                                 // per position kk: byte offset of its chunk inside a slot
+#pragma unroll
+  for (int k = 0; k < KW; ++k) xoff[k] = chunk_of(k) * MT * 3 * 1024;
+  const int xst = ((rb * NCH + (jb >> 1)) * MT * 3) * 1024 + ((jb & 1) * 32 + lane) * 16;
+
+  auto fetch = [&](int step_, float (&x)[NEL][4]) {
+    const int t_ = a.reverse ? (T - 1 - step_) : step_;
+    const float* __restrict__ G_ = a.gates + (int64_t)t_ * N * H4 + j0 + r;
+#pragma unroll
+    for (int i = 0; i < NEL; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) x[i][g] = G_[(int64_t)el_n[i] * H4 + g * H];
+  };
+
+  u32x4v av[RD][3];                     // units in flight: live ACROSS frames (the speculative prefetch)
+  // unit u = (position kk = u / MT, row tile mt = u % MT) of the frame in slot `so`
+  auto load = [&](int u, int so) __attribute__((always_inline)) {
+    const int kk = u / MT, mt = u % MT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      av[u % RD][p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xrow, so + xoff[kk] + (mt * 3 + p) * 1024, 16);   // ONE address register
+  };
+
+#ifdef DVAE_DEV
+  // dev build: nslot > 4 = one ring slot per frame, all poisoned in front of the launch, none re-poisoned here (no address
+  // is written twice in a launch: scripts/x3_fwd16_diag2.py)
+  const bool per_frame = a.nslot > PERS_NSLOT_S;
+  auto slot_of = [&](int s_) { return (per_frame ? s_ % a.nslot : (s_ & (PERS_NSLOT_S - 1))) * slot_bytes; };
+#else
+  constexpr bool per_frame = false;
+  auto slot_of = [&](int s_) { return (s_ & (PERS_NSLOT_S - 1)) * slot_bytes; };
+#endif
+  float x[NEL][4];
+  fetch(0, x);
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = a.reverse ? (T - 1 - step) : step;
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 own = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (MT == 2) {
+        if (e0) { own[2] = x[0][g]; own[3] = x[1][g]; } else { own[0] = x[0][g]; own[1] = x[1][g]; }
+        acc[0][g] = emt ? f32x4{0.f, 0.f, 0.f, 0.f} : own;
+        acc[1][g] = emt ? own : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) own[e] = (e == e0) ? x[0][g] : 0.f;
+        acc[0][g] = own;
+      }
+    }
+
+    PERS_STAMP(0);
+    if (step > 0) {
+      const int so = slot_of(step - 1);
+      // units 0 .. NPRE-1 were asked for at the end of the previous step
+#pragma unroll
+      for (int u = NPRE; u < RD; ++u) load(u, so);
+      fetch(min(step + 1, T - 1), x);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 w2[4];
+      bool ok = true;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int k = u / MT, mt = u % MT;
+        if (mt == 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            w2[g] = (k < K2R) ? W2[g][k < K2R ? k : 0] : L.w2[wave][g][k >= K2R ? k - K2R : 0][lane];
+        }
+        ok = ok && sent_wait<3>(av[u % RD], [&](int p) __attribute__((always_inline)) {
+               return __builtin_amdgcn_raw_buffer_load_b128(xrs, xrow, so + xoff[k] + (mt * 3 + p) * 1024, 16); }, lane, a.timeout);
+#ifdef DVAE_DEV
+        if (a.dbg_frag && jb == a.dbg_jb) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p)      // (in the wave's OWN unit order: position kk, not chunk)
+            *reinterpret_cast<u32x4v*>(a.dbg_frag + (((((int64_t)step * a.n_rb + rb) * NWV + wave) * (NU * 3) + u * 3 + p) * 64 + lane) * 4) = av[u % RD][p];
+        }
+#endif
+        const bf16x8 h0 = __builtin_bit_cast(bf16x8, av[u % RD][0]), h1 = __builtin_bit_cast(bf16x8, av[u % RD][1]),
+                     h2 = __builtin_bit_cast(bf16x8, av[u % RD][2]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, W01[g][k][0], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, W01[g][k][1], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, W01[g][k][0], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1, W01[g][k][1], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0, w2[g], acc[mt][g], 0, 0, 0);
+          acc[mt][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h2, W01[g][k][0], acc[mt][g], 0, 0, 0);
+        }
+        if (u + RD < NU) {
+          __builtin_amdgcn_sched_barrier(0);
+          load(u + RD, so);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (!ok) {
+        pers_give_up(a.err, 1, bid, step, wave);
+        *dead = 1;
+      }
+    } else {
+      fetch(min(step + 1, T - 1), x);
+    }
+    // speculative prefetch of the next frame's first units (waves 1..3 here; wave 0 behind its publish below, which
+    // must not wait for these loads)
+    if (wave != 0 && step + 1 < T) {
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) load(u, slot_of(step));
+    }
+#pragma unroll
+    for (int o = 0; o < NWV; ++o) {
+      if (o == wave) continue;
+      const int slot = (wave - o - 1) & (NWV - 1);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if constexpr (MT == 2) {
+          const f32x4 v = acc[o >> 1][g];
+          L.red[o][slot][g][lane] = (o & 1) ? f32x2{v[2], v[3]} : f32x2{v[0], v[1]};
+        } else {
+          const f32x4 v = acc[0][g];
+          L.red[o][slot][g][lane] = o == 0 ? v[0] : o == 1 ? v[1] : o == 2 ? v[2] : v[3];
+        }
+      }
+    }
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
+    if (*dead) break;
+
+    float go_[NEL][4], co_[NEL], ho_[NEL];
+    {
+      float gs[4][NEL];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        own_t sacc;
+        if constexpr (MT == 2) {
+          f32x4 own = acc[0][g];
+          if (emt) own = acc[1][g];
+          sacc = e0 ? f32x2{own[2], own[3]} : f32x2{own[0], own[1]};
+        } else {
+          const f32x4 own = acc[0][g];
+          sacc = e0 == 0 ? own[0] : e0 == 1 ? own[1] : e0 == 2 ? own[2] : own[3];
+        }
+#pragma unroll
+        for (int sl = 0; sl < NWV - 1; ++sl) sacc += L.red[wave][sl][g][lane];
+        if constexpr (MT == 2) { gs[g][0] = sacc[0]; gs[g][1] = sacc[1]; } else { gs[g][0] = sacc; }
+      }
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const float gi = gate_sigmoid(gs[0][i]);
+        const float gf = gate_sigmoid(gs[1][i]);
+        const float gg = gate_tanh(gs[2][i]);
+        const float go = gate_sigmoid(gs[3][i]);
+        const float c = gf * creg[i] + gi * gg;
+        const float h = go * gate_tanh(c);
+        creg[i] = c;
+        const int row = erow0 + i;
+        const __bf16 h0 = (__bf16)h;
+        const float r1 = h - (float)h0;
+        const __bf16 h1 = (__bf16)r1;
+        const __bf16 h2 = (__bf16)(r1 - (float)h1);
+        L.hx[0][row >> 4][row & 15][r] = h0;
+        L.hx[1][row >> 4][row & 15][r] = h1;
+        L.hx[2][row >> 4][row & 15][r] = h2;
+        go_[i][0] = gi; go_[i][1] = gf; go_[i][2] = gg; go_[i][3] = go;
+        co_[i] = c; ho_[i] = h;
+      }
+    }
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
+    if (wave == 0 && step + 1 < T) {
+      if (bid != a.drop_bid) {
+        const int so = slot_of(step);
+        const int sp = slot_of(step + 2);
+        // the poison stores of the previous step (and everything older) have left: see the protocol above
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < 32) {                // lane (r, q' in {0,1}): units 8q'..8q'+7 of row r
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(&L.hx[p][mt][r][(q & 1) * 8]);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + (mt * 3 + p) * 1024, so, 16);
+            }
+          if (!per_frame) {
+            const u32x4v pz = {PERS_POISON, PERS_POISON, PERS_POISON, PERS_POISON};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int p = 0; p < 3; ++p) __builtin_amdgcn_raw_buffer_store_b128(pz, xrs, xst + (mt * 3 + p) * 1024, sp, 16);
+          }
+        }
+        PERS_STAMP(6);
+      }
+#pragma unroll
+      for (int u = 0; u < NPRE; ++u) load(u, slot_of(step));
+    }
+    // the frame's outputs (activated gates, c, h)
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+      if (el_ok[i]) {
+        float* gp = a.gates + ((int64_t)t * N + el_n[i]) * H4 + j0 + r;
+        gp[0] = go_[i][0];
+        gp[H] = go_[i][1];
+        gp[2 * H] = go_[i][2];
+        gp[3 * H] = go_[i][3];
+        a.c_all[((int64_t)t * N + el_n[i]) * H + j0 + r] = co_[i];
+        reinterpret_cast<float*>(a.h_out)[((int64_t)t * N + el_n[i]) * a.ldh + j0 + r] = ho_[i];
+      }
+    }
+  }
+}
+
+#endif      // DVAE_DEV (sentinel hand-off)
 
 // ======================================================================================================================
 // fp32 backward (the default arithmetic keeps the backward recurrence on the fp32 MFMA: it streams the 4H-wide gate
@@ -932,6 +1301,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
   F32BwdLds<KL>& L = *reinterpret_cast<F32BwdLds<KL>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
   if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -991,7 +1361,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
@@ -1080,7 +1450,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
           }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       // waves 1..3 archive dG[t] (fp32, 64-byte row pieces) for the weight-gradient / dx contractions
@@ -1118,6 +1488,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
       if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
     }
   }
+  pers_finish(a);
 }
 
 // ======================================================================================================================
@@ -1155,6 +1526,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
   X3BwdLds<K2L, MT>& L = *reinterpret_cast<X3BwdLds<K2L, MT>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
   if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -1220,7 +1592,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
@@ -1333,7 +1705,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
@@ -1370,6 +1742,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
       if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
     }
   }
+  pers_finish(a);
 }
 
 // ======================================================================================================================
@@ -1429,6 +1802,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
   X3KLds& L = *reinterpret_cast<X3KLds*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
   if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -1505,7 +1879,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPQ, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPQ, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
@@ -1597,7 +1971,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
           for (int mt = 0; mt < MT; ++mt)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, mine[mt]), xrs, inb_st, so + mt * 1024, 16);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_store(pf_out, (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_store(pf_out, epoch + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       PERS_STAMP(3);
@@ -1606,7 +1980,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) L.u.e.fin[kq][mt][lane] = mine[mt];
       }
-      if (wave == NWV - 1 && !poll_ge(pf_in, lane < 4 && lane != kq, (unsigned)step, a.timeout)) {
+      if (wave == NWV - 1 && !poll_ge(pf_in, lane < 4 && lane != kq, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
@@ -1674,7 +2048,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PERS_STAMP(7);
-        if (lane == 0) __hip_atomic_store(myflag, (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
@@ -1712,6 +2086,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
       if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
     }
   }
+  pers_finish(a);
 }
 
 #ifdef DVAE_PERS_TS
@@ -1748,10 +2123,17 @@ int pers_mt(int N, int H, int cus) {
 #define PERS_KL 2
 #endif
 
-__global__ __launch_bounds__(256) void pers_clear_kernel(unsigned* __restrict__ w, int n) {
-  for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(n, (int)(blockIdx.x + 1) * 1024); i += 256)
-    __hip_atomic_store(w + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef DVAE_DEV
+// sentinel kernels: the first two ring slots are poisoned in front of the launch (write-through 16-byte stores; every other
+// slot by the producers themselves)
+__global__ __launch_bounds__(256) void pers_poison_kernel(char* __restrict__ xch, int bytes) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)xch, 0, bytes, 0x00020000);
+  const u32x4v pz = {PERS_POISON, PERS_POISON, PERS_POISON, PERS_POISON};
+  for (int o = (blockIdx.x * 256 + threadIdx.x) * 16; o < bytes; o += gridDim.x * 256 * 16)
+    __builtin_amdgcn_raw_buffer_store_b128(pz, rs, o, 0, 16);
 }
+
+#endif
 
 // one launch: LDS padded so that exactly one workgroup fits a CU
 template <class K>
@@ -1776,6 +2158,12 @@ int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStrea
       if (H == 1024) return pers_go(lstm_pers_bwd_bf16<1024, 2, KL>, (int)sizeof(BwdLds<2, KL>), a, grid, s);
       if (mt == 1) return pers_go(lstm_pers_bwd_bf16<512, 1, 0>, (int)sizeof(BwdLds<1, 0>), a, grid, s);
       return pers_go(lstm_pers_bwd_bf16<512, 2, 0>, (int)sizeof(BwdLds<2, 0>), a, grid, s);
+#ifdef DVAE_DEV
+    case 12:     // fp32x3 forward, sentinel hand-off
+      if (H == 1024) return pers_go(lstm_pers_fwd_x3s<1024, 8>, (int)sizeof(X3Lds<8, 8>), a, grid, s);
+      if (mt == 1) return pers_go(lstm_pers_fwd_x3s<512, 0, 1>, (int)sizeof(X3Lds<4, 0, 1>), a, grid, s);
+      return pers_go(lstm_pers_fwd_x3s<512, 0>, (int)sizeof(X3Lds<4, 0>), a, grid, s);
+#endif
     case 2:
       if (H == 1024) return pers_go(lstm_pers_fwd_x3<1024, 8>, (int)sizeof(X3Lds<8, 8>), a, grid, s);
 #ifdef DVAE_DEV      // (the 16-row forward form is not in the product library: see dvae_pers_launch)
@@ -1846,7 +2234,7 @@ static int64_t pers_ws_need(int T, int N, int H) {
   if (pers_x3_ok(N, H, 256))
     for (int kind = 2; kind < 6; ++kind) slot = std::max(slot, pers_slot_bytes(kind, N, H, 2));
   if (!slot) return 0;
-  return PERS_XCH_OFF + (T > 0 ? (int64_t)T : 2) * slot;
+  return PERS_XCH_OFF + (T > 0 ? (int64_t)T : 4) * slot;      // (two slots in use; four sized: the dev build's sentinel form)
 }
 DVAE_API int64_t dvae_lstm_pers_ws_bytes(int N, int H) { return pers_ws_need(0, N, H); }
 
@@ -1915,13 +2303,24 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   const int grid = (kind < 2 ? H / 32 : H / 16) * a.n_rb;
   const size_t flag_bytes = kind == 5 ? (size_t)PERS_FLAG_BYTES      // + the partial flags behind the dG flags
                                       : (size_t)a.n_rb * (kind < 2 ? PERS_FLAG_LD : PERS_FLAG_LD_X3) * 4;
-  // The flags are cleared by a kernel of our own with write-through (agent-scope) stores, NOT by hipMemsetAsync: as a
-  // memset node of a replayed hipGraph the clear was not always in memory when the next node's workgroups polled — about 1
-  // replayed step in 100 read a flag of the PREVIOUS launch, went ahead and took that launch's rows out of the ring (a loss
-  // off by 1e-5; scripts/replay_stress.py with several inputs).  Eager launches never showed it.
-  const int n_words = (int)(flag_bytes / 4);
-  hipLaunchKernelGGL(pers_clear_kernel, dim3((n_words + 1023) / 1024), dim3(256), 0, s, (unsigned*)ws, n_words);
-  if (dvae_check_launch() != DVAE_OK) return DVAE_ELAUNCH;
+#ifdef DVAE_DEV
+  static const int sent = dvae_dev_knob("DVAE_PERS_SENT", 0);      // dev build: 1 = the sentinel hand-off form of the fp32x3 forward kernel
+  if (kind == 2 && (sent & 1)) {
+    // sentinel hand-off: no flags; four slots, the first two poisoned here
+    // (the caller sized the workspace with dvae_lstm_pers_ws_bytes: four slots of the largest kind)
+    a.xch_bytes = (int)(PERS_NSLOT_S * slot);
+    int pb = (int)(2 * slot);
+    if (a.nslot > PERS_NSLOT_S) {      // one slot per frame (dvae_lstm_pers_set_dbg): all of them poisoned here
+      a.xch_bytes = (int)(a.nslot * slot);
+      pb = a.xch_bytes;
+    }
+    hipLaunchKernelGGL(pers_poison_kernel, dim3(std::min(1024, (pb / 16 + 255) / 256)), dim3(256), 0, s, a.xch, pb);
+    if (dvae_check_launch() != DVAE_OK) return DVAE_ELAUNCH;
+    return pers_dispatch(12, H, mt, a, grid, s);
+  }
+#endif
+  // (no clearing launch: the flags carry the epoch of their launch, see pers_epoch)
+  (void)flag_bytes;
   return pers_dispatch(kind, H, mt, a, grid, s);
 }
 
@@ -1941,7 +2340,7 @@ DVAE_API int dvae_lstm_pers_check(void* ws, int* info4, void* stream) {
   if (info4)
     for (int i = 0; i < 4; ++i) info4[i] = (int)rec[i];
   if (rec[0] == 0) return DVAE_OK;
-  (void)hipMemsetAsync((char*)ws + PERS_ERR_OFF, 0, 64, s);      // reported: clear the sticky record
+  (void)hipMemsetAsync((char*)ws + PERS_ERR_OFF, 0, 16, s);      // reported: clear the sticky record (NOT the flags' epoch behind it)
   (void)hipStreamSynchronize(s);
   g_dvae_last_hip_error = 0;
   return DVAE_ELAUNCH;

@@ -66,11 +66,21 @@ class VariationalBaseModelVAE:
         self.reducer = reducer
         if self.optimizer is not None:
             # a sharded step (rs_ag) reads — and could clear — only this rank's slices of the gradient buffer: zero_grad
-            # launches every step then; any other reducer (or none) lets the Adam launch clear what it has read
+            # launches every step while such a reducer is attached; whatever the setting was before comes back with the
+            # next reducer that is not sharded (or with None), so switching modes back and forth leaves no trace
+            opt = self.optimizer
             sharded = reducer is not None and getattr(reducer, "mode", "all_reduce") == "rs_ag"
-            if self.optimizer.fold_zero_grad == sharded:
-                self.optimizer.fold_zero_grad = not sharded
-                self.optimizer._clean = False
+            if sharded:
+                if getattr(self, "_fold_before_shard", None) is None:
+                    self._fold_before_shard = bool(opt.fold_zero_grad)
+                if opt.fold_zero_grad:
+                    opt.fold_zero_grad = False
+                    opt._clean = False
+            elif getattr(self, "_fold_before_shard", None) is not None:
+                if opt.fold_zero_grad != self._fold_before_shard:
+                    opt.fold_zero_grad = self._fold_before_shard
+                    opt._clean = False
+                self._fold_before_shard = None
 
     def enable_graph(self, flag: bool = True, ddp=None):
         """Capture the train step into a hipGraph on its second call and replay it afterwards.  The first call runs

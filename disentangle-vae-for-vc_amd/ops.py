@@ -587,14 +587,15 @@ if _ranks_share_a_gpu():
                   "slower) — a functional check, not the product set-up")
     LSTM_PERSISTENT = False
 LSTM_PERS_TIMEOUT_US = 0                    # 0: the library's default bound (2 s) on every cross-workgroup wait
-_PERS_WS_BYTES = (1 << 20) + 2 * 16 * 128 * 2 * 1024     # >= the workspace any supported (N, H) needs
+_PERS_WS_BYTES = (1 << 20) + 4 * 16 * 128 * 2 * 1024     # >= the workspace any supported (N, H) needs (four ring slots)
 _pers_ws: dict = {}
 _pers_owner: dict = {}                      # device index -> the torch stream whose launches used the workspace last
 
 
 def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1, bwd: bool = False) -> bool:
     """`mode`: precision of the recurrent product of that pass (derived.lstm_pack_modes)."""
-    return bool(LSTM_PERSISTENT and ndir == 1 and lib().dvae_lstm_pers_supported(N, H, int(mode), int(bwd)))
+    return bool(LSTM_PERSISTENT and ndir == 1 and lib().dvae_lstm_pers_supported(N, H, int(mode), int(bwd))
+                and lib().dvae_lstm_pers_ws_bytes(N, H) <= _PERS_WS_BYTES)
 
 
 def lstm_pers_workspace(dev) -> torch.Tensor:

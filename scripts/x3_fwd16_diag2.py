@@ -24,9 +24,16 @@ ap.add_argument("--nodump", action="store_true")
 ap.add_argument("--nobwd", action="store_true")
 ap.add_argument("--mt1", type=int, default=3)
 ap.add_argument("--maxbad", type=int, default=4)
+ap.add_argument("--sent", type=int, default=0, help="1: the sentinel hand-off kernel (DVAE_PERS_SENT; --nslot > 4: a slot per frame)")
+ap.add_argument("--traffic", default="big", help="big: rnd %% 5 copies of 1 GiB in front of the round (x3_handoff_stress.py); "
+                "small: 48 copies of 32 MiB (a kernel boundary on the other stream every ~15 us of the launch); "
+                "delay: big + the round's own launches held back by rnd*37 %% 400 us of filler so that the copies' boundaries "
+                "fall inside the forward launch; none")
+ap.add_argument("--realloc", action="store_true", help="draw the gates anew every round (torch.rand, as x3_handoff_stress.py does)")
 args = ap.parse_args()
 os.environ.setdefault("DVAE_LIB_PATH", os.path.join(ROOT, "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
 os.environ["DVAE_PERS_X3_MT1"] = str(args.mt1)
+os.environ["DVAE_PERS_SENT"] = str(args.sent)
 sys.path.insert(0, ROOT)
 import torch
 import dvae_amd  # noqa: F401
@@ -53,7 +60,7 @@ gates = torch.empty_like(gates0)
 h, c = torch.empty(T * N, H, **f), torch.empty(T * N, H, **f)
 dg, dc, db = torch.empty(T * N, 4 * H, **f), torch.empty(N, H, **f), torch.zeros(2, 4 * H, **f)
 
-ws_bytes = int(L.dvae_lstm_pers_ws_bytes_slots(N, H, max(args.nslot, 2)))
+ws_bytes = int(L.dvae_lstm_pers_ws_bytes_slots(N, H, max(args.nslot, 4)))
 hip = None
 if args.uncached:
     # the HIP runtime torch already loaded (a second copy of the runtime in one process would be another runtime)
@@ -70,6 +77,21 @@ if args.uncached:
 else:
     ws_t = torch.zeros(ws_bytes, device="cuda", dtype=torch.uint8)
     ws_ptr = ws_t.data_ptr()
+def gpu_ids():
+    """unique_id of the GPU nodes of this box (KFD topology): which chip a failure was seen on"""
+    import glob
+    out = []
+    for path in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
+        try:
+            kv = dict(l.split()[:2] for l in open(path) if len(l.split()) >= 2)
+            if int(kv.get("simd_count", "0")) > 0:
+                out.append(hex(int(kv.get("unique_id", "0"))))
+        except Exception:
+            pass
+    return out
+
+
+print(f"box: {os.uname().nodename} gpu unique_id {gpu_ids()}", flush=True)
 print(f"H={H} T={T} N={N} MT={MT} grid={grid} nslot={args.nslot} ws={ws_bytes >> 10} KiB uncached={args.uncached} poison={args.poison}",
       flush=True)
 
@@ -81,7 +103,12 @@ DBG_JB = 5
 
 
 def run(pers, dump):
-    gates.copy_(gates0)
+    if args.realloc and pers:
+        g2 = torch.Generator(device="cuda").manual_seed(1000)
+        _ = (torch.rand(4 * H, H, generator=g2, **f) * 2 - 1) / H ** 0.5
+        gates.copy_(torch.rand(T * N, 4 * H, generator=g2, **f) * 2 - 1)
+    else:
+        gates.copy_(gates0)
     h.fill_(float("nan"))
     d = (_lib.LstmDir * 1)()
     d[0].gates, d[0].c_all, d[0].h_out, d[0].w_hh, d[0].w_packed = ptr(gates), ptr(c), ptr(h), ptr(w_hh), ptr(der.pack_f)
@@ -132,10 +159,10 @@ def analyse(rnd):
     diff = d != ref_dbg                                   # [T, grid, 256, 12]
     per_frame = diff.reshape(T, -1).any(dim=1).nonzero().flatten().tolist()
     if not per_frame:
-        print("     no dump differs from the quiet run: the inputs AND the sums were right, the outputs went wrong after that")
-        return
-    f0 = per_frame[0]
-    print(f"     first frame with a differing dump: {f0} (frames that differ: {len(per_frame)})")
+        print("     no per-thread dump differs from the quiet run" + (" (the sentinel kernel writes none)" if args.sent else
+              ": the inputs AND the sums were right, the outputs went wrong after that"))
+    else:
+        print(f"     first frame with a differing dump: {per_frame[0]} (frames that differ: {len(per_frame)})")
     for ff in per_frame[:2]:
         for name, sl in (("pre-activations used (x)", slice(4, 8)), ("fragment xor-fold (h loaded)", slice(0, 4)), ("gate sums", slice(8, 12))):
             dd = diff[ff, :, :, sl].any(dim=2)           # [grid, 256]
@@ -175,11 +202,19 @@ def analyse(rnd):
 side = torch.cuda.Stream()
 a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
 b = torch.empty_like(a)
+filler = torch.zeros(1 << 22, device="cuda")
 bad = 0
 for rnd in range(args.rounds):
     with torch.cuda.stream(side):
-        for _ in range(rnd % 5):
-            b.copy_(a)
+        if args.traffic in ("big", "delay"):
+            for _ in range(rnd % 5):
+                b.copy_(a)
+        elif args.traffic == "small":
+            for i in range(48):
+                b[i << 23:(i + 1) << 23].copy_(a[i << 23:(i + 1) << 23])
+    if args.traffic == "delay":
+        for _ in range((rnd * 37) % 400 // 8):
+            filler.add_(1.0)                      # ~8 us each on the launch stream: shifts the launches against the copies
     got_g, got_h = run(True, dump)
     e = (got_g - ref_g).abs().reshape(T, N, -1)
     if float(e.max()) <= tol:
@@ -199,4 +234,4 @@ for rnd in range(args.rounds):
     if bad >= args.maxbad:
         break
 torch.cuda.synchronize()
-print(f"RESULT nslot={args.nslot} uncached={args.uncached} poison={args.poison} dump={dump} bwd={not args.nobwd}: {bad} bad rounds of {rnd + 1}")
+print(f"RESULT sent={args.sent} traffic={args.traffic} realloc={args.realloc} nslot={args.nslot} uncached={args.uncached} poison={args.poison} dump={dump} bwd={not args.nobwd}: {bad} bad rounds of {rnd + 1}")
