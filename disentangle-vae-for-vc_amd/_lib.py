@@ -52,7 +52,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 305     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 306     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {

@@ -77,6 +77,7 @@ struct PersArgs {
   unsigned* dbg_frag;       // [frame][row group][wave][unit*3 + plane][lane][4]: the raw fragments of workgroups with jb == dbg_jb
   int dbg_jb;
   int nslot;                // ring slots (2; T = one per frame: no address is reused inside a launch)
+  int nodrain;              // TIMING EXPERIMENT ONLY (results may be wrong): the flag does not wait for the payload's acknowledgement
 #endif
 };
 
@@ -84,6 +85,12 @@ struct PersArgs {
 #define PERS_STAMP(p_) do { if (a.ts && bid == a.ts_bid && lane == 0) a.ts[((int64_t)step * 8 + wave) * 8 + (p_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PERS_STAMP(p_) do {} while (0)
+#endif
+
+#ifdef DVAE_DEV
+#define PERS_DRAIN() do { if (!a.nodrain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#else
+#define PERS_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
 // wave-level bounded poll: lanes with `active` re-read their word until every one of them has reached `target`
@@ -899,7 +906,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
               __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + (mt * 3 + p) * 1024, so, 16);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_DRAIN();
         PERS_STAMP(6);
         if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1703,7 +1710,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
                                                        so + ((g * NCH * MT) + mt) * 2048 + h * 1024, 16);
               }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_DRAIN();
         PERS_STAMP(6);
         if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1970,7 +1977,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, mine[mt]), xrs, inb_st, so + mt * 1024, 16);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          PERS_DRAIN();
           if (lane == 0) __hip_atomic_store(pf_out, epoch + (unsigned)step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
@@ -2046,7 +2053,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
                                                        so + ((g * NCH * MT) + mt) * 2048 + h * 1024, 16);
               }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PERS_DRAIN();
         PERS_STAMP(7);
         if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -2296,6 +2303,9 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   }
 #endif
   a.drop_bid = drop_bid;
+#ifdef DVAE_DEV
+  a.nodrain = dvae_dev_knob("DVAE_PERS_NODRAIN", 0);
+#endif
 #ifdef DVAE_PERS_TS
   a.ts = g_pers_ts;
   a.ts_bid = g_pers_ts_bid;

@@ -599,11 +599,13 @@ def lstm_persistent_usable(N: int, H: int, mode: int, ndir: int = 1, bwd: bool =
 
 
 def lstm_pers_workspace(dev) -> torch.Tensor:
-    """Flags + sticky error record + two-slot exchange ring of the persistent LSTM launches of one device (zeroed once;
-    every launch clears its flags with a small kernel of its own in front of it — not hipMemsetAsync, see
-    csrc/lstm_pers.hip dvae_pers_launch; launches of one stream share it).
+    """Flags + sticky error record + the flags' epoch + exchange ring of the persistent LSTM launches of one device: zeroed
+    ONCE, here, and never touched by the host again — a flag holds `epoch + frames published`, every launch reads the epoch
+    its predecessor left and the last workgroup to finish advances it (csrc/lstm_pers.hip pers_epoch), so no launch has to
+    clear anything in front of it; launches of one stream share the workspace.
     (One exchange slot PER FRAME read with plain, L2-cached loads was tried and removed: wrong results under hipGraph
-    replay — blamed on stale L2 lines then, possibly the flag-clear hazard above — and no faster)"""
+    replay — blamed on stale L2 lines then, possibly the flag-clear hazard of the memset node that was in use — and no
+    faster; DESIGN_HISTORY.md.)"""
     key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
     ws = _pers_ws.get(key)
     if ws is None:

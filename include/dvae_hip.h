@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 305
+#define DVAE_ABI_VERSION 306
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -194,7 +194,9 @@ typedef struct {
                          consumers (the next frame, the next layer's projection, the weight gradients) read; the same
                          element strides */
   void* pers_ws;      /* optional: >= dvae_lstm_pers_ws_bytes(N, H) bytes, 256-byte aligned, zero-initialised ONCE by the
-                         caller.  When given to a plain one-direction dvae_lstm_seq_fwd / _bwd call whose shape has a
+                         caller and never written by it afterwards: the flags in it count frames across ALL launches (each
+                         launch reads the epoch the previous one left, ABI 306: no clearing launch in front of a persistent
+                         launch), so a workspace must not be cleared, copied or shared between devices.  When given to a plain one-direction dvae_lstm_seq_fwd / _bwd call whose shape has a
                          persistent kernel (dvae_lstm_pers_supported), the whole sequence
                          runs in ONE W_hh-resident launch (csrc/lstm_pers.hip) instead of one launch per frame; same
                          arithmetic, same tensors.  One workspace serves every layer run on one stream */
@@ -248,8 +250,8 @@ int dvae_repack_all(const dvae_repack_desc_t* descs, int n, void* stream);
  * gate gradients, which no residency shrinks: it stays on the per-frame kernels).
  * dvae_lstm_pers_supported: 1 when a call with (N, H, packed_mode = mode, pass) would take the persistent launch on the
  *   current device (given a workspace), else 0.
- * dvae_lstm_pers_ws_bytes: size of the synchronisation workspace (flags + sticky error record + two-slot exchange ring)
- *   for (N, H); 0 when the shape has no persistent kernel.
+ * dvae_lstm_pers_ws_bytes: size of the synchronisation workspace (flags + sticky error record + the flags' epoch + exchange
+ *   ring: two slots in use, four sized) for (N, H); 0 when the shape has no persistent kernel.
  * dvae_lstm_pers_check: SYNCHRONISES `stream`, then returns DVAE_ELAUNCH if a bounded wait of any persistent launch on
  *   this workspace gave up since the last check (info4 = {code 1 fwd / 2 bwd, workgroup, step, wave}; the outputs of
  *   that launch are garbage), DVAE_OK otherwise.  Not capturable; call it wherever the host synchronises anyway.
