@@ -1,4 +1,4 @@
-"""GPU-box: run ONE contraction shape repeatedly (for rocprofv3 --pmc runs). usage: one_shape.py conv|gemm [reps]"""
+"""GPU-box: run ONE contraction shape repeatedly (for rocprofv3 --pmc runs). usage: one_shape.py conv|wgrad|dgrad|gemm [reps]"""
 import os as _os
 # needs the DEVELOPMENT build of the library (csrc/build.sh dev): probes / environment knobs / timelines are not in the product
 _os.environ.setdefault("DVAE_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))),
@@ -17,6 +17,14 @@ t = lambda *s: torch.randn(*s, device="cuda")
 if kind == "conv":
     x, wp, b, y = t(R, 512), t(5, 512, 512), t(512), torch.empty(R, 512, device="cuda")
     fn = lambda: check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(b), ptr(y), R, N, 512, 512, -1, stream()), "")
+    fl = 2.0 * R * 512 * 512 * 5
+elif kind == "wgrad":     # conv weight gradient 512 -> 512: 8 tiles x 5 taps x 6 k-splits = 240 workgroups, atomic epilogue
+    dy, x, dw = t(R, 512), t(R, 512), torch.zeros(5, 512, 512, device="cuda")
+    fn = lambda: check(L.dvae_conv5_wgrad(ptr(dy), ptr(x), ptr(dw), R, N, 512, 512, 6, -1, stream()), "")
+    fl = 2.0 * R * 512 * 512 * 5
+elif kind == "dgrad":
+    dy, wpt, dx = t(R, 512), t(5, 512, 512), torch.empty(R, 512, device="cuda")
+    fn = lambda: check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, N, 512, 512, -1, stream()), "")
     fl = 2.0 * R * 512 * 512 * 5
 elif kind == "gemm2560":
     x, w, y = t(R, 2560), t(512, 2560), torch.empty(R, 512, device="cuda")
