@@ -94,15 +94,15 @@ struct PersArgs {
 #endif
 
 // wave-level bounded poll: lanes with `active` re-read their word until every one of them has reached `target`
-// (flags count frames over ALL launches — see pers_epoch — so the comparison is the wrap-safe one)
+// (flags count frames over ALL launches — see pers_epoch — and never wrap)
 __device__ __forceinline__ bool poll_ge(const unsigned* p, bool active, unsigned target, unsigned timeout) {
   unsigned v = active ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-  if (__all((int)(v - target) >= 0)) return true;
+  if (__all(v >= target)) return true;
   const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
   for (unsigned it = 1;; ++it) {
     __builtin_amdgcn_s_sleep(1);
     v = active ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-    if (__all((int)(v - target) >= 0)) return true;
+    if (__all(v >= target)) return true;
     if ((it & 15) == 0 && (__builtin_amdgcn_s_memrealtime() - t0) > timeout) return false;
   }
 }
@@ -110,19 +110,31 @@ __device__ __forceinline__ bool poll_ge(const unsigned* p, bool active, unsigned
 // EPOCH of the flags (round 5: no clearing launch in front of a persistent launch).  A flag holds `epoch + frames published`,
 // where `epoch` (word 8 of the error record) is what every workgroup reads when it starts and what the LAST workgroup to
 // finish (word 9 counts them) advances by T + 1 — not workgroup 0: a workgroup of another row group may not even have started
-// when workgroup 0 is done.  Whatever an earlier launch left in a flag is below the epoch of every later launch.
+// when workgroup 0 is done.  Whatever an earlier launch left in a flag is below the epoch of every later launch.  No wrap:
+// once the epoch has passed 2^30 the last workgroup — nobody else is left — zeroes every flag and starts again from 0.
 constexpr int PERS_EPOCH_WORD = 8, PERS_DONE_WORD = 9;
+constexpr unsigned PERS_EPOCH_MAX = 1u << 30;
 __device__ __forceinline__ unsigned pers_epoch(const PersArgs& a) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.err + PERS_EPOCH_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ void pers_finish(const PersArgs& a) {
+  __shared__ int recycle;
+  if (threadIdx.x == 0) recycle = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned d = atomicAdd(a.err + PERS_DONE_WORD, 1u);
     if (d == gridDim.x - 1) {
       __hip_atomic_store(a.err + PERS_DONE_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicAdd(a.err + PERS_EPOCH_WORD, (unsigned)a.T + 1u);
+      const unsigned e = atomicAdd(a.err + PERS_EPOCH_WORD, (unsigned)a.T + 1u) + (unsigned)a.T + 1u;
+      if (e > PERS_EPOCH_MAX) recycle = 1;
     }
+  }
+  __syncthreads();
+  if (recycle) {
+    for (int i = threadIdx.x; i < PERS_FLAG_BYTES / 4; i += blockDim.x)
+      __hip_atomic_store(a.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(a.err + PERS_EPOCH_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -29,6 +29,8 @@ ap.add_argument("--traffic", default="big", help="big: rnd %% 5 copies of 1 GiB 
                 "small: 48 copies of 32 MiB (a kernel boundary on the other stream every ~15 us of the launch); "
                 "delay: big + the round's own launches held back by rnd*37 %% 400 us of filler so that the copies' boundaries "
                 "fall inside the forward launch; none")
+ap.add_argument("--fresh", action="store_true", help="allocate gates / h / c / dgates anew every round, as x3_handoff_stress.py's _x3_pass does "
+                "(the one form in which the sentinel reproducer has failed so far)")
 ap.add_argument("--realloc", action="store_true", help="draw the gates anew every round (torch.rand, as x3_handoff_stress.py does)")
 args = ap.parse_args()
 os.environ.setdefault("DVAE_LIB_PATH", os.path.join(ROOT, "disentangle-vae-for-vc_amd", "libdvae_dev.so"))
@@ -103,6 +105,12 @@ DBG_JB = 5
 
 
 def run(pers, dump):
+    global gates, h, c, dg
+    if args.fresh and pers:
+        junk = [torch.empty(1 << 20, device="cuda") for _ in range(3)]      # perturb the allocator's reuse pattern a little
+        gates, h, c = torch.empty_like(gates0), torch.empty(T * N, H, **f), torch.empty(T * N, H, **f)
+        dg = torch.empty(T * N, 4 * H, **f)
+        del junk
     if args.realloc and pers:
         g2 = torch.Generator(device="cuda").manual_seed(1000)
         _ = (torch.rand(4 * H, H, generator=g2, **f) * 2 - 1) / H ** 0.5

@@ -271,6 +271,49 @@ def test_every_product_persistent_kernel_300_rounds_under_foreign_traffic(env, m
     torch.cuda.synchronize()
 
 
+def test_flag_epoch_advances_and_recycles_without_a_clearing_launch(env):
+    """Round 5: nothing clears the flags in front of a persistent launch — a flag holds `epoch + frames published`, the epoch
+    lives in the workspace (word 8 of the error record) and the last workgroup to finish advances it by T + 1.  (a) it advances
+    by exactly that per launch; (b) once it has passed 2^30 the last workgroup zeroes every flag and starts again from 0, so
+    nothing ever wraps: launches on both sides of that recycling stay correct — fp32x3 forward, both backward forms (the
+    k-split one has two hand-offs) and the bf16 kernels, against the per-frame kernels."""
+    _lib, ops, _ = env
+    ws = ops.lstm_pers_workspace("cuda")
+    off = _lib.lib().dvae_lstm_pers_err_word(ws.data_ptr()) - ws.data_ptr() + 8 * 4
+    word = ws[off:off + 4].view(torch.int32)
+    T = 300
+    ref = [t.clone() for t in _x3_pass(env, 512, T, 128, pers=False, seed=7)]
+    torch.cuda.synchronize()
+    e0 = int(word.item())
+    got = _x3_pass(env, 512, T, 128, pers=True, seed=7)
+    torch.cuda.synchronize()
+    e1 = int(word.item())
+    assert e1 - e0 == 2 * (T + 1), (e0, e1)                            # one forward + one backward launch
+    for name, x, y in zip(("gates", "c", "h", "dgates"), got, ref):
+        assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()), name
+    # 150 frames in front of the limit: the forward launch runs across it and recycles when it ends, the backward launch
+    # starts from epoch 0 on zeroed flags
+    word.fill_((1 << 30) - 150)
+    torch.cuda.synchronize()
+    got = _x3_pass(env, 512, T, 128, pers=True, seed=7)
+    for name, x, y in zip(("gates", "c", "h", "dgates"), got, ref):
+        assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()), f"{name} across the recycling"
+    torch.cuda.synchronize()
+    assert int(word.item()) == T + 1, int(word.item())                 # recycled by the forward launch, advanced by the backward one
+    assert int(ws[:64 * 1024].view(torch.int32).max()) <= T + 1        # every flag started again from zero
+    # the k-split backward (two hand-offs) and the bf16 kernels across a recycling of their own
+    word.fill_((1 << 30) - 40)
+    ref = [t.clone() for t in _x3_pass(env, 1024, 64, 128, pers=False, seed=8)]
+    got = _x3_pass(env, 1024, 64, 128, pers=True, seed=8)
+    for name, x, y in zip(("gates", "c", "h", "dgates"), got, ref):
+        assert float((x - y).abs().max()) <= 2e-5 * float(y.abs().max()), f"H=1024 {name} across the recycling"
+    word.fill_((1 << 30) - 40)
+    lay = Layer(env, 48, 256, 1024, True, seed=12)
+    compare(lay.run(pers=True), lay.run(pers=False), "bf16 across the recycling")
+    torch.cuda.synchronize()
+    assert int(word.item()) == 48 + 1, int(word.item())                # the forward launch recycled, the backward one advanced
+
+
 def test_fp32x3_soak_3000_frames(env):
     """3 000 frames of the H = 1024 layer in one launch per pass (6 000 partial-tile exchanges per workgroup in the backward
     pass): no hang, no drift against the per-frame kernels."""
