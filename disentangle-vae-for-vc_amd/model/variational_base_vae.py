@@ -184,7 +184,11 @@ class VariationalBaseModelVAE:
                 g = torch.cuda.CUDAGraph()
                 # with a reducer the RCCL collectives are captured too (opt-in, see enable_graph); its watchdog thread
                 # makes HIP calls of its own, hence thread-local capture checking
-                mode = {"capture_error_mode": "thread_local"} if self.reducer is not None else {}
+                # (also without a reducer while a process group exists — bench.py times the single-rank graph inside a
+                # data-parallel run: RCCL's watchdog is there either way)
+                import torch.distributed as _dist
+                pg = _dist.is_available() and _dist.is_initialized()
+                mode = {"capture_error_mode": "thread_local"} if (self.reducer is not None or pg) else {}
                 try:
                     with torch.cuda.graph(g, **mode):
                         self._g_losses = self._eager_train_step(self._g_x1, self._g_x2)
