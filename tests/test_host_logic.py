@@ -333,3 +333,86 @@ def test_flat_adam_state_is_layout_independent():
     assert float(e.exp_avg.sum()) == 24.0
     with pytest.raises(ValueError):
         c.load_state_dict(dict(sd, format=3))
+
+
+def test_attach_reducer_restores_the_zero_grad_folding_it_found():
+    """A sharded reducer (rs_ag) switches the Adam launch's gradient clear off (a rank reads and could clear only its own
+    slices); the next reducer that is not sharded — or None — brings back whatever the setting was BEFORE, including an explicit
+    False of the caller (tests/_ddp2_gpu_child.py reads the summed gradients after the step)."""
+    import dvae_amd  # noqa: F401
+    from dvae_amd.model.variational_base_vae import VariationalBaseModelVAE
+    from dvae_amd.optim import FlatAdam
+
+    class Red:
+        def __init__(self, mode):
+            self.mode = mode
+
+    class Tiny(VariationalBaseModelVAE):
+        def __init__(self):
+            super().__init__("VCTK", 64, 80, 1, 32, 1e-4, torch.device("cpu"), 500, 4)
+            self.model = torch.nn.Linear(4, 4)
+            self.optimizer = FlatAdam(list(self.model.named_parameters()), lr=1e-3)
+
+    t = Tiny()
+    opt = t.optimizer
+    assert opt.fold_zero_grad is True
+    t.attach_reducer(Red("all_reduce"))
+    assert opt.fold_zero_grad is True
+    t.attach_reducer(Red("rs_ag"))
+    assert opt.fold_zero_grad is False
+    t.attach_reducer(Red("rs_ag"))                       # twice in a row: the remembered value is still the original one
+    t.attach_reducer(Red("all_reduce"))
+    assert opt.fold_zero_grad is True
+    t.attach_reducer(Red("rs_ag"))
+    t.attach_reducer(None)
+    assert opt.fold_zero_grad is True
+    opt.fold_zero_grad = False                           # the caller's own choice ...
+    t.attach_reducer(Red("all_reduce"))
+    assert opt.fold_zero_grad is False                   # ... is not overridden by a reducer that is not sharded
+    t.attach_reducer(Red("rs_ag"))
+    t.attach_reducer(None)
+    assert opt.fold_zero_grad is False                   # ... and comes back after a sharded one
+
+
+def test_store_first_counters_restart_with_zero_grad():
+    """a step that was abandoned after its backward pass (a graph capture that failed, an exception) must not
+    leave the written-exactly-once count of a store-first gradient at 1 for the retry."""
+    from dvae_amd.optim import FlatAdam
+    ps = [("a", torch.nn.Parameter(torch.randn(8, 4))), ("b", torch.nn.Parameter(torch.randn(8)))]
+    opt = FlatAdam(ps, lr=1e-3)
+    opt.set_store_first(["a"])
+    ps[0][1]._dvae_sf_writes = 1                         # an abandoned attempt's backward wrote it once
+    opt.zero_grad()                                      # the retry starts a step
+    assert ps[0][1]._dvae_sf_writes == 0
+    assert not hasattr(ps[1][1], "_dvae_sf_writes") or ps[1][1]._dvae_sf_writes == 0
+    ps[0][1]._dvae_sf_writes = 1                         # the retry's backward
+    opt._store_first_guard()                             # exactly one write: fine, and the count is taken
+    assert ps[0][1]._dvae_sf_writes == 0
+    ps[0][1]._dvae_sf_writes = 2
+    with pytest.raises(RuntimeError, match="store-first"):
+        opt._store_first_guard()
+
+
+def test_shared_gpu_decision_needs_local_world_size(monkeypatch):
+    """WORLD_SIZE counts the ranks of every node; only LOCAL_WORLD_SIZE may switch the persistent recurrences off."""
+    import dvae_amd  # noqa: F401
+    from dvae_amd import ops
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "16")               # two nodes of eight: NOT a shared GPU
+    assert ops._ranks_share_a_gpu() is False
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert ops._ranks_share_a_gpu() is False
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "16")
+    assert ops._ranks_share_a_gpu() is True
+
+
+def test_abort_process_group_never_blocks_or_raises():
+    """train.main's failure path: tearing down the communicators of a failing rank must not itself enter a collective."""
+    import dvae_amd  # noqa: F401
+    from dvae_amd import train
+    train._abort_process_group()                         # no process group: a no-op
+    import inspect
+    src = inspect.getsource(train.main)
+    body = src[src.index("except BaseException"):]
+    assert "_abort_process_group()" in body and body.index("raise") < body.index("dist.barrier()")
