@@ -16,7 +16,7 @@ Weights come from oracle/fill.py (deterministic by state_dict key), inputs from
 seeded NumPy streams, the three eps tensors from torch.manual_seed(seed) drawn in
 the reference's own order — they are recorded in the fixture.
 
-Usage:  python tests/golden/make_golden.py [steps[:case_name]|conversion|frontend|dataset]
+Usage:  python tests/golden/make_golden.py [steps[:case_name]|conversion|frontend|dataset|bf16_autocast]
 """
 import os
 import sys
@@ -271,8 +271,34 @@ def run_dataset_case():
         print("wrote", out, p0.shape, o0.tolist())
 
 
+def run_bf16_autocast_case(name="c0_b4_t64"):
+    """The REAL reference's forward + loss under torch.autocast("cpu", dtype=torch.bfloat16) — the only bf16 execution the
+    reference has — next to its fp32 run on the same weights, inputs and noise.  The fixture is the band
+    |autocast - fp32| per loss scalar: the bf16 compute mode here (operands rounded, fp32 accumulation and tensors) has to stay
+    inside it (tests/test_oracle_bf16.py on CPU, tests/test_hip_bf16.py on the GPU)."""
+    torch.set_num_threads(8)
+    _, batch, n_frames, seed, eps_seed = next(c for c in CASES if c[0] == name)
+    x1, x2 = synthetic_pair(batch, n_frames, seed)
+    out = {"batch": batch, "n_frames": n_frames, "seed": seed, "eps_seed": eps_seed}
+    import contextlib
+    for tag, ctx in (("fp32", contextlib.nullcontext()), ("autocast_bf16", torch.autocast("cpu", dtype=torch.bfloat16))):
+        w = build(batch, n_frames)
+        torch.manual_seed(eps_seed)          # the three draws of _reparameterize happen inside forward, in the reference's order
+        with torch.no_grad(), ctx:
+            outs = w.model(x1, x2)
+            losses = w.loss_functionGVAE2(x1, x2, *outs, train=True)
+        out[f"losses_{tag}"] = np.array([float(l) for l in losses], dtype=np.float64)
+        out[f"recons_x1_abs_{tag}"] = np.float64(outs[0].float().abs().sum())
+    path = os.path.join(HERE, f"bf16_autocast_{name}.npz")
+    np.savez(path, **out)
+    d = np.abs(out["losses_autocast_bf16"] - out["losses_fp32"]) / np.maximum(1e-12, np.abs(out["losses_fp32"]))
+    print(f"wrote {path}: relative distance autocast(bf16) - fp32 per loss: {np.array2string(d, precision=5)}")
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("", "bf16_autocast"):
+        run_bf16_autocast_case()
     if only in ("", "frontend"):
         run_frontend_case()
     if only in ("", "steps") or only.startswith("steps:"):

@@ -386,6 +386,29 @@ def _bf16_losses_and_gradients(ops, B, T, det):
         assert cos >= 0.9, (k, cos)
 
 
+def test_model_bf16_inside_the_references_autocast_band(ops):
+    """configs[2] / [4] semantics against vectors FROM THE REFERENCE: its forward + loss under torch.autocast(bf16) on CPU and
+    its fp32 run (tests/golden/bf16_autocast_c0_b4_t64.npz, made by importing the reference).  The HIP bf16 mode must be no
+    further from the reference's fp32 losses than the reference's own bf16 execution is, loss by loss (B = 4, T = 64, the
+    reference's weights, inputs and noise).  (tests/test_oracle_bf16.py holds the bf16 oracle to the same band on the CPU.)"""
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g, c = np.load(os.path.join(here, "bf16_autocast_c0_b4_t64.npz")), np.load(os.path.join(here, "c0_b4_t64.npz"))
+    from oracle.fill import synthetic_pair
+    B, T = int(g["batch"]), int(g["n_frames"])
+    x1, x2 = synthetic_pair(B, T, int(g["seed"]))
+    w = _make(B, T)
+    w.model.eps_override = tuple(torch.tensor(c[k]).cuda() for k in ("eps_c1", "eps_c2", "eps_s"))
+    with torch.no_grad():
+        outs = w.model(x1.cuda(), x2.cuda())
+        got = np.array([float(l) for l in w.loss_functionGVAE2(x1.cuda(), x2.cuda(), *outs, train=True)])
+    f, a = g["losses_fp32"], g["losses_autocast_bf16"]
+    band = np.abs(a - f)
+    assert (np.abs(got - f) <= band).all(), (np.abs(got - f) / np.abs(f), band / np.abs(f))
+    assert (np.abs(got - f) / np.abs(f)).max() > 1e-7                       # (and it IS the bf16 mode, not the fp32 one)
+
+
 def test_model_bf16_trains(ops):
     w = _make(4, 64)
     from oracle.fill import synthetic_pair

@@ -43,3 +43,34 @@ def test_with_rounding_it_is_bf16_close():
     rel = float((g_got[k] - g_ref[k]).norm()) / float(g_ref[k].norm())
     assert 1e-4 < rel < 0.2, rel
     assert bf16_ref.r16(torch.tensor([1.00390625, 1.005859375])).tolist() == [1.0, 1.0078125]   # ties-to-even, RNE
+
+
+def _autocast_band(golden_dir=None):
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(here, "bf16_autocast_c0_b4_t64.npz"))
+    c = np.load(os.path.join(here, "c0_b4_t64.npz"))
+    return g, c
+
+
+def test_bf16_oracle_is_inside_the_references_own_autocast_band():
+    """The one bf16 execution the reference has is its forward + loss under torch.autocast("cpu", dtype=torch.bfloat16);
+    tests/golden/make_golden.py recorded it next to the fp32 run of the same weights, inputs and noise
+    (bf16_autocast_c0_b4_t64.npz: vectors from the imported reference).  The bf16 compute mode defined here (operands of every
+    contraction rounded, fp32 accumulation, fp32 tensors) must be NO FURTHER from the reference's fp32 losses than the
+    reference's own autocast run is, loss by loss — it is in fact 1.5 to 170 times closer (autocast also rounds every output
+    tensor, which costs the two KL terms 1 %)."""
+    g, c = _autocast_band()
+    f, a = g["losses_fp32"], g["losses_autocast_bf16"]
+    assert np.allclose(f, c["losses_fwd"], rtol=1e-6)                       # the same run as the pinned fp32 golden
+    B, T = int(g["batch"]), int(g["n_frames"])
+    x1, x2 = synthetic_pair(B, T, int(g["seed"]))
+    eps = tuple(torch.tensor(c[k]) for k in ("eps_c1", "eps_c2", "eps_s"))
+    m = bf16_ref.RefDVAEBf16(4, 32, T)
+    m.load_state_dict(fill_state_dict(m.state_dict()))
+    m.train()
+    with torch.no_grad():
+        got = np.array([float(l) for l in loss_gvae2(x1, x2, m(x1, x2, eps), B)])
+    band = np.abs(a - f)
+    assert (band > 0).all() and (band / np.abs(f)).max() < 2e-2            # the band is bf16-sized
+    assert (np.abs(got - f) <= band).all(), (np.abs(got - f) / np.abs(f), band / np.abs(f))
