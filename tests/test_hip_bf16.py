@@ -391,7 +391,7 @@ def test_model_bf16_inside_the_references_autocast_band(ops):
     its fp32 run (tests/golden/bf16_autocast_c0_b4_t64.npz, made by importing the reference).  The HIP bf16 mode — which also
     STORES activations, LSTM state and gate gradients as bf16 — must stay within TWICE the distance the reference's own bf16
     execution keeps from the reference's fp32 losses, loss by loss (B = 4, T = 64, the reference's weights, inputs and noise;
-    measured 0.03 – 1.3 of that distance: one realisation of bf16 rounding against another).  (tests/test_oracle_bf16.py
+    measured 0.06 – 1.4 of that distance in the deterministic test mode: one realisation of bf16 rounding against another).  (tests/test_oracle_bf16.py
     holds the bf16 oracle, which rounds operands only, INSIDE the band on the CPU.)"""
     import os
     import numpy as np
@@ -400,11 +400,15 @@ def test_model_bf16_inside_the_references_autocast_band(ops):
     from oracle.fill import synthetic_pair
     B, T = int(g["batch"]), int(g["n_frames"])
     x1, x2 = synthetic_pair(B, T, int(g["seed"]))
-    w = _make(B, T)
-    w.model.eps_override = tuple(torch.tensor(c[k]).cuda() for k in ("eps_c1", "eps_c2", "eps_s"))
-    with torch.no_grad():
-        outs = w.model(x1.cuda(), x2.cuda())
-        got = np.array([float(l) for l in w.loss_functionGVAE2(x1.cuda(), x2.cuda(), *outs, train=True)])
+    ops.set_deterministic(True)      # ONE fixed realisation of the roundings (bit-identical run to run and box to box): largest
+    try:                             # ratio 1.38; with the atomics' summation order it scatters up to 1.76 over 12 runs
+        w = _make(B, T)
+        w.model.eps_override = tuple(torch.tensor(c[k]).cuda() for k in ("eps_c1", "eps_c2", "eps_s"))
+        with torch.no_grad():
+            outs = w.model(x1.cuda(), x2.cuda())
+            got = np.array([float(l) for l in w.loss_functionGVAE2(x1.cuda(), x2.cuda(), *outs, train=True)])
+    finally:
+        ops.set_deterministic(False)
     f, a = g["losses_fp32"], g["losses_autocast_bf16"]
     band = np.abs(a - f)
     assert (np.abs(got - f) <= 2.0 * band).all(), (np.abs(got - f) / np.abs(f), band / np.abs(f))
