@@ -281,14 +281,24 @@ def run_bf16_autocast_case(name="c0_b4_t64"):
     x1, x2 = synthetic_pair(batch, n_frames, seed)
     out = {"batch": batch, "n_frames": n_frames, "seed": seed, "eps_seed": eps_seed}
     import contextlib
+    grads = {}
     for tag, ctx in (("fp32", contextlib.nullcontext()), ("autocast_bf16", torch.autocast("cpu", dtype=torch.bfloat16))):
         w = build(batch, n_frames)
         torch.manual_seed(eps_seed)          # the three draws of _reparameterize happen inside forward, in the reference's order
-        with torch.no_grad(), ctx:
+        with ctx:
             outs = w.model(x1, x2)
             losses = w.loss_functionGVAE2(x1, x2, *outs, train=True)
-        out[f"losses_{tag}"] = np.array([float(l) for l in losses], dtype=np.float64)
-        out[f"recons_x1_abs_{tag}"] = np.float64(outs[0].float().abs().sum())
+        w.optimizer.zero_grad()
+        losses[0].backward()                 # (variational_base_vae.py:67-68: backward of the total loss)
+        grads[tag] = {k: p.grad.detach().float().clone() for k, p in w.model.named_parameters()}
+        out[f"losses_{tag}"] = np.array([float(l.detach()) for l in losses], dtype=np.float64)
+        out[f"recons_x1_abs_{tag}"] = np.float64(outs[0].detach().float().abs().sum())
+    # per parameter: how far the reference's own bf16 execution moves its gradient (relative L2 against its fp32 gradient)
+    names = list(grads["fp32"].keys())
+    out["grad_names"] = np.array(names)
+    out["grad_norm_fp32"] = np.array([float(grads["fp32"][k].norm()) for k in names])
+    out["grad_dist_autocast"] = np.array([float((grads["autocast_bf16"][k] - grads["fp32"][k]).norm()) /
+                                          max(1e-30, float(grads["fp32"][k].norm())) for k in names])
     path = os.path.join(HERE, f"bf16_autocast_{name}.npz")
     np.savez(path, **out)
     d = np.abs(out["losses_autocast_bf16"] - out["losses_fp32"]) / np.maximum(1e-12, np.abs(out["losses_fp32"]))
