@@ -271,6 +271,30 @@ def run_dataset_case():
         print("wrote", out, p0.shape, o0.tolist())
 
 
+def run_bf16_autocast_full_size(batch=128, n_frames=256, seed=1234, eps_seed=19):
+    """BASELINE configs[2] (bf16, B=128, T=256) at FULL size, forward + loss only: the reference's fp32 losses and its losses
+    under torch.autocast(bf16), with the noise it drew (recorded) — the band the HIP bf16 mode is held to at the size it is
+    benchmarked at (tests/test_hip_bf16.py)."""
+    torch.set_num_threads(8)
+    x1, x2 = synthetic_pair(batch, n_frames, seed)
+    torch.manual_seed(eps_seed)
+    eps = [torch.empty(batch, 28).normal_(), torch.empty(batch, 28).normal_(), torch.empty(batch, 4).normal_()]
+    out = {"batch": batch, "n_frames": n_frames, "seed": seed, "eps_seed": eps_seed, "eps_c1": eps[0].numpy(),
+           "eps_c2": eps[1].numpy(), "eps_s": eps[2].numpy()}
+    import contextlib
+    for tag, ctx in (("fp32", contextlib.nullcontext()), ("autocast_bf16", torch.autocast("cpu", dtype=torch.bfloat16))):
+        w = build(batch, n_frames)
+        torch.manual_seed(eps_seed)          # forward draws the same three tensors, in the same order
+        with torch.no_grad(), ctx:
+            outs = w.model(x1, x2)
+            losses = w.loss_functionGVAE2(x1, x2, *outs, train=True)
+        out[f"losses_{tag}"] = np.array([float(l) for l in losses], dtype=np.float64)
+    path = os.path.join(HERE, f"bf16_autocast_b{batch}_t{n_frames}.npz")
+    np.savez(path, **out)
+    d = np.abs(out["losses_autocast_bf16"] - out["losses_fp32"]) / np.maximum(1e-12, np.abs(out["losses_fp32"]))
+    print(f"wrote {path}: relative distance autocast(bf16) - fp32 per loss: {np.array2string(d, precision=5)}")
+
+
 def run_bf16_autocast_case(name="c0_b4_t64"):
     """The REAL reference's forward + loss under torch.autocast("cpu", dtype=torch.bfloat16) — the only bf16 execution the
     reference has — next to its fp32 run on the same weights, inputs and noise.  The fixture is the band
@@ -309,6 +333,7 @@ if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     if only in ("", "bf16_autocast"):
         run_bf16_autocast_case()
+        run_bf16_autocast_full_size()
     if only in ("", "frontend"):
         run_frontend_case()
     if only in ("", "steps") or only.startswith("steps:"):
