@@ -333,7 +333,8 @@ if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     if only in ("", "bf16_autocast"):
         run_bf16_autocast_case()
-        run_bf16_autocast_full_size()
+        run_bf16_autocast_full_size()                       # configs[2]
+        run_bf16_autocast_full_size(64, 512, 1234, 23)      # configs[4]'s per-GPU shape
     if only in ("", "frontend"):
         run_frontend_case()
     if only in ("", "steps") or only.startswith("steps:"):
