@@ -41,7 +41,12 @@ Rank 0 prints ONE JSON line.  Extra objects:
                --steps steps (ddp_variants_ms_per_step); the headline is the fastest (no multi-GPU box has been available to
                choose in advance).  The step with the collectives captured inside the hipGraph is attempted only with
                DVAE_BENCH_DDP_GRAPH=1.  Diagnostics: rccl_ranks, visible devices, per-rank ms, buckets,
-               allreduce_exposed_ms (step minus the same step with the reducer detached).
+               allreduce_exposed_ms (step minus the same step with the reducer detached).  The line carries the SAME objects
+               as the N = 1 line: roofline / roofline_lstm (rank 0 alone, reducer detached, after the timed variants),
+               cpu_baseline (after the process group is gone) and scaling_vs_n1 (value / the single-rank graph-replayed step
+               timed in the same processes, all ranks at once; DVAE_BENCH_N1_MS supplies a number measured elsewhere).  A
+               watchdog over the exchange variants (DVAE_BENCH_VARIANT_TIMEOUT) prints the marked line of what was measured
+               if one of them wedges — and then every rank exits 5.
   other_configs  (N=1 only) BASELINE configs[2] (bf16, B=128, T=256) and the per-GPU shape of configs[4] (bf16, B=64,
                T=512), each timed here over a few graph-replayed steps, with its step-level fraction of the bf16 peak.
 """
