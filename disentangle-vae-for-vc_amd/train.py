@@ -196,6 +196,8 @@ def main(argv=None):
         vsc.enable_graph(True)     # with a reducer attached the step still runs eagerly unless DVAE_DDP_GRAPH=1
     hist = None
     try:
+        if os.environ.get("DVAE_TEST_FAIL_RANK") == str(rank):      # (tests: a rank that dies while its peers are in a collective)
+            raise RuntimeError(f"injected failure on rank {rank} (DVAE_TEST_FAIL_RANK)")
         if args.train:
             hist = vsc.run_training(loader, loader, args.epochs, args.report_interval, args.sample_size,
                                     reload_model=not args.do_not_resume,

@@ -66,6 +66,27 @@ def test_train_cli_gpus_2_launches_two_sharded_ranks(tmp_path):
     assert osd["t"] == 4, osd["t"]
 
 
+def test_train_cli_a_failing_rank_ends_the_job_instead_of_hanging_it(tmp_path):
+    """a rank that raises must not walk into the closing barrier while its peer sits in an all-reduce — it tears
+    its communicators down and leaves with the exception; the launcher sees the non-zero exit and stops the other rank.
+    The whole job must be over in seconds, not after a collective's timeout, and the traceback must be there."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""), MASTER_ADDR="127.0.0.1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", DVAE_ALLOW_SHARED_GPU="1", DVAE_DIST_BACKEND="gloo", DVAE_TEST_FAIL_RANK="1")
+    cmd = [sys.executable, "-c", "import dvae_amd.train as t, sys; t.main(sys.argv[1:])", "--train", "true",
+           f"--dataset_fp={_corpus(tmp_path)}", "--batch-size=4", "--latent-size=32", "--speaker_size=4", "--lr=1e-4",
+           "--epochs=50", "--report-interval=50", "--mse_cof=10", "--kl_cof=10", f"--log_dir={tmp_path / 'results'}", "--seed=3",
+           "--do-not-resume", "--gpus", "2"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    dt = time.time() - t0
+    assert r.returncode != 0, r.stdout[-500:]
+    assert "injected failure on rank 1" in r.stderr, r.stderr[-2000:]
+    assert dt < 240, f"the job took {dt:.0f} s to end after a rank failed"
+    assert not (tmp_path / "results" / "checkpoints" / "DisentangledVAE_VCTK_50.pth").exists()      # rank 0 did not train on alone
+
+
 def _bench_two_ranks(env_extra, frames="64", batch="4", rc=0):
     """`bench.py --gpus 2` as the driver starts it for N = 1 (no rendezvous in the environment: bench.py launches the two
     ranks itself); the box has one GPU, so the ranks share it and exchange through gloo — a functional check of the N > 1
