@@ -387,3 +387,13 @@ def test_workspace_size_contract(env):
     for N, H in ((128, 512), (256, 512), (512, 512), (128, 1024), (256, 1024), (17, 1024)):
         assert L.dvae_lstm_pers_ws_bytes(N, H) <= ops.lstm_pers_workspace("cuda").numel()
 
+
+
+def test_deployment_selftest_passes_here(env):
+    """dvae_amd.selftest (the check to run on a new box before a long training run): every product persistent kernel against
+    the per-frame kernels under foreign HBM traffic — a few rounds here; it must come back clean and leave the compute mode
+    as it found the default."""
+    from dvae_amd import selftest
+    lines = []
+    assert selftest.run(rounds=6, log=lines.append) == 0, "\n".join(lines)
+    assert any("PASSED" in ln for ln in lines) and sum("bad rounds of 6" in ln for ln in lines) == 5, lines
