@@ -77,7 +77,7 @@ def run(rounds: int = 200, log=print) -> int:
     a = torch.empty(1 << 28, device="cuda", dtype=torch.float32)
     bbuf = torch.empty_like(a)
     bad = 0
-    prev = ops.current_mode() if hasattr(ops, "current_mode") else None
+    prev = ops.get_compute_dtype()
     for name, mode, H, T, N, rtol in cases:
         ops.set_compute_dtype(name)
         if not (ops.lstm_persistent_usable(N, H, mode) and ops.lstm_persistent_usable(N, H, mode, bwd=True)):
@@ -109,8 +109,7 @@ def run(rounds: int = 200, log=print) -> int:
         torch.cuda.synchronize()
         log(f"{name} H={H} N={N} T={T}: {case_bad} bad rounds of {rounds}")
         bad += case_bad
-    if prev is not None:
-        ops.set_compute_dtype(ops.DEFAULT_COMPUTE_DTYPE)
+    ops.set_compute_dtype(prev)      # leave the compute mode as it was found
     log("selftest " + ("PASSED" if bad == 0 else f"FAILED: {bad} bad rounds — train on this GPU with DVAE_LSTM_PERSISTENT=0 and report its unique_id"))
     return 0 if bad == 0 else 1
 
