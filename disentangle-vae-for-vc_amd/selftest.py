@@ -2,7 +2,7 @@
 
 The persistent LSTM launches (csrc/lstm_pers.hip) hand h[t] / dG[t] from workgroup to workgroup through write-through stores,
 flags and L1-bypassing loads: a form that is measured valid on gfx950, not architecturally guaranteed, and in
-rounds 4 and 5 one chip in forty-three showed wrong rows in a kernel form that every other chip ran 5 000 times without one.
+rounds 4 and 5 one chip in fifty-nine showed wrong rows in a kernel form that every other chip ran 5 000 times without one.
 Before a long training run on a new box, this runs every persistent kernel the product dispatches (default arithmetic: forward +
 both backward forms at H = 512 and H = 1024; bf16 mode: H = 512 and H = 1024) for `--rounds` rounds while a second stream
 streams 0 .. 4 GiB through HBM, and compares every output word with the one-launch-per-frame kernels of the same arithmetic and,
