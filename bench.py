@@ -262,6 +262,8 @@ def dry_launch(args, world, rank):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     one = torch.ones(1)
     dist.all_reduce(one)
     dist.barrier()
@@ -277,6 +279,14 @@ def dry_launch(args, world, rank):
                           "unit": "utterances/sec", "n_gpus": int(one.item()), "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": 1e3 * el / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "none", "dry_launch": True,
+                          # the keys of a real N > 1 line (tests/test_launcher.py holds them): the cooperating ranks, the
+                          # DEFAULT exchange (train.py's: the headline) and the fastest one beside it
+                          "rccl_ranks": dist.get_world_size(), "backend": "gloo",
+                          "ddp_default": {"variant": f"{os.environ.get('DVAE_DDP_MODE', 'all_reduce')}:"
+                                                     f"{os.environ.get('DVAE_DDP_ISSUE', 'finish')}",
+                                          "ms_per_step": 1e3 * el / max(1, args.steps), "value": None},
+                          "ddp_fastest": {"variant": None, "ms_per_step": None, "value": None},
+                          "ddp_variants_ms_per_step": {},
                           "config": {"workload": "dry launch: rendezvous + barrier only, no GPU work",
                                      "parallelism": f"dp{dist.get_world_size()}"}}), flush=True)
     dist.barrier()
@@ -470,6 +480,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if dist.get_world_size() != args.gpus:
+            # never a line that claims N GPUs from another number of cooperating ranks
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
     from dvae_amd import ops
     from dvae_amd.data import SyntheticPairs
@@ -531,9 +544,27 @@ def main():
     else:
         # ---------------- data parallel: eager first, then the graph with the collectives captured, if it captures
         log(f"rank {rank}/{world}: model built ({n_params} params), {dtype}, EAGER data-parallel warm-up x{args.warmup}")
+        import threading
+
+        def first_wedged():
+            # the first (default) exchange has no measured predecessor to fall back on: a marked line without a value, and
+            # every rank leaves with WATCHDOG_RC (rank 0 first; the others wait so that no launcher takes it down earlier)
+            if rank == 0:
+                print(json.dumps({"metric": f"utterances/sec (B={B}, 80-mel, T={T}) train step", "value": None,
+                                  "unit": "utterances/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                  "error": "the default data-parallel exchange did not finish its warm-up + timed region "
+                                           f"within DVAE_BENCH_FIRST_TIMEOUT; every rank exits {WATCHDOG_RC}",
+                                  "variant_watchdog_rc": WATCHDOG_RC}), flush=True)
+            else:
+                time.sleep(3.0)
+            os._exit(WATCHDOG_RC)
+        fdog = threading.Timer(float(os.environ.get("DVAE_BENCH_FIRST_TIMEOUT", "420")), first_wedged)
+        fdog.daemon = True
+        fdog.start()
         for _ in range(max(args.warmup, 1)):
             w.step(x1, x2, spk, train=True)
         el_e, last, own_e = timed(args.steps)
+        fdog.cancel()
         last = tuple(last.tolist())
         ms_eager = 1e3 * el_e / args.steps
         per_rank = torch.zeros(world, device=cdev, dtype=torch.float64)
@@ -542,6 +573,7 @@ def main():
         red = w.reducer
         extra.update({"ms_per_step_eager": ms_eager, "per_rank_ms_eager": [round(v, 3) for v in per_rank.tolist()],
                       "rccl_ranks": dist.get_world_size(), "visible_devices": torch.cuda.device_count(),
+                      "kfd_gpu_nodes": visible_gpu_count(),
                       "backend": backend, "ranks_share_a_gpu": bool(shared_gpu),
                       "ddp_mode": red.mode, "ddp_issue": red.issue,
                       "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"),
@@ -553,9 +585,15 @@ def main():
         # No multi-GPU box has ever been available to choose between the exchange variants, so the first one that is measures
         # them all: bucketed all-reduce or reduce-scatter + sharded Adam + all-gather, each with its collectives issued from the
         # backward hooks (overlap) or after backward (nothing beside the W_hh-resident recurrences).  Every variant computes
-        # the same update, so the replicas stay in step; each is timed over EXACTLY --steps steps like the first; the headline
-        # is the fastest, all are listed.  DVAE_BENCH_DDP_VARIANTS="" keeps only the configured one.
-        variants = {f"{red.mode}:{red.issue}": ms_eager}
+        # the same update, so the replicas stay in step; each is timed over EXACTLY --steps steps like the first.  The
+        # HEADLINE is the default variant (train.py's), measured first; the fastest is reported beside it (`ddp_fastest`), all
+        # are listed.  DVAE_BENCH_DDP_VARIANTS="" keeps only the configured one.
+        default_variant = f"{red.mode}:{red.issue}"      # what train.py runs (DVAE_DDP_MODE / DVAE_DDP_ISSUE unset): the HEADLINE
+        extra["ddp_default"] = {"variant": default_variant, "ms_per_step": ms_eager,
+                                "value": world * B * args.steps / el_e,
+                                "note": "the exchange train.py uses by default: `value` / `ms_per_step` of this line are this variant's"}
+        variants = {default_variant: ms_eager}
+        fastest = {"variant": default_variant, "ms_per_step": ms_eager}
         want = os.environ.get("DVAE_BENCH_DDP_VARIANTS", "all_reduce:hook,all_reduce:finish,rs_ag:hook,rs_ag:finish")
         from dvae_amd import ddp as _ddp
         # A variant that WEDGES (a collective some rank never enters) must not cost the line either: from here on a watchdog
@@ -571,7 +609,7 @@ def main():
             # at the first non-zero exit) can take rank 0 down before its line is out.
             if rank == 0:
                 ex = dict(extra, ddp_variants_ms_per_step=dict(variants), variant_watchdog_rc=WATCHDOG_RC,
-                          variant_watchdog=f"fired during {wd['now']}: the line is the fastest variant measured until then; "
+                          variant_watchdog=f"fired during {wd['now']}: the line is the default variant, measured before; "
                                            f"every rank exits {WATCHDOG_RC}")
                 print(json.dumps(_result(args, world, B, T, dtype, n_params, wd["elapsed"], wd["last"], wd["launch"], ex, None)),
                       flush=True)
@@ -597,14 +635,14 @@ def main():
                 r2.gather_moments(w.optimizer)
                 variants[v] = 1e3 * el_v / args.steps
                 log(f"rank {rank}: {v}: {variants[v]:.2f} ms")
-                if el_v < elapsed:
-                    elapsed, last, launch = el_v, tuple(last_v.tolist()), f"eager ({mode_v}, collectives issued from {issue_v})"
-                    extra["ddp_mode"], extra["ddp_issue"] = mode_v, issue_v
-                    wd.update(elapsed=elapsed, last=last, launch=launch)
+                if variants[v] < fastest["ms_per_step"]:      # reported beside the headline, never instead of it
+                    fastest = {"variant": v, "ms_per_step": variants[v]}
             except Exception as e:      # a variant that fails must not cost the line
                 variants[v] = "failed: " + repr(e)[:160]
         wd["now"] = "the measurements after the variants"
         extra["ddp_variants_ms_per_step"] = variants
+        fastest["value"] = world * B / (fastest["ms_per_step"] * 1e-3)
+        extra["ddp_fastest"] = fastest
         red.issue = os.environ.get("DVAE_DDP_ISSUE", "finish")
         w.attach_reducer(red)            # (sets fold_zero_grad for the reducer's mode, both directions)
         # graph attempt, guarded three ways: try/except around the capture, agreement of all ranks, and a watchdog that
@@ -668,17 +706,26 @@ def main():
         if os.environ.get("DVAE_BENCH_N1_MS"):
             n1_ms, n1_src = float(os.environ["DVAE_BENCH_N1_MS"]), "DVAE_BENCH_N1_MS (supplied)"
         elif args.graph:
+            # the capture may fail on ONE rank: the ranks agree on it (an all-reduce outside the try) BEFORE any of them
+            # enters timed(), whose barriers would otherwise hold the others until the watchdog ends the whole job
+            ok1, err1 = 1, None
             try:
                 w.attach_reducer(None)
                 w.enable_graph(True)
                 for _ in range(3):
                     w.step_async(x1, x2, spk)
+                torch.cuda.synchronize()
+            except Exception as e:
+                ok1, err1 = 0, repr(e)[:200]
+            flag1 = torch.tensor([ok1], device=cdev, dtype=torch.int32)
+            dist.all_reduce(flag1, op=dist.ReduceOp.MIN)
+            if int(flag1.item()):
                 el_1, _, _ = timed(n_nr)
                 n1_ms = 1e3 * el_1 / n_nr
                 n1_src = (f"in-process: {n_nr} graph-replayed steps with the reducer detached, all {world} ranks at once "
                           "(max over ranks)")
-            except Exception as e:
-                extra["scaling_vs_n1_error"] = repr(e)[:200]
+            else:
+                extra["scaling_vs_n1_error"] = err1 or "another rank failed to capture the single-rank step"
             w.enable_graph(False)
             w.attach_reducer(red)
         if n1_ms:

@@ -30,7 +30,7 @@ HDR_NEWEST="$(ls -t "$HERE"/*.h "$HERE"/../../include/*.h | head -1)"
 pids=()
 objs=()
 compiled=()
-for f in gemm lstm lstm_pers bn elem frontend prof repack; do
+for f in gemm gemm256 lstm lstm_pers bn elem frontend prof repack; do
   o="$OBJ/$f.o"
   objs+=("$o")
   if [ ! -f "$o" ] || [ "$HERE/$f.hip" -nt "$o" ] || [ "$HDR_NEWEST" -nt "$o" ]; then

@@ -24,6 +24,7 @@
 #include <type_traits>
 #include <utility>
 #include "common.h"
+#include "gemm_common.h"
 
 // Development ablations (build with -DDVAE_GEMM_ABL=<bits>, results are WRONG): 1 no operand split (one conversion),
 // 2 no global loads inside the k loop, 4 no LDS staging inside the loop, 8 no fragment reads inside the loop, 16 no MFMAs
@@ -49,82 +50,6 @@ __device__ unsigned long long g_gemm_ts[1024 * 8];
 __device__ __attribute__((aligned(16))) float g_gemm_zero[4] = {0.f, 0.f, 0.f, 0.f};   // what masked lanes load
 
 namespace {
-
-// Workgroup = WG x WG waves (WG = 2: 128 x 64*NTW tile, 256 threads; WG = 4: 256 x 128*NTW tile, 1024 threads).
-// The large tile halves the global-load instructions per MFMA (measured: loads cost ~15 % of the small tile's time).
-
-struct GemmParams {
-  const void* A;         // fp32, or bf16 when a16 (bf16 mode only)
-  const void* B;
-  void* C;               // fp32, or bf16 when c16 (plain store only)
-  const float* bias;
-  int a16, b16, c16;
-  int M, N, K;
-  int64_t lda, ldb, ldc;
-  int taps;              // 1 or 5
-  int tap_mode;          // 0 none | 1 loop over taps, one output | 2 one output per tap (grid.z)
-  int64_t a_row_shift;   // mode 1: A row offset per (tap-2)
-  int64_t b_tap_stride;  // mode 1: elements between per-tap B matrices
-  int64_t bk_row_shift;  // mode 2: B k-row offset per (tap-2)
-  int64_t c_tap_stride;  // mode 2: elements between per-tap C matrices
-  int split_k;
-  int k_per_split;       // multiple of the k-tile
-  int act, epi;
-  int tiles_m;
-  int xcd_map;           // XCD-aware workgroup -> tile map (gemm_tile_of)
-  int map_gm, map_gn;    // ... its block of tiles that run on one XCD at a time: map_gm m-tiles x map_gn n-tiles
-  int map_nstr;          // ... n-strips of map_gn tiles (tiles_n / map_gn)
-  // conv forward feeding a training-mode BatchNorm: per-column partial sums of the stored outputs, one fp64 pair per
-  // (64-row chunk, group, column) in the layout bn.hip's finalize kernels read — drops bn_partial's pass over Y
-  double* bn_part;
-  int bn_groups, bn_nseg;
-  // batched launch (dvae_gemm_f32_batched; 128 x 128 kernel, tap_mode 0): `batch` products of one shape in grid.z, product b
-  // on A + a_boff[b] ... (byte offsets) — several small under-filled launches become one that fills the chip
-  int batch;
-  int64_t a_boff[4], b_boff[4], c_boff[4];
-  int c_vec;             // 128 x 128 kernel: C rows can be stored / accumulated 16 bytes at a time (N, ldc multiples of 4, aligned)
-};
-
-// BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded
-// to bf16 (RNE, v_cvt_pk_bf16_f32) while they are staged into LDS; the products run on v_mfma_f32_32x32x16_bf16 with
-// fp32 accumulation.  Images: k-contiguous [rows][BK + 8] bf16 (80-B rows: conflict-free ds_read_b128 of 8 k values);
-// row-contiguous [BK][rows + 32] bf16 read with ds_read_b64_tr_b16 (the hardware transpose delivers 4 consecutive k
-// of one row per lane; 320-B / 192-B k-rows put the 4 k-rows of a read in 4 different 64-B bank quadrants).
-//
-// X3 = "fp32 on the bf16 matrix pipe" (dvae_set_compute_mode(2)): the fp32 MFMA runs at the VALU rate (157 TFLOP/s),
-// 1/16 of the bf16 MFMA.  Every fp32 operand x is split EXACTLY into three bf16 terms, x = x1 + x2 + x3 (x1 = rne(x),
-// x2 = rne(x - x1), x3 = x - x1 - x2: 3 x 8 significand bits + the sign of each residual cover all 24 bits of x), and
-// a product a*b is evaluated as the six partial products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, each EXACT in fp32
-// (8 x 8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms are <= 2^-24 |ab| together
-// — below the rounding of one fp32 FMA — so the result is an fp32 contraction with a different summation order, at
-// 6/16 of the fp32-MFMA cost.  The split runs ONCE per element per workgroup, while the k-tile is staged into LDS
-// (4.5 VALU operations per element: v_cvt_pk_bf16_f32, two bit operations and a packed subtract per level); LDS holds
-// three bf16 images per operand and the fragment reads are those of the bf16 mode, three per tile.  Splitting in
-// registers after the fragment read (fp32 images) measured 160 TFLOP/s: every element is then split by both waves
-// that read it and the VALU stream sits in front of each MFMA burst.
-// A16 / B16M (bf16 mode only): the operand is ALREADY bf16 in memory (activations written as bf16 by their producers,
-// bf16 weight copies from the repack launch): half the bytes per element and no conversion on the way into LDS.
-// Workgroup -> tile.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MB L2; the workgroups that are
-// resident on an XCD at the same time are consecutive in q = blockIdx.x / 8.  With xcd_map, XCD x owns the CONTIGUOUS
-// m-tiles [x * tiles_m / 8, (x + 1) * tiles_m / 8) (the +-2-row shifts of the conv taps stay in one L2), and walks its
-// part of the tile grid in BLOCKS of map_gm x map_gn tiles — the set that is resident at once — n fastest inside a
-// block, the n-strips of one m-group before the next m-group.  The block reads map_gm A tiles + map_gn B tiles from the
-// fabric and shares them through the L2 (with one n-tile per round, as before, every A tile went over the fabric once
-// per n-tile: 4 GB for the M = 65536, N = 1024, K = 4096 bf16 product, which ran AT the 4 TB/s that allows).
-__device__ __forceinline__ void gemm_tile_of(const GemmParams& p, int& tile_m, int& tile_n) {
-  if (p.xcd_map) {
-    const int per = p.tiles_m >> 3, x = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int blk = p.map_gm * p.map_gn;
-    const int round = q / blk, r = q - round * blk;
-    const int mg = round / p.map_nstr, st = round - mg * p.map_nstr;
-    const int rm = r / p.map_gn;
-    tile_m = x * per + mg * p.map_gm + rm;
-    tile_n = st * p.map_gn + (r - rm * p.map_gn);
-  } else {
-    tile_m = blockIdx.x % p.tiles_m;
-    tile_n = blockIdx.x / p.tiles_m;
-  }
-}
 
 template <bool A_KC, bool B_KC, int NTW, int BK, int WG, int MODE = 0, bool BNS = false, bool A16 = false, bool B16M = false>
 __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams p) {
@@ -184,6 +109,10 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   const int kiters = (klen + BK - 1) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
 
+  // k-split without atomics (p.slab): split 0 writes C as p.epi says, split ks >= 1 STORES its partial product into slab ks - 1
+  // (batched: product b has its own run of slabs behind the others')
+  const bool to_slab = p.slab != nullptr && ks > 0;
+  if (to_slab) pC = (char*)(p.slab + ((int64_t)(p.batch > 1 ? blockIdx.z / p.split_k : 0) * (p.split_k - 1) + (ks - 1)) * p.slab_stride);
   float* __restrict__ C = (float*)pC + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // ---- per-thread source descriptors (byte pointers), computed once
@@ -538,7 +467,7 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 
   // ---- epilogue: C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const bool add_bias = (p.bias != nullptr) && (ks == 0);
-  const int epi = p.epi, act = p.act;
+  const int epi = to_slab ? DVAE_EPI_STORE : p.epi, act = p.act;
   // BNS: BatchNorm partial statistics of this wave's 64 rows x 32*NTW columns (= one 64-row chunk of bn.hip), gathered
   // in the SAME pass that stores the tile (each accumulator is read once): sum and sum of squares per statistics group,
   // fp32 over the 64 values of a chunk, fp64 from there on (bn_stats_finalize).  A separate instantiation: in the
@@ -684,11 +613,6 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
 //                    ONE barrier
 // Tiles past the end read zeros (offsets past the operand), the iteration count is rounded up to even.
 // Requires: every k range a multiple of 16 and operands below 2 GiB (launch_gemm falls back to the 128 x 128 kernel).
-template <class F, int... Is>
-__device__ __forceinline__ void for_seq(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-
 // BNU (with BNS): every 64-row statistics chunk lies inside ONE group (group size a multiple of 64): two FMAs per element
 // instead of the per-element row arithmetic and four selects; a separate instantiation (as a run-time branch inside the
 // unrolled epilogue it made both paths slower)
@@ -729,7 +653,9 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int kiters = (k_end - k_begin) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
-  float* __restrict__ C = (float*)p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+  const bool to_slab = p.slab != nullptr && ks > 0;      // k-split without atomics: see gemm_f32_kernel
+  float* __restrict__ C = (to_slab ? p.slab + (int64_t)(ks - 1) * p.slab_stride : (float*)p.C) +
+                          (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // ---- operands as raw buffers: byte offsets, unsigned 32-bit; anything outside [0, bytes) reads zeros.  A row shifted
   // outside the matrix by a conv tap, a row past M / N, a k-row outside [0, K) (wgrad taps) or a tile past the end all
@@ -1114,8 +1040,9 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
     }
   };
   using std::integral_constant;
-  if (p.epi == DVAE_EPI_ATOMIC) emit(integral_constant<int, DVAE_EPI_ATOMIC>{}, integral_constant<int, DVAE_ACT_NONE>{});
-  else if (p.epi == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  const int epi_here = to_slab ? DVAE_EPI_STORE : p.epi;
+  if (epi_here == DVAE_EPI_ATOMIC) emit(integral_constant<int, DVAE_EPI_ATOMIC>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (epi_here == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
   else if (p.act == DVAE_ACT_NONE) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
   else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
   else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_TANH>{});
@@ -1180,7 +1107,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p)
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int kiters = (k_end - k_begin) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
-  float* __restrict__ C = (float*)p.C + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+  const bool to_slab = p.slab != nullptr && ks > 0;      // k-split without atomics: see gemm_f32_kernel
+  float* __restrict__ C = (to_slab ? p.slab + (int64_t)(ks - 1) * p.slab_stride : (float*)p.C) +
+                          (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // operands as raw buffers (see gemm_x3_tall_kernel): byte offsets, anything outside reads zeros
   const int a_rows = A_KC ? p.M : p.K, b_rows = B_KC ? p.N : p.K;
@@ -1448,8 +1377,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p)
     }
   };
   using std::integral_constant;
-  if (p.epi == DVAE_EPI_ATOMIC) emit(integral_constant<int, DVAE_EPI_ATOMIC>{}, integral_constant<int, DVAE_ACT_NONE>{});
-  else if (p.epi == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  const int epi_here = to_slab ? DVAE_EPI_STORE : p.epi;
+  if (epi_here == DVAE_EPI_ATOMIC) emit(integral_constant<int, DVAE_EPI_ATOMIC>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (epi_here == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
   else if (p.act == DVAE_ACT_NONE) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
   else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
   else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_TANH>{});
@@ -1502,6 +1432,11 @@ void launch_variant(const GemmParams& p, dim3 grid, hipStream_t s, bool narrow, 
   }
 }
 
+}  // namespace
+// gemm256.hip: the 256 x 256 LDS-DMA kernel of the bf16 mode (`params` is a complete GemmParams)
+int dvae_launch_gemm_bf16_256(const void* params, int a_kc, int b_kc, int bn_uniform, unsigned gx, unsigned gz, hipStream_t s);
+namespace {
+
 int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   // operand storage flags ride in the upper bits of `mode`
   p.a16 = (mode >= 0 && (mode & DVAE_MODE_A_BF16)) ? 1 : 0;
@@ -1523,8 +1458,16 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   if ((((uintptr_t)p.A) | ((uintptr_t)p.B)) & 15) return DVAE_EINVAL;
   if (!a_kc && (p.M & 3)) return DVAE_EINVAL;
   if (!b_kc && (p.N & 3)) return DVAE_EINVAL;
-  if (p.split_k < 1 || g_dvae_deterministic) p.split_k = 1;   // deterministic: one writer per element, no atomic races
-  if (p.split_k > 1 && (p.epi != DVAE_EPI_ATOMIC || p.act != DVAE_ACT_NONE)) return DVAE_EINVAL;
+  // deterministic test mode: one writer per element, no atomic races (slab splits have one writer per element anyway)
+  if (p.split_k < 1 || (g_dvae_deterministic && !p.slab)) p.split_k = 1;
+  if (p.slab) {      // k-split without atomics: plain stores into caller-provided slabs (dvae_gemm_f32_slabs ...)
+    if (p.slab_cap < 0 || (p.slab_stride & 3) || (((uintptr_t)p.slab) & 15) || p.c16 || p.act != DVAE_ACT_NONE ||
+        (p.epi != DVAE_EPI_STORE && p.epi != DVAE_EPI_ACCUM))
+      return DVAE_EINVAL;
+    if (p.split_k > p.slab_cap + 1) p.split_k = p.slab_cap + 1;
+  } else if (p.split_k > 1 && (p.epi != DVAE_EPI_ATOMIC || p.act != DVAE_ACT_NONE)) return DVAE_EINVAL;
+  const bool splittable = p.slab != nullptr || p.epi == DVAE_EPI_ATOMIC;      // a launch may cut k further itself
+  const int max_sk = p.slab ? p.slab_cap + 1 : (1 << 30);
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
   // tuning knobs for experiments (scripts/one_shape.py): environment variables in the DEV build, constants in the product
   static const int bk_env = dvae_dev_knob("DVAE_GEMM_BK", 0);
@@ -1553,7 +1496,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
                        (p.N % 4 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) && (p.c_tap_stride % 4 == 0);
   if (mode == DVAE_MODE_F32X3 && tall_env != 0 && tall_ok && p.M >= 256 && p.N > 64 && p.batch <= 1) {
     const int t2 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-    if (t2 * zdim < 192 && p.split_k > 1 && p.epi == DVAE_EPI_ATOMIC && kps >= 1024) {
+    if (t2 * zdim < 192 && p.split_k > 1 && splittable && kps >= 1024 &&
+        (p.K + ((kps / 2 + bk - 1) / bk) * bk - 1) / (((kps / 2 + bk - 1) / bk) * bk) <= max_sk) {
       kps = ((kps / 2 + bk - 1) / bk) * bk;
       p.k_per_split = kps;
       p.split_k = (p.K + kps - 1) / kps;
@@ -1575,7 +1519,8 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     int kps64 = ((kps + 63) / 64) * 64;
     int sk64 = (p.K + kps64 - 1) / kps64;
     const int t2 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-    if (t2 * sk64 * (p.tap_mode == 2 ? p.taps : 1) < 192 && p.split_k > 1 && p.epi == DVAE_EPI_ATOMIC && kps64 >= 1024) {
+    if (t2 * sk64 * (p.tap_mode == 2 ? p.taps : 1) < 192 && p.split_k > 1 && splittable && kps64 >= 1024 &&
+        (p.K + ((kps64 / 2 + 63) / 64) * 64 - 1) / (((kps64 / 2 + 63) / 64) * 64) <= max_sk) {
       kps64 = ((kps64 / 2 + 63) / 64) * 64;
       sk64 = (p.K + kps64 - 1) / kps64;
     }
@@ -1590,25 +1535,52 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
       zdim = z64;
     }
   }
+  // ... and 256 x 256 tiles staged by LDS-DMA (gemm256.hip) when THOSE still fill the chip (one workgroup per CU): both
+  // operands of one layout.  An atomically accumulated product is cut into as many k-splits as make one workgroup per CU.
+  bool t256 = false;
+  const int t256_env = dvae_dev_knob("DVAE_GEMM_256", -1);      // (dev build: read per call, scripts/g256_check.py toggles it)
+  if (bf && p.batch <= 1 && p.a16 && p.b16 && !p.c16 && t256_env != 0 && a_kc == b_kc && p.M >= 256 && p.N >= 256 &&
+      (p.K % 64 == 0) && (p.N % 8 == 0) && (p.M % 8 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
+      (p.c_tap_stride % 4 == 0) && a_bytes < (1ll << 31) && b_bytes < (1ll << 31)) {
+    const int tz = ((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.tap_mode == 2 ? p.taps : 1);
+    int sk = 1;
+    if (p.split_k > 1 && p.slab) sk = 256 / tz > 1 ? 256 / tz : 1;
+    if (sk > max_sk) sk = max_sk;
+    int kps256 = (((p.K + sk - 1) / sk + 63) / 64) * 64;
+    if (kps256 < 512 && sk > 1) kps256 = 512;
+    sk = (p.K + kps256 - 1) / kps256;
+    const int iters = (kps256 / 64) * (p.tap_mode == 1 ? p.taps : 1);
+    const int t256_min = dvae_dev_knob("DVAE_GEMM_256_MIN", 224);
+    // (no atomic and no tanh epilogue in that kernel: k-splits only into slabs)
+    const bool epi_ok = p.epi != DVAE_EPI_ATOMIC && p.act != DVAE_ACT_TANH && (p.split_k == 1 || p.slab != nullptr);
+    if (epi_ok && ((tz * sk >= t256_min && iters >= 8) || t256_env == 1)) {
+      t256 = true;
+      tall16 = false;
+      kps = kps256;
+      p.k_per_split = kps;
+      p.split_k = sk;
+      zdim = sk * (p.tap_mode == 2 ? p.taps : 1);
+    }
+  }
   static const int big_env = dvae_dev_knob("DVAE_GEMM_BIG", -1);
   // 256x256 tiles when they still give every CU >= 2 workgroups' worth of tiles and the k-tile can be 32
   const int tiles256 = ((p.M + 255) / 256) * ((p.N + 255) / 256) * zdim;
   bool big = (bk == 32) && (tiles256 >= 512) && (p.N >= 256) && (p.M >= 256) && (p.tap_mode == 0) && (p.batch <= 1);
   if (big_env >= 0) big = (big_env != 0) && (bk == 32) && (p.tap_mode == 0) && (p.batch <= 1);
   if (mode != DVAE_MODE_F32) big = false;   // the 16-wave tile exists for the fp32 MFMA only (128 registers per lane)
-  const int bm = (big || tall || tall16) ? 256 : 128;
+  const int bm = (big || tall || tall16 || t256) ? 256 : 128;
   p.tiles_m = (p.M + bm - 1) / bm;
   // 128-wide n-tiles unless that leaves the chip badly under-filled: then 64-wide
   const int tiles128 = p.tiles_m * ((p.N + 127) / 128) * zdim;
-  const bool narrow = !big && !tall && !tall16 && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
-  const int bn = big ? 256 : (narrow ? 64 : 128);
+  const bool narrow = !big && !tall && !tall16 && !t256 && (narrow_env >= 0 ? (narrow_env != 0) : (tiles128 < 256 && p.N > 32));
+  const int bn = (big || t256) ? 256 : (narrow ? 64 : 128);
   const int tiles_n = (p.N + bn - 1) / bn;
   static const int xcd_env = dvae_dev_knob("DVAE_GEMM_XCDMAP", 1);
   static const int strip_env = dvae_dev_knob("DVAE_GEMM_STRIP", 8);    // n-tiles per block (0: one, the round-2 map)
   p.xcd_map = (xcd_env && (p.tiles_m % 8 == 0) && !big && (xcd_env == 2 || p.tap_mode == 1 || strip_env > 0)) ? 1 : 0;
   {
     // the block resident on one XCD: 32 CUs x (1 tall | 2 square) workgroups; fabric bytes per block ~ gm * BM + gn * BN
-    const int per = p.tiles_m >> 3, conc = (tall || tall16) ? 32 : 64;
+    const int per = p.tiles_m >> 3, conc = (tall || tall16 || t256) ? 32 : 64;
     int gn = 1;
     for (int d = 1; d <= (strip_env > 0 ? strip_env : 1); ++d)
       if (tiles_n % d == 0) gn = d;
@@ -1627,7 +1599,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   dim3 grid(p.tiles_m * tiles_n, 1, zdim * nb);
   // tag of this instantiation: template arguments <A_KC, B_KC, NTW, BK, WG, MODE> + tap mode (dvae_prof_collect_tags)
   const unsigned tag = (a_kc ? 1u : 0u) | (b_kc ? 2u : 0u) | ((narrow ? 1u : 2u) << 2) | ((unsigned)bk << 4) |
-                       ((big ? 4u : (tall || tall16) ? 1u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15) |
+                       ((big ? 4u : t256 ? 3u : (tall || tall16) ? 1u : 2u) << 10) | ((unsigned)mode << 13) | ((unsigned)p.tap_mode << 15) |
                        ((unsigned)p.a16 << 17) | ((unsigned)p.b16 << 18) | ((p.bn_part ? 1u : 0u) << 19);
   // algorithmic bytes: every operand element once (the activation matrix of a conv once, not once per tap)
   const double ntap = p.tap_mode ? p.taps : 1;
@@ -1639,7 +1611,10 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     return DVAE_EINVAL;
   // statistics chunks (64 rows) that never straddle a group or a frame: the cheap form of the BatchNorm epilogue
   const bool bn_uniform = p.bn_part && p.bn_groups >= 1 && ((p.bn_nseg / p.bn_groups) % 64 == 0) && (p.bn_nseg % p.bn_groups == 0);
-  if (tall16) {
+  if (t256) {
+    const int rc = dvae_launch_gemm_bf16_256(&p, a_kc, b_kc, bn_uniform, grid.x, grid.z, s);
+    if (rc != DVAE_OK) return rc;
+  } else if (tall16) {
 #define TALL16(AK_, BK_, BNS_) hipLaunchKernelGGL((gemm_bf16_tall_kernel<AK_, BK_, BNS_>), grid, dim3(256), 0, s, p)
     if (p.bn_part && bn_uniform) hipLaunchKernelGGL((gemm_bf16_tall_kernel<true, true, true, true>), grid, dim3(256), 0, s, p);
     else if (p.bn_part) TALL16(true, true, true);
@@ -1723,6 +1698,52 @@ DVAE_API int dvae_gemm_f32_batched(const void* const* A, const void* const* B, v
   return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
 }
 
+// ---- k-split WITHOUT atomics (round 6).  Split 0 writes C as `epi` says (DVAE_EPI_STORE / DVAE_EPI_ACCUM), split ks >= 1 stores
+// its partial product plainly into slab + (ks - 1) * slab_stride.  Returns the number of k-splits launched (>= 1; the
+// dispatch may take fewer or — up to slab_cap + 1 — more than `split_k`), or a negative error code.  The caller adds the
+// slabs to C in the fixed order ks = 1, 2, ...: dvae_slab_sum, dvae_slab_fold.  Every output element has ONE writer per
+// buffer and the sum one order: results are run-to-run bit-identical.
+DVAE_API int dvae_gemm_f32_slabs(const void* A, const void* B, void* C, float* slab, int64_t slab_stride, int slab_cap,
+                                 const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                                 int a_kcontig, int b_kcontig, int epi, int split_k, int mode, void* stream) {
+  if (!slab && split_k > 1) return DVAE_EINVAL;
+  GemmParams p{};
+  p.A = A; p.B = B; p.C = C; p.bias = bias;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.taps = 1; p.tap_mode = 0;
+  p.split_k = split_k; p.act = DVAE_ACT_NONE; p.epi = epi;
+  p.slab = slab; p.slab_stride = slab_stride; p.slab_cap = slab_cap;
+  if (slab && slab_stride < (int64_t)M * ldc) return DVAE_EINVAL;
+  const int rc = launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
+  return rc == DVAE_OK ? p.split_k : rc;
+}
+
+// batched form: product b stores its splits ks >= 1 into slabs (b * (n - 1) + ks - 1), n = the returned split count
+DVAE_API int dvae_gemm_f32_batched_slabs(const void* const* A, const void* const* B, void* const* C, int batch, float* slab,
+                                         int64_t slab_stride, int slab_cap, int M, int N, int K, int64_t lda, int64_t ldb,
+                                         int64_t ldc, int a_kcontig, int b_kcontig, int epi, int split_k, int mode,
+                                         void* stream) {
+  if (!A || !B || !C || batch < 1 || batch > 4 || (!slab && split_k > 1)) return DVAE_EINVAL;
+  GemmParams p{};
+  p.A = A[0]; p.B = B[0]; p.C = C[0]; p.bias = nullptr;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.taps = 1; p.tap_mode = 0;
+  p.split_k = split_k; p.act = DVAE_ACT_NONE; p.epi = epi;
+  p.batch = batch;
+  p.slab = slab; p.slab_stride = slab_stride; p.slab_cap = slab_cap / batch;      // the slabs are shared out evenly
+  if (slab && slab_stride < (int64_t)M * ldc) return DVAE_EINVAL;
+  for (int b = 0; b < batch; ++b) {
+    if (!A[b] || !B[b] || !C[b] || ((((uintptr_t)A[b]) | ((uintptr_t)B[b]) | ((uintptr_t)C[b])) & 15)) return DVAE_EINVAL;
+    p.a_boff[b] = (const char*)A[b] - (const char*)A[0];
+    p.b_boff[b] = (const char*)B[b] - (const char*)B[0];
+    p.c_boff[b] = (char*)C[b] - (char*)C[0];
+  }
+  const int rc = launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
+  return rc == DVAE_OK ? p.split_k : rc;
+}
+
 // conv forward that also leaves the BatchNorm partial statistics of Y in `bn_ws` (>= dvae_bn_ws_bytes(R, Cout, G) bytes,
 // the layout dvae_bn_stats_finalize reads); G = statistics groups (1 or 2)
 DVAE_API int dvae_zero_f32(float* x, int64_t n, void* stream);   // elem.hip
@@ -1737,7 +1758,7 @@ void narrow_conv_split(GemmParams& p, int mode, hipStream_t s) {
   int m = mode;
   if (m >= 0) m &= 0xff;
   if (m == DVAE_MODE_DEFAULT) m = g_dvae_compute_mode;
-  if (m != DVAE_MODE_F32X3 || g_dvae_deterministic || (mode >= 0 && (mode & ~0xff))) return;
+  if (m != DVAE_MODE_F32X3 || (g_dvae_deterministic && !p.slab) || (mode >= 0 && (mode & ~0xff))) return;
   if (p.N <= 64 || p.N > 128 || (p.N & 3) || p.M < 256 || (((uintptr_t)p.C) & 15)) return;
   const int tiles = (p.M + 255) / 256;
   if (tiles >= 192) return;
@@ -1746,6 +1767,11 @@ void narrow_conv_split(GemmParams& p, int mode, hipStream_t s) {
     const int steps = (p.K / sk / 16) * p.taps;
     if (steps < 24) return;
     if (tiles * sk >= 192) {
+      if (p.slab) {      // plain stores into the caller's slabs (dvae_conv5_fwd_slabs / dgrad_t_slabs): the caller sums them
+        if (sk - 1 > p.slab_cap) return;
+        p.split_k = sk;
+        return;
+      }
       if (dvae_zero_f32((float*)p.C, (int64_t)p.M * p.ldc, s) != DVAE_OK) return;
       p.split_k = sk;
       p.epi = DVAE_EPI_ATOMIC;
@@ -1806,4 +1832,55 @@ DVAE_API int dvae_conv5_wgrad(const void* dY, const void* X, float* dWp, int R, 
   p.bk_row_shift = N; p.c_tap_stride = (int64_t)Cout * Cin;
   p.split_k = split_k; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_ATOMIC;
   return launch_gemm(p, false, false, mode, (hipStream_t)stream);
+}
+
+// ---- the three conv products with k-splits into slabs instead of atomics (see dvae_gemm_f32_slabs); return the split count
+DVAE_API int dvae_conv5_fwd_slabs(const void* X, const void* Wp, const float* bias, float* Y, float* slab, int64_t slab_stride,
+                                  int slab_cap, int R, int N, int Cin, int Cout, int mode, void* stream) {
+  GemmParams p{};
+  p.A = X; p.B = Wp; p.C = Y; p.bias = bias;
+  p.M = R; p.N = Cout; p.K = Cin;
+  p.lda = Cin; p.ldb = Cin; p.ldc = Cout;
+  p.taps = 5; p.tap_mode = 1;
+  p.a_row_shift = N; p.b_tap_stride = (int64_t)Cout * Cin;
+  p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
+  p.slab = slab; p.slab_stride = slab_stride; p.slab_cap = slab_cap;
+  if (slab && slab_stride < (int64_t)R * Cout) return DVAE_EINVAL;
+  narrow_conv_split(p, mode, (hipStream_t)stream);
+  if (p.split_k == 1) p.slab = nullptr;
+  const int rc = launch_gemm(p, true, true, mode, (hipStream_t)stream);
+  return rc == DVAE_OK ? p.split_k : rc;
+}
+
+DVAE_API int dvae_conv5_dgrad_t_slabs(const void* dY, const void* Wpt, float* dX, float* slab, int64_t slab_stride,
+                                      int slab_cap, int R, int N, int Cin, int Cout, int mode, void* stream) {
+  GemmParams p{};
+  p.A = dY; p.B = Wpt; p.C = dX; p.bias = nullptr;
+  p.M = R; p.N = Cin; p.K = Cout;
+  p.lda = Cout; p.ldb = Cout; p.ldc = Cin;
+  p.taps = 5; p.tap_mode = 1;
+  p.a_row_shift = -(int64_t)N; p.b_tap_stride = (int64_t)Cout * Cin;
+  p.split_k = 1; p.act = DVAE_ACT_NONE; p.epi = DVAE_EPI_STORE;
+  p.slab = slab; p.slab_stride = slab_stride; p.slab_cap = slab_cap;
+  if (slab && slab_stride < (int64_t)R * Cin) return DVAE_EINVAL;
+  narrow_conv_split(p, mode, (hipStream_t)stream);
+  if (p.split_k == 1) p.slab = nullptr;
+  const int rc = launch_gemm(p, true, true, mode, (hipStream_t)stream);
+  return rc == DVAE_OK ? p.split_k : rc;
+}
+
+DVAE_API int dvae_conv5_wgrad_slabs(const void* dY, const void* X, float* dWp, float* slab, int64_t slab_stride, int slab_cap,
+                                    int R, int N, int Cin, int Cout, int epi, int split_k, int mode, void* stream) {
+  if (!slab && split_k > 1) return DVAE_EINVAL;
+  GemmParams p{};
+  p.A = dY; p.B = X; p.C = dWp; p.bias = nullptr;
+  p.M = Cout; p.N = Cin; p.K = R;
+  p.lda = Cout; p.ldb = Cin; p.ldc = Cin;
+  p.taps = 5; p.tap_mode = 2;
+  p.bk_row_shift = N; p.c_tap_stride = (int64_t)Cout * Cin;
+  p.split_k = split_k; p.act = DVAE_ACT_NONE; p.epi = epi;
+  p.slab = slab; p.slab_stride = slab_stride; p.slab_cap = slab_cap;
+  if (slab && slab_stride < 5 * (int64_t)Cout * Cin) return DVAE_EINVAL;
+  const int rc = launch_gemm(p, false, false, mode, (hipStream_t)stream);
+  return rc == DVAE_OK ? p.split_k : rc;
 }

@@ -1,0 +1,359 @@
+// bf16 contraction, 256 x 256 x 64 tile, operands staged by LDS-DMA (round 6).
+//
+// Replaces aten::addmm / aten::convolution(_backward) of the reference's Conv1d / LSTM / Linear layers
+// (/root/reference/model/disentangled_vae.py:111-114,163,172,193) in the bf16 compute mode (BASELINE configs[2], [4]) for
+// the products whose operands are both bf16 in memory and that still fill the chip with 256 x 256 tiles.
+//
+// What differs from gemm_bf16_tall_kernel (256 x 128, buffer_load_dwordx4 -> VGPR -> ds_write_b128):
+//   * the operands never pass through registers: `buffer_load_dwordx4 ... lds` (raw_ptr_buffer_load_lds, 16 bytes per
+//     lane) writes a wave's 1 KiB piece straight into the LDS image.  No staging VGPRs, no ds_write, and the k loop's
+//     memory-instruction stream is 8 LDS-DMA + 24 ds_read_b128 per 32 MFMAs (the tall kernel: 12 loads + 12 ds_write +
+//     24 ds_read per 32 MFMAs) — DESIGN.md §9 measured that stream, not the arithmetic, to be what its loop pays for;
+//   * one workgroup of EIGHT waves per CU (two per SIMD), each wave a 128 x 64 output tile (4 x 2 MFMA tiles of 32 x 32):
+//     L2 -> LDS bytes per MFMA fall by a third.  Two waves per SIMD because an LDS-DMA piece costs its issuing wave
+//     100+ cycles of issue (MI355X_MICROARCH.md): with one wave per SIMD (four waves of 128 x 128, measured first:
+//     scripts/g256_check.py, 0.55 of the MFMA stream on 8192^3, slower than the tall kernel everywhere) the matrix pipe
+//     idles behind every piece; with two the partner's MFMAs run meanwhile;
+//   * out-of-range rows, conv padding (negative / past-the-end tap shifts), ragged edges and the tiles past the end are
+//     offsets outside the buffer descriptor: the DMA writes ZEROS for them (scripts/probes/glds_probe.hip, measured on
+//     MI355X: OOB lanes -> 0 in LDS, destinations above 64 KiB fine).
+//
+// LDS images (128 KiB: two buffers x {A, B} x 32 KiB; an LDS-DMA piece is lane-linear, base + 16 * lane, so the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and again on the read — cdna_hip_programming.md rule 21):
+//   k-contiguous operand ([rows][K] in memory): [256 rows][128 B]; 16-byte chunk c of row r sits at chunk c ^ ((r >> 1) & 7)
+//     (a ds_read_b128 lane group — 16 rows, one logical chunk — then covers all 16 slots of the 256-byte bank row);
+//     piece q (0..31) = rows 8q .. 8q+7, lane l -> row 8q + (l >> 3), physical chunk l & 7: every row read as one whole 128-byte line;
+//   row-contiguous operand ([K][rows] in memory): [64 k-rows][512 B]; byte b of k-row kr sits at b ^ ((kr & 3) << 6)
+//     (the four k-rows of a ds_read_b64_tr_b16 lane group fall into the four 64-byte quadrants of the bank row);
+//     piece q = k-rows 2q, 2q+1, lane l -> k-row 2q + (l >> 5), physical chunk l & 31.
+// Fragment k order, MFMA shape (v_mfma_f32_32x32x16_bf16) and the (k-tile, tap) walk are those of gemm_bf16_tall_kernel
+// and the 128 x 128 kernel: unsplit results are BIT-IDENTICAL to theirs (tests/test_hip_bf16.py).
+//
+// Pipeline (two LDS buffers, ONE barrier per 64-deep k-tile, one tile of LDS-DMA in flight across it):
+//   iteration i (buffer u = i & 1), fragments of (tile i, sub-step 0) already in registers:
+//     sub-steps 0-2: 8 MFMAs each on fragment set s & 1; the 6 ds_read_b128 of the next sub-step in their shadows
+//     s_waitcnt vmcnt(0) lgkmcnt(0)      this wave's pieces of tile i+1 have landed; its reads of tile i are done
+//     s_barrier                          ... everybody's: buffer u^1 is complete, buffer u is dead
+//     sub-step 3:    8 MFMAs; fragment reads of (tile i+1, sub-step 0) from buffer u^1; this wave's 8 LDS-DMA pieces
+//                    of tile i+2 into buffer u
+// A staged buffer is read only behind the barrier that follows the wait that retired it; it is restaged only behind a
+// barrier that every wave reaches after its last read of it has returned (lgkmcnt(0)).
+#include "gemm_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4_t;
+
+template <bool A_KC, bool B_KC, bool BNS, bool BNU>
+__global__ __launch_bounds__(512) void gemm_bf16_256_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, MTW = 4, NTW = 2;
+  constexpr int OPB = 32768;                 // bytes of one operand's k-tile image
+  constexpr unsigned OOB = 0xC0000000u;      // an offset no operand reaches (operands < 1 GiB): the DMA writes zeros
+  __shared__ __attribute__((aligned(1024))) char lds[4 * OPB];     // [buffer][A | B]
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, kh = lane >> 5;
+
+  int tile_m, tile_n;
+  gemm_tile_of(p, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int tap_fixed = 0, ks = blockIdx.z;
+  if (p.tap_mode == 2) {
+    tap_fixed = blockIdx.z % p.taps;
+    ks = blockIdx.z / p.taps;
+  }
+  const int k_begin = ks * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int kiters = (k_end - k_begin) / BK;
+  const int ntaps_loop = (p.tap_mode == 1) ? p.taps : 1;
+  const int n_iters = ntaps_loop * kiters;
+  // k-split without atomics: split 0 writes the result buffer, split ks >= 1 its own slab (summed later in the fixed order
+  // ks = 0, 1, ...: dvae_slab_sum / the Adam launch)
+  float* __restrict__ C = ((p.slab && ks > 0) ? p.slab + (int64_t)(ks - 1) * p.slab_stride : (float*)p.C) +
+                          (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
+
+  const int a_rows = A_KC ? p.M : p.K, b_rows = B_KC ? p.N : p.K;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((int64_t)a_rows * p.lda * 2), 0x00020000);
+  const int64_t b_bytes = (int64_t)b_rows * p.ldb * 2 * ((p.tap_mode == 1) ? p.taps : 1);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
+
+  // ---- per-lane source offsets of this wave's 4 + 4 pieces (k-tile 0, tap 2)
+  unsigned voa[4], vob[4];
+  const int64_t b_shift = (p.tap_mode == 2) ? (int64_t)(tap_fixed - 2) * p.bk_row_shift : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wave * 4 + j;
+    if (A_KC) {
+      const int r = 8 * q + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      voa[j] = (unsigned)(((int64_t)(m0 + r) * p.lda + k_begin + c * 8) * 2);
+      if (m0 + r >= p.M) voa[j] = OOB;
+    } else {
+      const int kr = 2 * q + (lane >> 5), lc = (lane & 31) ^ ((kr & 3) << 2);
+      voa[j] = (unsigned)(((int64_t)(k_begin + kr) * p.lda + m0 + lc * 8) * 2);
+      if (m0 + lc * 8 >= p.M) voa[j] = OOB;
+    }
+    if (B_KC) {
+      const int r = 8 * q + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+      vob[j] = (unsigned)(((int64_t)(n0 + r) * p.ldb + k_begin + c * 8) * 2);
+      if (n0 + r >= p.N) vob[j] = OOB;
+    } else {
+      const int kr = 2 * q + (lane >> 5), lc = (lane & 31) ^ ((kr & 3) << 2);
+      vob[j] = (unsigned)((((int64_t)(k_begin + kr) + b_shift) * p.ldb + n0 + lc * 8) * 2);
+      if (n0 + lc * 8 >= p.N) vob[j] = OOB;
+    }
+  }
+  const int a_tap_step = (p.tap_mode == 1) ? (int)(p.a_row_shift * p.lda * 2) : 0;
+  const int b_tap_step = (p.tap_mode == 1) ? (int)(p.b_tap_stride * 2) : 0;
+  const int a_k_step = A_KC ? BK * 2 : (int)(BK * p.lda * 2);
+  const int b_k_step = B_KC ? BK * 2 : (int)(BK * p.ldb * 2);
+  int tap_n = 0, kit_n = 0;       // next tile to fetch: taps fastest, as the tall kernel walks them
+  unsigned a_s = 0, b_s = 0;      // its uniform byte offsets
+  auto next_tile_offsets = [&]() {
+    const bool live = kit_n < kiters;
+    a_s = live ? (unsigned)((tap_n - 2) * a_tap_step + kit_n * a_k_step) : OOB;
+    b_s = live ? (unsigned)(tap_n * b_tap_step + kit_n * b_k_step) : OOB;
+    const bool wrap = (tap_n + 1 == ntaps_loop);
+    tap_n = wrap ? 0 : tap_n + 1;
+    kit_n += wrap ? 1 : 0;
+  };
+  // piece j of this wave (0-3: A, 4-7: B) of the tile whose offsets are current -> buffer `buf`
+  auto dma_piece = [&](int buf, int j) {
+    char* dst = lds + buf * 2 * OPB + (j >= 4 ? OPB : 0) + (wave * 4 + (j & 3)) * 1024;
+    if (j < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void_t*)dst, 16, voa[j] + a_s, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void_t*)dst, 16, vob[j - 4] + b_s, 0, 0, 0);
+  };
+
+  // ---- per-lane fragment addresses (bytes inside one operand image); everything else is an immediate
+  // k-contiguous: [sub] -> row (first row of the wave + l31), chunk (2 sub + kh) ^ ((l31 >> 1) & 7); MFMA tile adds 32 rows = 4096 B
+  // row-contiguous: [tile] -> k-row tr_k, byte ((first column of the wave + 32 tile + tr_r) * 2) ^ ((tr_k & 3) << 6);
+  //                 sub-step adds 16 k-rows = 8192 B, the upper half of the fragment 4 k-rows = 2048 B
+  const int g16 = lane >> 4, li = lane & 15;
+  const int tr_k = 8 * (g16 >> 1) + (li >> 2), tr_r = 16 * (g16 & 1) + 4 * (li & 3);
+  int fa[4], fb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (A_KC) fa[i] = (wm * 128 + l31) * 128 + (((2 * i + kh) ^ ((l31 >> 1) & 7)) << 4);
+    else fa[i] = tr_k * 512 + (((wm * 128 + i * 32 + tr_r) * 2) ^ ((tr_k & 3) << 6));
+    if (B_KC) fb[i] = (wn * 64 + l31) * 128 + (((2 * i + kh) ^ ((l31 >> 1) & 7)) << 4);
+    else fb[i] = tr_k * 512 + (((wn * 64 + (i & 1) * 32 + tr_r) * 2) ^ ((tr_k & 3) << 6));
+  }
+  auto frag = [&](const char* img, bool kc, const int (&f)[4], int tile, int sub) -> bf16x8 {
+    if (kc) return *reinterpret_cast<const bf16x8*>(img + f[sub] + tile * 4096);
+    const char* q0 = img + f[tile] + sub * 8192;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q0 + 2048));
+    return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  struct Frags {
+    bf16x8 a[MTW], b[NTW];
+  };
+  auto read_frag = [&](Frags& f, int buf, int sub, int w) {    // w = 0..5: A tiles, then B tiles
+    if (w < MTW) f.a[w] = frag(lds + buf * 2 * OPB, A_KC, fa, w, sub);
+    else f.b[w - MTW] = frag(lds + buf * 2 * OPB + OPB, B_KC, fb, w - MTW, sub);
+  };
+
+  f32x16 acc[MTW][NTW];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Frags fr[2];
+  // ---- prologue: tiles 0 and 1 in flight, tile 0 waited for, fragments of (tile 0, sub-step 0) read
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dma_piece(0, j);
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dma_piece(1, j);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int w = 0; w < MTW + NTW; ++w) read_frag(fr[0], 0, 0, w);
+
+  // one k-tile = 32 pinned steps: MFMA g, then at most one fragment read and one LDS-DMA piece
+  auto step = [&](auto G, auto U) {
+    constexpr int g = decltype(G)::value, u = decltype(U)::value;    // u = parity of the k-tile being computed
+    constexpr int sub = g / 8, e = g % 8, mt = e / 2, nt = e % 2;
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sub & 1].a[mt], fr[sub & 1].b[nt], acc[mt][nt], 0, 0, 0);
+    if constexpr (e < MTW + NTW) {
+      if constexpr (sub < 3) read_frag(fr[(sub + 1) & 1], u, sub + 1, e);
+      else read_frag(fr[0], u ^ 1, 0, e);
+    }
+    if constexpr (sub == 3) dma_piece(u, e);      // tile i+2 -> the buffer tile i just left
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto run = [&](auto U) {
+    for_seq([&](auto G) { step(G, U); }, std::make_integer_sequence<int, 24>{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for_seq([&](auto G) { step(std::integral_constant<int, 24 + decltype(G)::value>{}, U); }, std::make_integer_sequence<int, 8>{});
+  };
+  for (int it0 = 0; it0 < n_iters; it0 += 2) {
+    next_tile_offsets();      // tile it0 + 2
+    run(std::integral_constant<int, 0>{});
+    next_tile_offsets();
+    run(std::integral_constant<int, 1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the (all-zero) pieces past the end: nothing may be in flight into LDS at exit
+
+  // ---- epilogue (the tall kernels'): C/D lane map of the 32x32 tile: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5);
+  // 16-byte stores after a 4 x 4 transpose inside each lane quad; one straight-line copy per (kind, activation)
+  const bool add_bias = (p.bias != nullptr) && (ks == 0);
+  auto emit = [&](auto EPI_, auto ACT_) {
+    constexpr int epi = decltype(EPI_)::value, act = decltype(ACT_)::value;
+    if constexpr (epi == DVAE_EPI_ATOMIC) {
+      if (add_bias) {      // bias into the accumulators first (a load pending beside the atomics serialises them)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+          const float bv = col < p.N ? p.bias[col] : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bv;
+        }
+      }
+    }
+#pragma unroll
+    for (int half = 0; half < MTW / 2; ++half) {     // 64 rows = one BatchNorm statistics chunk
+      float bst[NTW][4];
+      int bmod = 0;
+      if constexpr (BNS) {
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bst[nt][q] = 0.f;
+        bmod = (m0 + wm * 128 + half * 64 + 4 * kh) % p.bn_nseg;
+      }
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+        const int mt = 2 * half + m2;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+          if (col >= p.N) continue;            // (N % 4 == 0: a quad of lanes is inside or outside as a whole)
+          const float bias_v = (epi != DVAE_EPI_ATOMIC && add_bias) ? p.bias[col] : 0.f;
+          const int row0 = m0 + wm * 128 + mt * 32 + 4 * kh;
+          float* cbase = C + (int64_t)row0 * p.ldc + col;
+          const int q4 = lane & 3;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float x[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * g + e, dr = e + 8 * g;
+              const bool ok = row0 + dr < p.M;
+              float v = acc[mt][nt][r] + bias_v;
+              v = act_apply(v, act);
+              if constexpr (epi == DVAE_EPI_ATOMIC) {
+                if (ok) atomicAdd(cbase + (int64_t)dr * p.ldc, v);
+              }
+              x[e] = v;
+              if constexpr (BNS && BNU) {
+                const float uu = ok ? v : 0.f;
+                bst[nt][0] += uu;
+                bst[nt][1] += uu * uu;
+              } else if constexpr (BNS) {
+                const int nseg = p.bn_nseg;
+                int rm = bmod + m2 * 32 + dr;
+                if (nseg >= 64) rm -= (rm >= nseg) ? nseg : 0; else rm %= nseg;
+                const float uu = ok ? v : 0.f;
+                const bool g1 = rm >= nseg / p.bn_groups;
+                bst[nt][0] += g1 ? 0.f : uu;
+                bst[nt][1] += g1 ? 0.f : uu * uu;
+                bst[nt][2] += g1 ? uu : 0.f;
+                bst[nt][3] += g1 ? uu * uu : 0.f;
+              }
+            }
+            if constexpr (epi != DVAE_EPI_ATOMIC) {
+              float y[4], z[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
+                y[e] = ((q4 ^ e) & 1) ? o : x[e];
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
+                z[e] = ((q4 ^ e) & 2) ? o : y[e];
+              }
+              // this lane now holds row (8 g + 4 kh + q4) of the tile, columns 4 (l31 >> 2) .. + 3
+              const int row = row0 + 8 * g + q4;
+              if (row < p.M) {
+                f32x4* dst = reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4));
+                f32x4 o4 = {z[0], z[1], z[2], z[3]};
+                if constexpr (epi == DVAE_EPI_ACCUM) o4 += *dst;
+                *dst = o4;
+              }
+            }
+          }
+          // 256 registers per lane here (two waves per SIMD): left alone, hipcc hoists the addresses of a whole tile column
+          // and spills 64 accumulator registers — and a scratch reload pending beside the atomics (both count in vmcnt)
+          // makes every atomic wait for the one before it (measured: the k-split products at 0.55 of the tall kernel)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if constexpr (BNS) {
+        const int chunk = tile_m * 4 + wm * 2 + half, nchunks = (p.M + DVAE_BN_ROWS_PER_CHUNK - 1) / DVAE_BN_ROWS_PER_CHUNK;
+        bool second = false;      // BNU: the chunk's sums belong to the second group
+        if constexpr (BNU) second = ((m0 + wm * 128 + half * 64) % p.bn_nseg) >= p.bn_nseg / p.bn_groups;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          if (second) {
+            bst[nt][2] = bst[nt][0];
+            bst[nt][3] = bst[nt][1];
+            bst[nt][0] = bst[nt][1] = 0.f;
+          }
+          const int col = n0 + wn * 64 + nt * 32 + l31;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bst[nt][q] += __shfl_xor(bst[nt][q], 32, 64);
+          if (kh == 0 && col < p.N && chunk < nchunks) {
+            double* o = p.bn_part + ((int64_t)chunk * p.bn_groups * p.N + col) * 2;
+            o[0] = (double)bst[nt][0];
+            o[1] = (double)bst[nt][1];
+            if (p.bn_groups > 1) {
+              o[(int64_t)p.N * 2] = (double)bst[nt][2];
+              o[(int64_t)p.N * 2 + 1] = (double)bst[nt][3];
+            }
+          }
+        }
+      }
+    }
+  };
+  // Plain stores and read-modify-write only: no atomic epilogue here (k-splits go to slabs, see slab / slab_stride) and no
+  // tanh (no caller at these sizes).  With both compiled in, the 256 registers a lane has at two waves per SIMD did not hold
+  // the epilogue: 64 accumulator registers were spilled in front of it, and scratch reloads pending beside atomics (both
+  // count in vmcnt) serialised the atomics — the k-split products ran at 0.55 of the tall kernel.
+  using std::integral_constant;
+  const int epi_here = (p.slab && ks > 0) ? DVAE_EPI_STORE : p.epi;      // splits behind the first store their slab plainly
+  if (epi_here == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
+  else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
+  else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
+}
+
+}  // namespace
+
+// launch_gemm (gemm.hip) decides; `p` arrives complete (tiles_m for 256-row tiles, the XCD map, k_per_split a multiple of 64)
+int dvae_launch_gemm_bf16_256(const void* params, int a_kc, int b_kc, int bn_uniform, unsigned gx, unsigned gz, hipStream_t s) {
+  const GemmParams& p = *static_cast<const GemmParams*>(params);
+  const dim3 grid(gx, 1, gz);
+#define G256(AK_, BK_, BNS_, BNU_) hipLaunchKernelGGL((gemm_bf16_256_kernel<AK_, BK_, BNS_, BNU_>), grid, dim3(512), 0, s, p)
+  if (p.bn_part) {
+    if (!a_kc || !b_kc) return DVAE_EINVAL;
+    if (bn_uniform) G256(true, true, true, true); else G256(true, true, true, false);
+  } else if (a_kc && b_kc) G256(true, true, false, false);
+  else if (!a_kc && !b_kc) G256(false, false, false, false);
+  else return DVAE_EINVAL;      // mixed layouts: no caller at these sizes (launch_gemm keeps them on the tall kernel)
+#undef G256
+  return DVAE_OK;
+}

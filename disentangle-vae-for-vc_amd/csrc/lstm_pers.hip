@@ -43,9 +43,12 @@ constexpr int PERS_FLAG_STRIDE = 32;          // words between the flags of two 
 constexpr int PERS_FLAG_LD = 32 * PERS_FLAG_STRIDE;   // words per row group (H/32 <= 32 producers)
 constexpr int PERS_FLAG_LD_X3 = 64 * PERS_FLAG_STRIDE;   // fp32x3 forward: H/16 <= 64 producers per row group
 constexpr int PERS_MAX_RB = 16;               // row groups
-constexpr int PERS_FLAG_BYTES = PERS_MAX_RB * PERS_FLAG_LD * 4;   // 64 KiB; a launch zeroes the n_rb groups it uses
+constexpr int PERS_FLAG_BYTES = PERS_MAX_RB * PERS_FLAG_LD * 4;   // 64 KiB; zeroed ONCE by the caller: no launch clears flags (they carry their epoch, pers_epoch)
 static_assert(4 * PERS_FLAG_LD_X3 * 4 <= PERS_FLAG_BYTES, "fp32x3: at most 4 row groups of 64 producers");
-constexpr int PERS_ERR_OFF = PERS_FLAG_BYTES; // sticky error record: 16 words (never cleared by a launch)
+constexpr int PERS_ERR_OFF = PERS_FLAG_BYTES; // sticky error record: 16 words (never cleared by a launch).  INVARIANT: words 8
+                                              // (the flags' epoch) and 9 (workgroups done) belong to the launches — nobody else may
+                                              // write them, dvae_lstm_pers_check clears words 0..7 only: a zeroed epoch beside
+                                              // flags that still hold an old epoch's counts would publish frames nobody stored
 constexpr int PERS_XCH_OFF = PERS_FLAG_BYTES + 4096;   // exchange ring
 constexpr int PERS_PAD_LDS = 84 * 1024;       // total LDS per workgroup >= this: exactly one workgroup fits a CU
 
@@ -122,7 +125,10 @@ __device__ __forceinline__ void pers_finish(const PersArgs& a) {
   if (threadIdx.x == 0) recycle = 0;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned d = atomicAdd(a.err + PERS_DONE_WORD, 1u);
+    // release: every flag store of this workgroup (also one that was never polled: a give-up path, a dropped workgroup) is
+    // ordered in front of its DONE increment; acquire in the last workgroup: its zeroing of the flags (recycle) is ordered
+    // behind every peer's stores — a late flag of ~2^30 + T can then not land on a recycled (zero) flag
+    const unsigned d = __hip_atomic_fetch_add(a.err + PERS_DONE_WORD, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (d == gridDim.x - 1) {
       __hip_atomic_store(a.err + PERS_DONE_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned e = atomicAdd(a.err + PERS_EPOCH_WORD, (unsigned)a.T + 1u) + (unsigned)a.T + 1u;

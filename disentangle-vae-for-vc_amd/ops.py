@@ -1246,7 +1246,9 @@ def prof_collect_tags(max_tags: int = 64):
     for i in range(n):
         t = int(tags[i])
         bns, a16, b16 = (t >> 19) & 1, (t >> 17) & 1, (t >> 18) & 1
-        if (t >> 10) & 7 == 1:      # the 256 x 128 tile, one workgroup per CU
+        if (t >> 10) & 7 == 3:      # the 256 x 256 LDS-DMA tile of the bf16 mode (gemm256.hip)
+            name = f"gemm_bf16_256_kernel<A_KC={t & 1}, B_KC={(t >> 1) & 1}, BNS={bns}> tap_mode={(t >> 15) & 3}"
+        elif (t >> 10) & 7 == 1:    # the 256 x 128 tile, one workgroup per CU
             kn = "gemm_bf16_tall_kernel" if (t >> 13) & 3 == 1 else "gemm_x3_tall_kernel"
             name = f"{kn}<A_KC={t & 1}, B_KC={(t >> 1) & 1}, BNS={bns}> tap_mode={(t >> 15) & 3}"
         else:

@@ -31,7 +31,8 @@ def wrap(name):
         e1.record()
         if name == "dvae_gemm_f32":
             M, N, K, a_kc, b_kc, act, epi, sk = a[4], a[5], a[6], a[10], a[11], a[12], a[13], a[14]
-            key, fl = f"gemm M={M} N={N} K={K} akc={a_kc} bkc={b_kc} epi={epi} sk={sk}", 2.0 * M * N * K
+            md = a[15]
+            key, fl = f"gemm M={M} N={N} K={K} akc={a_kc} bkc={b_kc} epi={epi} sk={sk} mode={md & 0xff if md >= 0 else md} a16={(md >> 8) & 1 if md >= 0 else 0} b16={(md >> 9) & 1 if md >= 0 else 0}", 2.0 * M * N * K
         elif name == "dvae_conv5_wgrad":
             R, N_, Cin, Cout, sk = a[3], a[4], a[5], a[6], a[7]
             key, fl = f"conv_wgrad R={R} Cin={Cin} Cout={Cout} sk={sk}", 10.0 * R * Cin * Cout

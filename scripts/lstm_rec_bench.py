@@ -88,10 +88,6 @@ def copy_only():
         y["gates"].copy_(y["gates0"])
 
 
-dbg = None
-if os.environ.get("LSTM_DBG") and hasattr(L, "dvae_lstm_pers_set_dbg"):
-    dbg = torch.zeros(16, device=dev, dtype=torch.int32)      # dev build: counters of the sentinel kernels' careful passes
-    L.dvae_lstm_pers_set_dbg(ptr(dbg), None, 0, 2)
 cp = timeit(copy_only)
 tf = timeit(fwd, cp)
 tb = timeit(bwd)
@@ -101,6 +97,4 @@ if PERS:
 per = T * nl
 print(f"H={H} N={N} T={T} stack={stack} mode={BF} s16={S16} pers={PERS}: fwd {1e3 * tf / per:.2f} us/layer-frame ({tf:.3f} ms), bwd {1e3 * tb / per:.2f} us/layer-frame "
       f"({tb:.3f} ms)  [lib {os.path.basename(_lib.LIB_PATH)}]", flush=True)
-if dbg is not None:
-    print(f"   careful passes (wave-level) over {2 + reps} forward launches: at steps <= 1: {int(dbg[0])}, later: {int(dbg[1])}")
 assert torch.isfinite(layers[-1]["h"].float()).all() and torch.isfinite(layers[0]["dg"].float()).all()

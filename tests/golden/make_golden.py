@@ -16,7 +16,7 @@ Weights come from oracle/fill.py (deterministic by state_dict key), inputs from
 seeded NumPy streams, the three eps tensors from torch.manual_seed(seed) drawn in
 the reference's own order — they are recorded in the fixture.
 
-Usage:  python tests/golden/make_golden.py [steps[:case_name]|conversion|frontend|dataset|bf16_autocast]
+Usage:  python tests/golden/make_golden.py [steps[:case_name]|conversion|frontend|dataset|bf16_autocast|trajectory]
 """
 import os
 import sys
@@ -329,6 +329,77 @@ def run_bf16_autocast_case(name="c0_b4_t64"):
     print(f"wrote {path}: relative distance autocast(bf16) - fp32 per loss: {np.array2string(d, precision=5)}")
 
 
+def run_trajectory_case(name="c0_b4_t64", n_steps=20, n_inputs=5):
+    """The reference's own training trajectory: `step()` (variational_base_vae.py:58-70: zero_grad, forward, loss, backward,
+    Adam, 8 x .item()) called n_steps times on a cycle of n_inputs seeded input pairs, the noise of every step drawn from the
+    reference's own stream and RECORDED.  Run with 1, 2, 4 and 8 intra-op threads — the same program, the same inputs, only
+    the summation order inside the BLAS / oneDNN kernels changes — so the fixture also holds how far the REFERENCE is from
+    itself per step and loss (its own reproducibility band), and once more under torch.autocast("cpu", bfloat16), the only bf16
+    execution the reference has.  tests/test_oracle_golden.py (CPU oracle) and tests/test_hip_model.py / test_hip_bf16.py (HIP
+    path) are held to these vectors."""
+    import contextlib
+    _, batch, n_frames, seed, eps_seed = next(c for c in CASES if c[0] == name)
+    inputs = [synthetic_pair(batch, n_frames, seed + 101 * i) for i in range(n_inputs)]
+    out = {"batch": batch, "n_frames": n_frames, "seed": seed, "eps_seed": eps_seed, "n_steps": n_steps,
+           "n_inputs": n_inputs, "input_seeds": np.array([seed + 101 * i for i in range(n_inputs)]), "lr": 1e-4}
+
+    def run(threads, ctx, f64=False):
+        torch.set_num_threads(threads)
+        w = build(batch, n_frames)
+        if f64:          # the same program in double precision: parameters, inputs, Adam moments (eps stays the fp32 draw)
+            w.model.double()
+            w.optimizer = torch.optim.Adam(w.model.parameters(), lr=1e-4)
+        torch.manual_seed(eps_seed)
+        traj, eps_all = [], []
+        for s in range(n_steps):
+            st = torch.get_rng_state()       # what forward is about to draw (disentangled_vae.py:252,255,261), recorded
+            eps_all.append([torch.empty(batch, 28).normal_().numpy(), torch.empty(batch, 28).normal_().numpy(),
+                            torch.empty(batch, 4).normal_().numpy()])
+            torch.set_rng_state(st)
+            x1, x2 = inputs[s % n_inputs]
+            if f64:
+                x1, x2 = x1.double(), x2.double()
+            with ctx:
+                traj.append(w.step(x1, x2, None, train=True))
+        pn = np.array([float(p.detach().double().norm()) for _, p in w.model.named_parameters()])
+        return np.array(traj, dtype=np.float64), eps_all, pn
+
+    threads = [1, 2, 4, 8]
+    runs = []
+    for t in threads:
+        tr, eps_all, pn = run(t, contextlib.nullcontext())
+        runs.append(tr)
+        out[f"param_norm_after_fp32_t{t}"] = pn
+        print(f"fp32 threads={t}: LOSS step 1 {tr[0, 0]:.6f} step {n_steps} {tr[-1, 0]:.6f}")
+    out["threads"] = np.array(threads)
+    out["traj_fp32"] = np.stack(runs)                            # [threads, steps, 8]
+    out["eps_c1"] = np.stack([e[0] for e in eps_all])            # [steps, B, 28] (the same stream in every run)
+    out["eps_c2"] = np.stack([e[1] for e in eps_all])
+    out["eps_s"] = np.stack([e[2] for e in eps_all])
+    # the reference in DOUBLE precision: how far its own fp32 execution is from exact arithmetic, step by step — the
+    # distance any other fp32 implementation (another summation order) may equally keep
+    tr64, _, _ = run(8, contextlib.nullcontext(), f64=True)
+    out["traj_fp64"] = tr64
+    d64 = np.abs(out["traj_fp32"][-1] - tr64) / np.maximum(1e-12, np.abs(tr64))
+    print("fp32 (8 threads) vs fp64, per step (max over losses):", np.array2string(d64.max(1), precision=2))
+    print("   step 2 per loss:", np.array2string(d64[1], precision=2))
+    ac = []
+    for t in (1, 8):
+        tr, _, _ = run(t, torch.autocast("cpu", dtype=torch.bfloat16))
+        ac.append(tr)
+        print(f"autocast(bf16) threads={t}: LOSS step 1 {tr[0, 0]:.6f} step {n_steps} {tr[-1, 0]:.6f}")
+    out["traj_autocast_bf16"] = np.stack(ac)                     # [2, steps, 8]
+    ref = out["traj_fp32"][-1]
+    spread = np.abs(out["traj_fp32"] - ref[None]).max(0) / np.maximum(1e-12, np.abs(ref))
+    print("reference's own spread over thread counts, per step (max over the 8 losses):")
+    print(np.array2string(spread.max(1), precision=2))
+    dist = np.abs(out["traj_autocast_bf16"][-1] - ref) / np.maximum(1e-12, np.abs(ref))
+    print("autocast(bf16) distance per step (max over losses):", np.array2string(dist.max(1), precision=2))
+    path = os.path.join(HERE, f"trajectory_{name}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path))
+
+
 if __name__ == "__main__":
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     if only in ("", "bf16_autocast"):
@@ -345,3 +416,5 @@ if __name__ == "__main__":
         run_conversion_case()
     if only in ("", "dataset"):
         run_dataset_case()
+    if only in ("", "trajectory"):
+        run_trajectory_case()

@@ -3,6 +3,8 @@ operands to bf16 (nearest-even) and accumulates in fp32.  A product of two bf16 
 PyTorch reference fed the SAME rounded operands only the summation order differs: tolerance 2e-5 of the tensor scale
 (tighter than the fp32 tests), i.e. a wrong fragment layout or a missed rounding cannot hide.  Against the unrounded
 fp32 reference the distance must be of bf16 size (~1e-3..1e-2): that checks the mode is really on."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -443,6 +445,28 @@ def test_model_bf16_full_size_losses_inside_the_references_autocast_band(ops, fi
     for grp in (slice(0, 5), slice(5, 8)):
         assert ours[grp].max() <= 1.5 * band[grp].max(), (ours, band)
     assert ours.max() > 1e-7
+
+
+def test_model_bf16_trajectory_inside_the_references_autocast_trajectory(ops, golden_dir):
+    """20 training steps of the bf16 mode against the REAL reference's trajectories: its fp32 one (8 threads) is the target,
+    the distance its own autocast(bf16) run keeps from it — recorded per step and loss, 1 and 8 threads — x 1.5 is the
+    band (conftest.trajectory_band_bf16; never tighter than the mode's 2e-3 end-to-end bound or the fp32 band)."""
+    from conftest import trajectory_band_bf16
+    from oracle.fill import synthetic_pair
+    g = np.load(os.path.join(golden_dir, "trajectory_c0_b4_t64.npz"))
+    ref, band = trajectory_band_bf16(g)
+    B, T = int(g["batch"]), int(g["n_frames"])
+    w = _make(B, T)
+    inputs = [tuple(t.cuda() for t in synthetic_pair(B, T, int(s))) for s in g["input_seeds"]]
+    worst = []
+    for s in range(int(g["n_steps"])):
+        w.model.eps_override = tuple(torch.from_numpy(g[k][s]) for k in ("eps_c1", "eps_c2", "eps_s"))
+        x1, x2 = inputs[s % len(inputs)]
+        got = np.array(w.step(x1, x2, None, train=True))
+        d = np.abs(got - ref[s]) / np.maximum(1e-12, np.abs(ref[s]))
+        worst.append(float((d / band[s]).max()))
+        assert np.all(d <= band[s]), (s, d, band[s])
+    print("bf16 trajectory: worst distance / band per step:", np.array2string(np.array(worst), precision=2))
 
 
 def test_model_bf16_gradients_inside_the_references_autocast_band(ops):

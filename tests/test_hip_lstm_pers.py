@@ -396,4 +396,8 @@ def test_deployment_selftest_passes_here(env):
     from dvae_amd import selftest
     lines = []
     assert selftest.run(rounds=6, log=lines.append) == 0, "\n".join(lines)
-    assert any("PASSED" in ln for ln in lines) and sum("bad rounds of 6" in ln for ln in lines) == 5, lines
+    assert any("PASSED" in ln for ln in lines), lines
+    # seven cases (five at T <= 64, two at the T = 512 of configs[4]): every one either ran clean or was reported as skipped
+    ran = sum("0 bad rounds of" in ln for ln in lines)
+    skipped = sum("(skipped)" in ln for ln in lines)
+    assert ran + skipped == 7 and ran >= 1, lines

@@ -94,13 +94,39 @@ def test_two_steps_against_reference_golden(golden_dir, name):
     s2 = w.step(x2, x1, None, train=True)
     for i in range(8):
         assert rel(s1[i], g["step1"][i]) <= LOSS_RTOL, (i, s1[i], g["step1"][i])
-    # The second step runs on Adam-updated weights.  Adam's first update is lr*sign(g) per weight, so every
-    # gradient element that is zero up to round-off moves its weight by +-lr on either side independently:
-    # the reference itself is only reproducible to this level across BLAS builds.  L1 terms 1e-3, KL terms 1e-2.
+    # The second step runs on Adam-updated weights.  Adam's first update is lr*sign(g) per weight, so every gradient
+    # element that is zero up to round-off moves its weight by +-lr on either side independently: how far that moves the
+    # REFERENCE from itself is measured, not argued — tests/golden/trajectory_c0_b4_t64.npz holds its trajectory at four
+    # thread counts (step 2: <= 1.1e-7 on the L1 terms, <= 4e-6 on the KL terms; test_trajectory_... below holds all 20
+    # steps to 3 x that spread).  Here, on other shapes and one realisation of the reference: 1e-4 on the L1 terms (the
+    # single-step contract), 1e-3 on the KL terms.
+    print(name, "step 2 relative distances:", [f"{rel(s2[i], g['step2'][i]):.1e}" for i in range(8)])
     for i in range(8):
-        assert rel(s2[i], g["step2"][i]) <= (1e-3 if i < 5 else 1e-2), (i, s2[i], g["step2"][i])
+        assert rel(s2[i], g["step2"][i]) <= (LOSS_RTOL if i < 5 else 1e-3), (i, s2[i], g["step2"][i])
     pn = np.array([float(p.detach().double().norm()) for _, p in w.model.named_parameters()])
     np.testing.assert_allclose(pn, g["param_norm_after2"], rtol=1e-3, atol=2e-3)
+
+
+def test_trajectory_inside_the_references_own_spread(golden_dir):
+    """20 training steps of the HIP path (default arithmetic) against the REAL reference's trajectory
+    (/root/reference/model/variational_base_vae.py:58-70 called 20 times on five cycled input pairs, noise recorded):
+    every loss of every step within max(1e-4, 3 x the distance the reference keeps from ITSELF at 1 / 2 / 4 / 8 threads)
+    (conftest.trajectory_band) — the multi-step pin that replaces the argued step-2 tolerances."""
+    from conftest import trajectory_band
+    g = np.load(os.path.join(golden_dir, "trajectory_c0_b4_t64.npz"))
+    ref, band = trajectory_band(g)
+    B, T = int(g["batch"]), int(g["n_frames"])
+    w = make(B, T, lr=float(g["lr"]))
+    inputs = [tuple(t.cuda() for t in synthetic_pair(B, T, int(s))) for s in g["input_seeds"]]
+    worst = []
+    for s in range(int(g["n_steps"])):
+        w.model.eps_override = tuple(torch.from_numpy(g[k][s]) for k in ("eps_c1", "eps_c2", "eps_s"))
+        x1, x2 = inputs[s % len(inputs)]
+        got = np.array(w.step(x1, x2, None, train=True))
+        d = np.abs(got - ref[s]) / np.maximum(1e-12, np.abs(ref[s]))
+        worst.append(float((d / band[s]).max()))
+        assert np.all(d <= band[s]), (s, d, band[s])
+    print("trajectory: worst distance / band per step:", np.array2string(np.array(worst), precision=2))
 
 
 def test_against_oracle_b8_t64_full_gradients():

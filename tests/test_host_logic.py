@@ -415,4 +415,6 @@ def test_abort_process_group_never_blocks_or_raises():
     import inspect
     src = inspect.getsource(train.main)
     body = src[src.index("except BaseException"):]
-    assert "_abort_process_group()" in body and body.index("raise") < body.index("dist.barrier()")
+    # (round 6: the abort runs on a thread of its own with a five-second bound, then os._exit(1) — ADVICE r5)
+    assert "target=_abort_process_group" in body and "os._exit(1)" in body
+    assert body.index("raise") < body.index("dist.barrier()")

@@ -28,6 +28,12 @@ def test_gpus_2_launches_two_cooperating_ranks():
     # the slowest rank (rank 1 sleeps 2 ms per step) sets the time: max over ranks, not rank 0's own
     assert out["ms_per_step"] >= 1.9, out
     assert sum(l.lstrip().startswith("{") for l in lines) == 1          # ONE JSON line
+    # the keys every N > 1 line carries: the ranks that really cooperated, the DEFAULT exchange — the
+    # one train.py runs, which is what `value` is — and the fastest variant beside it, never instead of it
+    assert out["rccl_ranks"] == 2
+    assert set(out["ddp_default"]) >= {"variant", "ms_per_step", "value"} and out["ddp_default"]["variant"] == "all_reduce:finish"
+    assert set(out["ddp_fastest"]) >= {"variant", "ms_per_step", "value"}
+    assert "ddp_variants_ms_per_step" in out
 
 
 def test_world_size_mismatch_is_an_error_not_a_silent_single_rank_run():

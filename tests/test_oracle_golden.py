@@ -100,3 +100,30 @@ def test_conversion_path_against_reference(golden_dir):
     np.testing.assert_allclose(out["source"].numpy(), g["source_cat"], rtol=0, atol=0)
     np.testing.assert_allclose(out["recons"].numpy(), g["recons"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out["converted"].numpy(), g["converted"], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_trajectory_inside_the_references_own_spread(golden_dir):
+    """20 training steps of the oracle against the REAL reference's own trajectory (variational_base_vae.py:58-70 called 20
+    times on five cycled input pairs, its noise recorded): every loss of every step within 3 x the distance the reference
+    keeps from ITSELF when only its thread count changes (conftest.trajectory_band), and the first step — before any
+    chaotic amplification — at the 2e-6 of the single-step goldens."""
+    from conftest import trajectory_band
+    g = _load(golden_dir, "trajectory_c0_b4_t64")
+    ref, band = trajectory_band(g)
+    tr = _trainer(g)
+    B, T = int(g["batch"]), int(g["n_frames"])
+    inputs = [synthetic_pair(B, T, int(s)) for s in g["input_seeds"]]
+    worst = 0.0
+    for s in range(int(g["n_steps"])):
+        eps = tuple(torch.from_numpy(g[k][s]) for k in ("eps_c1", "eps_c2", "eps_s"))
+        x1, x2 = inputs[s % len(inputs)]
+        got = np.array(tr.step(x1, x2, eps, train=True))
+        d = np.abs(got - ref[s]) / np.maximum(1e-12, np.abs(ref[s]))
+        assert np.all(d <= band[s]), (s, d, band[s])
+        if s == 0:
+            np.testing.assert_allclose(got, ref[0], rtol=2e-6)
+        worst = max(worst, float((d / band[s]).max()))
+    assert worst <= 1.0
+    # the reference's autocast(bf16) trajectory is recorded beside it: sanity of the fixture itself
+    ac = g["traj_autocast_bf16"]
+    assert ac.shape == (2, int(g["n_steps"]), 8) and np.all(np.isfinite(ac))
