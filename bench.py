@@ -84,7 +84,7 @@ def log(msg):
 
 def kernel_source_hash():
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in ("gemm.hip", "gemm256.hip", "gemm_common.h", "common.h"):
         with open(os.path.join(ROOT, "disentangle-vae-for-vc_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -403,7 +403,7 @@ def time_other_config(dev, name, B, T, dtype, steps=5):
         t1, tot1, t2, tot2 = profile_families(w, x1, x2, spk, ops, 2)
         if tot1[0] > 0:
             ach = tot1[2] / (tot1[0] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "contraction family (gemm_bf16_tall_kernel / gemm_f32_kernel<MODE=1>)",
+            out["roofline"] = {"bound": "mfma", "kernel": "contraction family (gemm_bf16_256_kernel / gemm_bf16_tall_kernel / gemm_f32_kernel<MODE=1>)",
                                "achieved": ach, "peak": PEAKS[dtype], "unit": "TFLOP/s", "frac": ach / PEAKS[dtype],
                                "kernel_ms_per_step": tot1[0] / 2, "launches_per_step": tot1[1] / 2,
                                "instantiations": [{"kernel": t["kernel"], "ms_per_step": t["ms"] / 2,
@@ -759,7 +759,7 @@ def main():
                     traffic_src = "profiles/pmc_traffic.json was collected for other kernel sources / another workload: not used"
             except Exception:
                 pass
-            roof = {"bound": "mfma", "kernel": "contraction family: gemm_f32_kernel<...> + gemm_x3_tall_kernel<...> (" + ARITH[dtype] + ")",
+            roof = {"bound": "mfma", "kernel": "contraction family: " + ("gemm_bf16_256_kernel / gemm_bf16_tall_kernel / gemm_f32_kernel<MODE=1>" if dtype == "bf16" else "gemm_f32_kernel<...> + gemm_x3_tall_kernel<...>") + " (" + ARITH[dtype] + ")",
                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "peak_note": {"fp32x3": "2500 TFLOP/s dense bf16 MFMA / 6 bf16 partial products per fp32 product",
                                   "fp32": "fp32 MFMA = vector rate", "bf16": "dense bf16 MFMA"}[dtype],

@@ -27,7 +27,16 @@ class LstmDir(C.Structure):
     """dvae_lstm_dir_t"""
     _fields_ = [("gates", vp), ("w_hh", vp), ("h_out", vp), ("c_all", vp), ("dh_out", vp),
                 ("dgates", vp), ("dc_ws", vp), ("w_packed", vp), ("reverse", i32), ("packed_mode", i32),
-                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint), ("dbias_ih", vp), ("dbias_hh", vp), ("gate_ld", i64)]
+                ("step_shift", i32), ("state_bf16", i32), ("pers_ws", vp), ("pers_timeout_us", C.c_uint), ("dbias_ih", vp), ("dbias_hh", vp), ("dbias_part", vp), ("gate_ld", i64)]
+
+
+class SlabDesc(C.Structure):
+    """dvae_slab_desc_t"""
+    _fields_ = [("c", vp), ("slab", vp), ("slab_stride", i64), ("n", i64), ("nslab", i32), ("pad_", i32)]
+
+
+SLAB_FOLD_MAX = 64        # DVAE_SLAB_FOLD_MAX
+PERS_BIAS_SLABS = 16      # DVAE_PERS_BIAS_SLABS
 
 
 class RepackDesc(C.Structure):
@@ -52,7 +61,7 @@ COMPUTE_MODES = {"fp32": MODE_F32, "f32": MODE_F32, "float32": MODE_F32, "bf16":
                  "fp32x3": MODE_F32X3, "f32x3": MODE_F32X3}
 
 DEFAULT_COMPUTE_DTYPE = "fp32x3"
-ABI_VERSION = 306     # DVAE_ABI_VERSION of include/dvae_hip.h
+ABI_VERSION = 307     # DVAE_ABI_VERSION of include/dvae_hip.h
 
 # name -> (restype, argtypes); mirrors include/dvae_hip.h one to one
 SIGNATURES = {
@@ -95,6 +104,16 @@ SIGNATURES = {
     "dvae_loss_fwd": (i32, [C.POINTER(LossDesc), vp, vp, vp]),
     "dvae_loss_bwd": (i32, [C.POINTER(LossDesc), vp] + [vp] * 10 + [vp]),
     "dvae_gemm_f32_batched": (i32, [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "dvae_gemm_f32_slabs": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "dvae_gemm_f32_batched_slabs": (i32, [vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i64, i64, i64, i32, i32, i32, i32,
+                                          i32, vp]),
+    "dvae_conv5_fwd_slabs": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv5_dgrad_t_slabs": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "dvae_conv5_wgrad_slabs": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "dvae_slab_sum": (i32, [vp, vp, i64, i32, i64, i32, vp]),
+    "dvae_slab_fold": (i32, [C.POINTER(SlabDesc), i32, vp]),
+    "dvae_colsum_ws_bytes": (i64, [i32, i32]),
+    "dvae_colsum_add_ws": (i32, [vp, vp, vp, i32, i32, i64, i32, vp, vp]),
     "dvae_adam_flat": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, vp]),
     "dvae_adam_flat_dev": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, vp, vp, vp, i32, vp]),
     "dvae_lstm_pers_err_word": (vp, [vp]),

@@ -861,6 +861,162 @@ DVAE_API int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int
   return dvae_check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k-split without atomics (round 6): the partial products a contraction stored into slabs (dvae_gemm_f32_slabs ...) are
+// added to the result in the FIXED order ks = 1, 2, ...: every element has one writer and one summation order, so the
+// result is run-to-run bit-identical.  HBM-bound: (nslab + 2) * 4 bytes per element.
+__global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ C, const float* __restrict__ slab, int64_t stride,
+                                                       int nslab, int64_t n4, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(C + 4 * i);
+    for (int k = 0; k < nslab; ++k) v += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * stride + 4 * i);
+    if (act != DVAE_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
+    }
+    *reinterpret_cast<f32x4*>(C + 4 * i) = v;
+  }
+}
+// C[i] = act(C[i] + sum_k slab[k * slab_stride + i]), i < n (n, slab_stride multiples of 4; 16-byte aligned pointers)
+DVAE_API int dvae_slab_sum(float* C, const float* slab, int64_t slab_stride, int nslab, int64_t n, int act, void* stream) {
+  if (!C || n < 4 || (n & 3) || nslab < 0 || (nslab > 0 && (!slab || (slab_stride & 3) || (((uintptr_t)slab) & 15))) ||
+      (((uintptr_t)C) & 15))
+    return DVAE_EINVAL;
+  if (nslab == 0 && act == DVAE_ACT_NONE) return DVAE_OK;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(nblk(n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, C, slab, slab_stride,
+                     nslab, n >> 2, act);
+  return dvae_check_launch();
+}
+
+// the same for MANY results in one launch (the weight gradients of a step, in front of the Adam launch or of a bucket's
+// collective): entry e adds its nslab slabs to its n elements.  The table travels as a kernel argument (<= 64 entries).
+struct SlabTable {
+  dvae_slab_desc_t e[DVAE_SLAB_FOLD_MAX];
+};
+__global__ __launch_bounds__(256) void slab_fold_kernel(const SlabTable t) {
+  const dvae_slab_desc_t d = t.e[blockIdx.y];
+  const int64_t n4 = d.n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(d.c + 4 * i);
+    for (int k = 0; k < d.nslab; ++k) v += *reinterpret_cast<const f32x4*>(d.slab + (int64_t)k * d.slab_stride + 4 * i);
+    *reinterpret_cast<f32x4*>(d.c + 4 * i) = v;
+  }
+}
+DVAE_API int dvae_slab_fold(const dvae_slab_desc_t* descs, int n_entries, void* stream) {
+  if (!descs || n_entries < 0) return DVAE_EINVAL;
+  for (int base = 0; base < n_entries; base += DVAE_SLAB_FOLD_MAX) {
+    SlabTable t{};
+    const int m = n_entries - base < DVAE_SLAB_FOLD_MAX ? n_entries - base : DVAE_SLAB_FOLD_MAX;
+    int64_t nmax = 0;
+    for (int i = 0; i < m; ++i) {
+      const dvae_slab_desc_t& d = descs[base + i];
+      if (!d.c || !d.slab || d.n < 4 || (d.n & 3) || (d.slab_stride & 3) || d.nslab < 1 ||
+          ((((uintptr_t)d.c) | ((uintptr_t)d.slab)) & 15))
+        return DVAE_EINVAL;
+      t.e[i] = d;
+      nmax = d.n > nmax ? d.n : nmax;
+    }
+    hipLaunchKernelGGL(slab_fold_kernel, dim3(nblk(nmax / 4, 256, 512), m), dim3(256), 0, (hipStream_t)stream, t);
+  }
+  return dvae_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Column sums WITHOUT atomics: every workgroup stores the partial sums of its row block, the LAST workgroup of a column
+// block to arrive (a ticket counter per column block, agent-scope release / acquire around it) adds them up in row-block
+// order and is the one writer of out[c].  ws: [column blocks] counters (zero when the call starts, left zero) + the partials.
+template <bool XB16>
+__global__ __launch_bounds__(256) void colsum_ws_kernel(const void* __restrict__ Xv, float* __restrict__ o1,
+                                                        float* __restrict__ o2, int R, int C, int64_t ld, int rows_pb,
+                                                        unsigned* __restrict__ cnt, float* __restrict__ part) {
+  using elem_t = typename std::conditional<XB16, __bf16, float>::type;
+  const elem_t* __restrict__ X = reinterpret_cast<const elem_t*>(Xv);
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cl) * 4;
+  const int r0 = blockIdx.y * rows_pb, r1 = min(R, r0 + rows_pb);
+  const int Cp = gridDim.x * 256;                    // padded row length of the partials
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (c + 3 < C) {
+    const elem_t* __restrict__ px = X + (int64_t)(r0 + rl) * ld + c;
+    const int n = (r1 - r0 - rl + 3) >> 2;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ld4<XB16>(px + (int64_t)(i + u) * 4 * ld, 0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < n; ++i) s += ld4<XB16>(px + (int64_t)i * 4 * ld, 0);
+  } else if (c < C) {
+    for (int r = r0 + rl; r < r1; r += 4)
+      for (int k = 0; k < 4 && c + k < C; ++k) s[k] += (float)X[(int64_t)r * ld + c + k];
+  }
+  __shared__ f32x4 red[4][64];
+  __shared__ int last;
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0) {
+    const f32x4 tot = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.y * Cp + (blockIdx.x * 64 + cl) * 4) = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(cnt + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (tk == gridDim.y - 1);
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (!last) return;
+  // wave rl adds the row blocks rl, rl + 4, ... in that order, then the four waves' sums are combined in a fixed tree: the
+  // same sum in every run
+  f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (unsigned b = rl; b < gridDim.y; b += 4)
+    ps += *reinterpret_cast<const f32x4*>(part + (int64_t)b * Cp + (blockIdx.x * 64 + cl) * 4);
+  red[rl][cl] = ps;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    const f32x4 tot = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c + k >= C) break;
+      o1[c + k] += tot[k];
+      if (o2) o2[c + k] += tot[k];
+    }
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(cnt + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static inline int colsum_rows_pb(int R, int C) {
+  const int cb = (C + 255) / 256;
+  return ((int64_t)R * cb >= (int64_t)512 * 1024) ? 1024 : 512;
+}
+DVAE_API int64_t dvae_colsum_ws_bytes(int R, int C) {
+  if (R < 1 || C < 1) return 0;
+  const int cb = (C + 255) / 256, rows_pb = colsum_rows_pb(R, C);
+  return 4096 + (int64_t)((R + rows_pb - 1) / rows_pb) * cb * 256 * 4;
+}
+// out1[c] (and out2[c]) += sum_r X[r][c], deterministic (see above).  ws: >= dvae_colsum_ws_bytes(R, C) bytes, 16-byte aligned,
+// its first 4096 bytes ZERO before the first call (the counters; every call leaves them zero); one ws per stream in flight
+DVAE_API int dvae_colsum_add_ws(const void* X, float* out1, float* out2, int R, int C, int64_t ld, int x_bf16, void* ws,
+                                void* stream) {
+  if (!X || !out1 || !ws || R < 1 || C < 1 || C > 256 * 1024) return DVAE_EINVAL;
+  if ((ld & 3) || (((uintptr_t)X) & (x_bf16 ? 7 : 15)) || (((uintptr_t)ws) & 15)) return DVAE_EINVAL;
+  const int cb = (C + 255) / 256, rows_pb = colsum_rows_pb(R, C);
+  dim3 grid(cb, (R + rows_pb - 1) / rows_pb);
+  unsigned* cnt = (unsigned*)ws;
+  float* part = (float*)((char*)ws + 4096);
+  if (x_bf16) hipLaunchKernelGGL(colsum_ws_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb, cnt, part);
+  else hipLaunchKernelGGL(colsum_ws_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, X, out1, out2, R, C, ld, rows_pb, cnt, part);
+  return dvae_check_launch();
+}
+
 DVAE_API int dvae_transpose(const float* in, float* out, int R, int C, void* stream) {
   if (!in || !out || R < 1 || C < 1) return DVAE_EINVAL;
   dim3 grid((C + 31) / 32, (R + 31) / 32);

@@ -61,6 +61,8 @@ struct PersArgs {
   char* dgates;          // backward: [T,N,4H] bf16 (s16) or fp32
   float* db1;            // backward, optional: += column sums of dG over all frames and rows (bias gradients)
   float* db2;
+  float* dbp;            // backward, optional, instead of db1 / db2: row group rb STORES its share at dbp[(rb * 4 + g) * H + unit]
+                         // (one writer per element; the caller adds the n_rb slabs in a fixed order: no atomics)
   unsigned* flags;       // ws + 0
   unsigned* err;         // ws + PERS_ERR_OFF
   char* xch;             // ws + PERS_XCH_OFF
@@ -178,6 +180,39 @@ constexpr int NWV = 4;
 #ifndef PERS_PD_BWD2
 #define PERS_PD_BWD2 6
 #endif
+
+// Bias gradients of a backward launch: every thread holds its share bs[g] of the column sums of dG (its elements over all
+// frames) for hidden unit `unit` (0 .. NU-1 inside this workgroup's block at j0).  The workgroup's sums are formed in a FIXED
+// order (thread order; the round-5 form added them with LDS atomics, whose order changes from run to run), then either
+// STORED into this row group's slab of a.dbp (round 6: run-to-run bit-identical gradients, the default) or added to
+// a.db1 / a.db2 with global atomics (the older interface).  The frame loop's LDS is dead here; the launch has >= 84 KB.
+template <int NU>
+__device__ __forceinline__ void pers_bias_out(const PersArgs& a, char* lds_raw, const float (&bs)[4], int unit, int rb,
+                                              int j0, int H) {
+  if (!(a.db1 || a.db2 || a.dbp)) return;
+  __syncthreads();
+  float* val = reinterpret_cast<float*>(lds_raw + 65536);        // [4][256]
+  int* un = reinterpret_cast<int*>(lds_raw + 65536 + 4096);      // [256]
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) val[g * 256 + tid] = bs[g];
+  un[tid] = unit;
+  __syncthreads();
+  if (tid < 4 * NU) {
+    const int g = tid / NU, u = tid % NU;
+    float v = 0.f;
+    for (int t = 0; t < 256; ++t) v += (un[t] == u) ? val[g * 256 + t] : 0.f;
+    if (a.dbp) {
+      a.dbp[((int64_t)rb * 4 + g) * H + j0 + u] = v;
+      // the caller always adds DVAE_PERS_BIAS_SLABS row-group slabs: row group 0 clears the ones this launch does not have
+      if (rb == 0)
+        for (int r2 = a.n_rb; r2 < DVAE_PERS_BIAS_SLABS; ++r2) a.dbp[((int64_t)r2 * 4 + g) * H + j0 + u] = 0.f;
+    } else {
+      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
+      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
+    }
+  }
+}
 
 // ======================================================================================================================
 // forward:  G = Xproj[t] + h[t-1] W_hh^T ; i,f,o = sigmoid, g = tanh ; c = f c' + i g ; h = o tanh(c)
@@ -640,18 +675,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
   }
-  if (a.db1 || a.db2) {
-    // db_ih = db_hh = sum over frames and rows of dG (replaces a colsum pass over [T*N, 4H])
-#pragma unroll
-    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][eunit], bs[g]);
-    __syncthreads();
-    if (tid < 128) {
-      const int g = tid >> 5, u = tid & 31;
-      const float v = L.bsum[g][u];
-      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
-      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
-    }
-  }
+  // db_ih = db_hh = sum over frames and rows of dG (replaces a colsum pass over [T*N, 4H])
+  pers_bias_out<32>(a, lds_raw, bs, eunit, rb, j0, H);
   pers_finish(a);
 }
 
@@ -1502,17 +1527,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_f32(const PersArgs 
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
   }
-  if (a.db1 || a.db2) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][r], bs[g]);
-    __syncthreads();
-    if (tid < 64) {
-      const int g = tid >> 4, u = tid & 15;
-      const float v = L.bsum[g][u];
-      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
-      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
-    }
-  }
+  pers_bias_out<16>(a, lds_raw, bs, r, rb, j0, H);
   pers_finish(a);
 }
 
@@ -1756,17 +1771,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
   }
-  if (a.db1 || a.db2) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][r], bs[g]);
-    __syncthreads();
-    if (tid < 64) {
-      const int g = tid >> 4, u = tid & 15;
-      const float v = L.bsum[g][u];
-      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
-      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
-    }
-  }
+  pers_bias_out<16>(a, lds_raw, bs, r, rb, j0, H);
   pers_finish(a);
 }
 
@@ -2100,17 +2105,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3k(const PersArgs 
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
   }
-  if (a.db1 || a.db2) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) atomicAdd(&L.bsum[g][r], bs[g]);
-    __syncthreads();
-    if (tid < 64) {
-      const int g = tid >> 4, u = tid & 15;
-      const float v = L.bsum[g][u];
-      if (a.db1) atomicAdd(a.db1 + g * H + j0 + u, v);
-      if (a.db2) atomicAdd(a.db2 + g * H + j0 + u, v);
-    }
-  }
+  pers_bias_out<16>(a, lds_raw, bs, r, rb, j0, H);
   pers_finish(a);
 }
 
@@ -2304,6 +2299,8 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
   a.dh_out = d.dh_out; a.dgates = (char*)d.dgates;
   a.db1 = bwd ? d.dbias_ih : nullptr; a.db2 = bwd ? d.dbias_hh : nullptr;
+  a.dbp = bwd ? d.dbias_part : nullptr;
+  if (a.dbp) a.db1 = a.db2 = nullptr;
   char* ws = (char*)d.pers_ws;
   a.flags = (unsigned*)ws; a.err = (unsigned*)(ws + PERS_ERR_OFF); a.xch = ws + PERS_XCH_OFF;
   a.T = T; a.N = N; a.ldh = ldh; a.reverse = d.reverse; a.s16 = d.state_bf16 ? 1 : 0;

@@ -44,6 +44,7 @@ class GradReducer:
         if mode not in ("all_reduce", "rs_ag") or issue not in ("hook", "finish"):
             raise ValueError("GradReducer: mode is 'all_reduce' or 'rs_ag', issue is 'hook' or 'finish'")
         self.flat = flat_grad
+        self.params = list(params)
         self.group = group
         self.mode, self.issue = mode, issue
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -104,6 +105,9 @@ class GradReducer:
         self.works = []
         self.active = True
         ops.grad_ready_hook = self._ready
+        # the k-split slabs of a weight gradient (ops.wgrad_gemm) must be summed into the flat buffer before its bucket leaves:
+        # per reported parameter when buckets go out from the hooks, once for everything in finish() otherwise
+        ops.fold_on_ready = self.issue == "hook"
 
     def _collective_on(self) -> bool:
         return self.world_size > 1 or (dist.is_initialized() and self.force)
@@ -143,7 +147,11 @@ class GradReducer:
     def finish(self):
         """Enqueue whatever was not triggered (parameters without gradient this step) and join."""
         ops.grad_ready_hook = None
+        ops.fold_on_ready = True
         ops.join_side()
+        for ow in {id(getattr(p, "_dvae_owner", None)): getattr(p, "_dvae_owner", None) for p in self.params}.values():
+            if ow is not None:
+                ops.fold_pending(ow)      # whatever was not summed from a hook: in front of the collectives below
         self.active = False
         self.stats["steps"] += 1
         for b in range(self.next_bucket, len(self.buckets)):

@@ -33,11 +33,31 @@ _side_dirty = False
 _cb_queued = False
 
 
+_fold_owners: list = []      # optimisers with k-split slabs pending from the running backward pass (see _defer_fold)
+
+
 def _end_of_backward():
     # autograd final callback: runs on the thread that called backward(), after the last node
     global _cb_queued
     _cb_queued = False
     join_side()
+    # the k-split slabs of this pass's weight gradients: ONE table-driven launch, so that `.grad` is complete when backward()
+    # returns (a reducer that issued from its hooks has summed its own already)
+    while _fold_owners:
+        fold_pending(_fold_owners.pop())
+
+
+def _queue_end_of_backward() -> bool:
+    """True when the final callback is (now) queued on the running backward pass; False outside one"""
+    global _cb_queued
+    if _cb_queued:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _cb_queued = True
+    except RuntimeError:
+        return False
+    return True
 
 
 def side_stream():
@@ -123,12 +143,189 @@ def _grad_buf(p: torch.Tensor) -> torch.Tensor:
     return p.grad
 
 
+fold_on_ready = True      # data parallel: sum a gradient's slabs when it is reported ready (a reducer that issues its
+                          # collectives only after backward clears this and sums everything once: GradReducer.finish)
+
+
 def _ready(*ps):
     if grad_ready_hook is not None:
         join_side()
+        if fold_on_ready:
+            fold_pending(params=[p for p in ps if p is not None])      # the collective reads the SUMMED gradient
         for p in ps:
             if p is not None:
                 grad_ready_hook(p)
+
+
+# ----------------------------------------------------------------------------- k-split slabs (no atomics)
+# A contraction that is cut along k stores every split's partial product plainly — split 0 into the result, the others into
+# slabs — and the slabs are added in a fixed order: every element has one writer and one summation order, so a train step is
+# run-to-run bit-identical in the DEFAULT mode (round 6; until then only under set_deterministic, which ran unsplit and
+# slower).  Weight gradients of an optimiser-owned parameter are summed LATER, by one table-driven launch at the end of the
+# backward pass (autograd's final callback; FlatAdam.step sums whatever is still pending) or — data parallel with
+# collectives issued from the hooks — when their bucket becomes ready (_ready); everything else (Linear outputs and
+# data gradients with few rows, stand-alone use in kernel tests) right behind the contraction (dvae_slab_sum, which also
+# applies the activation).
+_slab_param: dict = {}       # (data_ptr of the result, elements, cap) -> slab tensor of an optimiser-owned gradient
+_slab_scratch: dict = {}     # (device index, stream handle) -> scratch slabs of transient results (consumed on that stream)
+_colsum_ws: dict = {}        # (device index, stream handle) -> workspace of the deterministic column sums
+SLAB_CAP = 15                # slabs provided to a split contraction: up to 16 k-splits (the 256-row tiles cut K further
+                             # themselves, to one workgroup per CU)
+
+
+def _stream_key(dev):
+    """One scratch / workspace per device for the launches of the caller's stream (a captured graph replays on it and uses the
+    buffers the eager first step created), a second one for the opt-in side stream (its launches run beside the main stream's)."""
+    d = torch.device(dev)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    side = _side_stream is not None and torch.cuda.current_stream(idx).cuda_stream == _side_stream.cuda_stream
+    return idx, bool(side)
+
+
+_retired: list = []          # outgrown scratch buffers: kept alive, a graph captured earlier may still write into them
+
+
+def _pad4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def _scratch_slabs(dev, n_elems: int, cap: int):
+    """(slab tensor, stride) for a result of n_elems elements that is summed right away on the current stream"""
+    stride = _pad4(n_elems)
+    key = _stream_key(dev)
+    buf = _slab_scratch.get(key)
+    if buf is None or buf.numel() < cap * stride:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("k-split scratch would have to be allocated during a graph capture: run one eager step first")
+        if buf is not None:
+            _retired.append(buf)
+        buf = _slab_scratch[key] = torch.empty(max(cap * stride, 1 << 24), device=dev, dtype=torch.float32)
+    return buf, stride
+
+
+def _param_slabs(c: torch.Tensor, cap: int):
+    """(slab tensor, stride) that lives as long as the gradient view `c` it belongs to"""
+    stride = _pad4(c.numel())
+    key = (c.data_ptr(), c.numel(), cap)
+    buf = _slab_param.get(key)
+    if buf is None:
+        buf = _slab_param[key] = torch.empty(cap * stride, device=c.device, dtype=torch.float32)
+    return buf, stride
+
+
+def _fold_entry(c_ptr: int, slab_ptr: int, stride: int, n: int, nslab: int):
+    d = _lib.SlabDesc()
+    d.c, d.slab, d.slab_stride, d.n, d.nslab = c_ptr, slab_ptr, stride, n, nslab
+    return d
+
+
+def _fold_launch(entries):
+    if entries:
+        arr = (_lib.SlabDesc * len(entries))(*entries)
+        check(lib().dvae_slab_fold(arr, len(entries), stream()), "dvae_slab_fold")
+
+
+def _defer_fold(grad: torch.Tensor, owner, slab_ptr: int, stride: int, nslab: int, n: int = None):
+    """`nslab` slabs are to be added to `grad` (n elements, a multiple of 4): later when an optimiser owns it, now otherwise"""
+    if nslab < 1:
+        return
+    n = _pad4(grad.numel()) if n is None else n
+    e = _fold_entry(grad.data_ptr(), slab_ptr, stride, n, nslab)
+    if owner is None:
+        _fold_launch([e])
+        return
+    if not _queue_end_of_backward():      # not inside a backward pass (an op's backward called by hand): sum right away
+        _fold_launch([e])
+        return
+    pend = owner.__dict__.setdefault("_slab_pending", {})
+    key = (grad.data_ptr(), slab_ptr)
+    if key in pend:            # a second contribution to this gradient before the first was summed: sum that one now
+        _fold_launch([pend.pop(key)])
+    pend[key] = e
+    if not any(o is owner for o in _fold_owners):
+        _fold_owners.append(owner)
+
+
+def fold_pending(owner=None, params=None):
+    """Add every pending k-split slab to its gradient (one launch per 64 results): `owner`'s, or those of `params` only."""
+    if params is not None:
+        for p in params:
+            ow = getattr(p, "_dvae_owner", None)
+            pend = getattr(ow, "_slab_pending", None) if ow is not None else None
+            if pend and p.grad is not None:
+                lo, hi = p.grad.data_ptr(), p.grad.data_ptr() + 4 * p.grad.numel()
+                ks = [k for k in pend if lo <= k[0] < hi]
+                _fold_launch([pend.pop(k) for k in ks])
+        return
+    pend = getattr(owner, "_slab_pending", None)
+    if pend:
+        _fold_launch(list(pend.values()))
+        pend.clear()
+
+
+def wgrad_gemm_batched(As, Bs, params, M, N, K, lda, ldb, split_k, mode, flags=0):
+    """the weight gradients of len(params) (<= 4) parameters of one shape in ONE launch (dvae_gemm_f32_batched_slabs): each
+    += its product, k-splits behind the first into slabs (see wgrad_gemm)"""
+    a = lambda t: t if isinstance(t, int) else t.data_ptr()
+    nb = len(params)
+    grads = [_grad_buf(p) for p in params]
+    arr = lambda xs: (C.c_void_p * nb)(*[a(x) for x in xs])
+    m = _mflags(_mode(mode), As[0], Bs[0], grads[0]) | flags
+    if split_k <= 1:
+        check(lib().dvae_gemm_f32_batched(arr(As), arr(Bs), arr(grads), nb, M, N, K, lda, ldb, N, 0, 0, EPI_ACCUM, 1, m,
+                                          stream()), "dvae_gemm_f32_batched")
+        return
+    owner = _owner_of(params[0])
+    stride = _pad4(M * N)
+    cap = SLAB_CAP * nb
+    key = (grads[0].data_ptr(), M * N, cap)
+    slab = _slab_param.get(key) if owner is not None else None
+    if slab is None:
+        if owner is not None:
+            slab = _slab_param[key] = torch.empty(cap * stride, device=grads[0].device, dtype=torch.float32)
+        else:
+            slab, _ = _scratch_slabs(grads[0].device, cap * stride, 1)
+    n = lib().dvae_gemm_f32_batched_slabs(arr(As), arr(Bs), arr(grads), nb, ptr(slab), stride, cap, M, N, K, lda, ldb, N, 0, 0,
+                                          EPI_ACCUM, split_k, m, stream())
+    if n < 1:
+        check(n, "dvae_gemm_f32_batched_slabs")
+    for b, (g, p) in enumerate(zip(grads, params)):
+        _defer_fold(g, _owner_of(p), slab.data_ptr() + 4 * b * (n - 1) * stride, stride, n - 1)
+
+
+def _owner_of(p):
+    return getattr(p, "_dvae_owner", None)
+
+
+def gemm_slabs(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi, split_k, mode, slab, stride, cap, flags=0):
+    """dvae_gemm_f32_slabs: returns the number of k-splits launched (split 0 in Cout, the others in `slab`)"""
+    a = lambda t: t if (t is None or isinstance(t, int)) else t.data_ptr()
+    n = lib().dvae_gemm_f32_slabs(a(A), a(B), a(Cout), a(slab), stride, cap, a(bias), M, N, K, lda, ldb, ldc, int(a_kc),
+                                  int(b_kc), epi, split_k, _mflags(_mode(mode), A, B, Cout) | flags, stream())
+    if n < 1:
+        check(n, "dvae_gemm_f32_slabs")
+    return n
+
+
+def gemm_split(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, split_k, mode, flags=0):
+    """Cout = act(A B + bias) with K cut into (about) split_k parts and NO atomics: partial products into scratch slabs,
+    summed (and activated) right behind the contraction.  Cout: [M, N] contiguous (ldc == N)."""
+    n_el = M * ldc
+    slab, stride = _scratch_slabs(Cout.device, n_el, SLAB_CAP)
+    n = gemm_slabs(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, EPI_STORE, split_k, mode, slab, stride, SLAB_CAP, flags)
+    if n > 1 or act != ACT_NONE:
+        check(lib().dvae_slab_sum(ptr(Cout), ptr(slab), stride, n - 1, n_el, act, stream()), "dvae_slab_sum")
+
+
+def wgrad_gemm(A, B, grad, owner, M, N, K, lda, ldb, a_kc, b_kc, split_k, mode, flags=0):
+    """grad[M, N] += A^T B-shaped weight gradient, K cut into (about) split_k parts without atomics: split 0 adds to `grad`
+    (read-modify-write), the others store slabs that are summed later (optimiser-owned gradient) or now."""
+    if split_k <= 1:
+        gemm(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, ACT_NONE, EPI_ACCUM, 1, mode, flags)
+        return
+    slab, stride = _param_slabs(grad, SLAB_CAP) if owner is not None else _scratch_slabs(grad.device, grad.numel(), SLAB_CAP)
+    n = gemm_slabs(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, EPI_ACCUM, split_k, mode, slab, stride, SLAB_CAP, flags)
+    _defer_fold(grad, owner, slab.data_ptr(), stride, n - 1)
 
 
 _DETERMINISTIC = False
@@ -324,13 +521,10 @@ def linear_fwd(x, w, b, act=ACT_NONE, mode=None, w16=None):
     w = w if w16 is None else w16
     Nout = w.shape[0]
     sk = _split_k(_tiles(M, Nout), K)
-    if sk > 1:
-        y = zeros((M, Nout), x.device)
-        gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, ACT_NONE, EPI_ATOMIC, sk, mode)
-        if act != ACT_NONE:
-            check(lib().dvae_act_fwd(ptr(y), y.numel(), act, stream()), "dvae_act_fwd")
+    y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
+    if sk > 1 and (M * Nout) % 4 == 0:
+        gemm_split(x, w, y, b, M, Nout, K, K, K, Nout, True, True, act, sk, mode)
     else:
-        y = torch.empty((M, Nout), device=x.device, dtype=torch.float32)
         gemm(x, w, y, b, M, Nout, K, K, K, Nout, True, True, act, EPI_STORE, 1, mode)
     return y
 
@@ -341,17 +535,17 @@ def linear_dgrad(dy, w, mode=None, w16=None):
     M, Nout = dy.shape
     K = w.shape[1]
     sk = _split_k(_tiles(M, K), Nout)
-    if sk > 1:
-        dx = zeros((M, K), dy.device)
-        gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, ACT_NONE, EPI_ATOMIC, sk, mode)
+    dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
+    if sk > 1 and (M * K) % 4 == 0:
+        gemm_split(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, ACT_NONE, sk, mode)
     else:
-        dx = torch.empty((M, K), device=dy.device, dtype=torch.float32)
         gemm(dy, w, dx, None, M, K, Nout, Nout, K, K, True, False, mode=mode)
     return dx
 
 
-def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None, mode=None, store=False):
-    """wgrad[Nout,K] += dy[rows,Nout]^T @ x[rows,K] (atomic accumulation, split over rows).
+def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None, mode=None, store=False, owner=None):
+    """wgrad[Nout,K] += dy[rows,Nout]^T @ x[rows,K] (split over rows into slabs, summed later when `owner` — the optimiser
+    that owns the gradient buffer — is given, right away otherwise).
     store: the caller guarantees this launch is the ONLY contribution to `wgrad` this step and that nothing zeroed it
     (FlatAdam.zero_grad skips such parameters): an unsplit launch then STORES instead of read-modify-writing — for the two
     134 MB outer products (enc_linear, dec_pre_linear2: K = 2B rows only) that halves an HBM-bound launch."""
@@ -365,16 +559,25 @@ def linear_wgrad_acc(dy, x, wgrad, rows=None, lda=None, ldb=None, mode=None, sto
             raise ValueError("store-first weight gradient needs an unsplit launch")
         gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, EPI_STORE, 1, mode)
         return
-    # one split: every element has one writer, a plain read-modify-write (coalesced 128-B rows) replaces the atomics
-    epi = EPI_ATOMIC if (sk > 1 or os.environ.get("DVAE_WGRAD_ATOMIC") == "1") else EPI_ACCUM
-    gemm(dy, x, wgrad, None, Nout, K, rows, lda, ldb, K, False, False, ACT_NONE, epi, sk, mode)
+    # one split: a plain read-modify-write (coalesced 128-B rows); several: split 0 the same, the others into slabs — no atomics
+    wgrad_gemm(dy, x, wgrad, owner, Nout, K, rows, lda, ldb, False, False, sk, mode)
 
 
 def colsum_add(x, out1, out2=None, rows=None, cols=None, ld=None):
     rows = x.shape[0] if rows is None else rows
     cols = x.shape[1] if cols is None else cols
     ld = x.shape[1] if ld is None else ld
-    check(lib().dvae_colsum_add(ptr(x), ptr(out1), ptr(out2), rows, cols, ld, _b16(x), stream()), "dvae_colsum_add")
+    key = _stream_key(x.device)
+    need = lib().dvae_colsum_ws_bytes(rows, cols)
+    ws = _colsum_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("column-sum workspace would have to be allocated during a graph capture: run one eager step first")
+        if ws is not None:
+            _retired.append(ws)
+        ws = _colsum_ws[key] = torch.zeros(max(need, 1 << 23), device=x.device, dtype=torch.uint8)   # counters start at zero
+    check(lib().dvae_colsum_add_ws(ptr(x), ptr(out1), ptr(out2), rows, cols, ld, _b16(x), ptr(ws), stream()),
+          "dvae_colsum_add_ws")
 
 
 def mel_to_frames(x1, x2=None, dtype=torch.float32):
@@ -426,7 +629,7 @@ class LinearFn(torch.autograd.Function):
             if getattr(weight, "_dvae_grad_store_first", False) and not store:
                 raise RuntimeError("store-first weight gradient: the launch would be split; clear the flag "
                                    "(FlatAdam.set_store_first) for this shape")
-            linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode, store=store)
+            linear_wgrad_acc(dy, x, _grad_buf(weight), mode=ctx.mode, store=store, owner=_owner_of(weight))
             if store:
                 weight._dvae_sf_writes = getattr(weight, "_dvae_sf_writes", 0) + 1     # FlatAdam.step checks: exactly one
             colsum_add(dy, _grad_buf(bias))
@@ -475,11 +678,17 @@ class ConvBnActFn(torch.autograd.Function):
             mean = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             rstd = torch.empty((G, Cout), device=dev, dtype=torch.float32)
             ws = torch.empty((L.dvae_bn_ws_bytes(R, Cout, G),), device=dev, dtype=torch.uint8)
-            if 64 < Cout <= 128 and R >= 4096 and mode == MODE_F32X3 and not _DETERMINISTIC:
-                # few output columns (postnet's last conv: 80 mel channels): dvae_conv5_fwd cuts such a conv along k and
-                # accumulates atomically (csrc/gemm.hip narrow_conv_split) — no statistics in that epilogue: one pass over
-                # the [R, 80] result instead
-                check(L.dvae_conv5_fwd(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), R, n_seg, Cin, Cout, fmode, st), "dvae_conv5_fwd")
+            if 64 < Cout <= 128 and R >= 4096 and mode == MODE_F32X3 and (R * Cout) % 4 == 0:
+                # few output columns (postnet's last conv: 80 mel channels): the conv is cut along k (csrc/gemm.hip
+                # narrow_conv_split), its splits stored into slabs and summed right here (no atomics) — no statistics in
+                # that epilogue: one pass over the [R, 80] result instead
+                slab, stride = _scratch_slabs(dev, R * Cout, 7)
+                n = L.dvae_conv5_fwd_slabs(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), ptr(slab), stride, 7, R, n_seg, Cin, Cout,
+                                           fmode, st)
+                if n < 1:
+                    check(n, "dvae_conv5_fwd_slabs")
+                if n > 1:
+                    check(L.dvae_slab_sum(ptr(y), ptr(slab), stride, n - 1, R * Cout, ACT_NONE, st), "dvae_slab_sum")
                 check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt),
                                           ptr(ws), R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_fwd")
             else:
@@ -541,8 +750,18 @@ class ConvBnActFn(torch.autograd.Function):
             if wpt is None:
                 from .derived import conv_wpt_local
                 wpt = conv_wpt_local(conv_wp)
-            check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, _mflags(mode, dy, wpt), st),
-                  "dvae_conv5_dgrad_t")
+            if Cin <= 128 and (R * Cin) % 4 == 0:
+                # few output columns (the 80 mel channels): the default arithmetic cuts K to fill the chip — into slabs
+                slab, stride = _scratch_slabs(dev, R * Cin, 7)
+                n = L.dvae_conv5_dgrad_t_slabs(ptr(dy), ptr(wpt), ptr(dx), ptr(slab), stride, 7, R, n_seg, Cin, Cout,
+                                               _mflags(mode, dy, wpt), st)
+                if n < 1:
+                    check(n, "dvae_conv5_dgrad_t_slabs")
+                if n > 1:
+                    check(L.dvae_slab_sum(ptr(dx), ptr(slab), stride, n - 1, R * Cin, ACT_NONE, st), "dvae_slab_sum")
+            else:
+                check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, _mflags(mode, dy, wpt), st),
+                      "dvae_conv5_dgrad_t")
         with side_work(dy, xa):
             # the weight gradient goes straight into the (packed) gradient view: atomic split-K epilogue
             if Cout >= 256 and Cin > 64:
@@ -551,8 +770,18 @@ class ConvBnActFn(torch.autograd.Function):
                 sk = _split_k(5 * ((Cout + 255) // 256) * ((Cin + 127) // 128), R, slots=256, fixed=384)
             else:
                 sk = _split_k(5 * _tiles(Cout, Cin), R)
-            check(L.dvae_conv5_wgrad(ptr(dy), ptr(xa), ptr(_grad_buf(conv_wp)), R, n_seg, Cin, Cout, sk,
-                                     _mflags(mode, dy, xa), stream()), "dvae_conv5_wgrad")
+            # split 0 adds to the (packed) gradient view, the other k-splits store slabs that are summed in front of the
+            # Adam launch (or right here for a gradient no optimiser owns): no atomics
+            gw, own = _grad_buf(conv_wp), _owner_of(conv_wp)
+            slab, stride = (None, 0)
+            if sk > 1:
+                slab, stride = _param_slabs(gw, SLAB_CAP) if own is not None else _scratch_slabs(dev, gw.numel(), SLAB_CAP)
+            n = L.dvae_conv5_wgrad_slabs(ptr(dy), ptr(xa), ptr(gw), ptr(slab), stride, SLAB_CAP if sk > 1 else 0, R, n_seg,
+                                         Cin, Cout, EPI_ACCUM, sk, _mflags(mode, dy, xa), stream())
+            if n < 1:
+                check(n, "dvae_conv5_wgrad_slabs")
+            if n > 1:
+                _defer_fold(gw, own, slab.data_ptr(), stride, n - 1)
             colsum_add(dy, _grad_buf(conv_b))
         _ready(conv_wp, conv_b, bn_w, bn_b)
         dres = dz if has_res else None
@@ -782,13 +1011,24 @@ class LstmLayerFn(torch.autograd.Function):
             dirs[d].reverse = d
             dirs[d].state_bf16 = int(s16)
         pers = lstm_persistent_usable(N, H, bf, ndir, bwd=True)
-        pers_bias = pers and not _DETERMINISTIC      # (atomics across row groups and waves: not in the deterministic mode)
+        pers_bias = pers
         if pers:
             _pers_fill(dirs[0], dev)
         if pers_bias:
-            # the persistent launch also leaves the bias gradients (column sums of dG): no colsum pass below
-            dirs[0].dbias_ih, dirs[0].dbias_hh = ptr(_grad_buf(params[0][2])), ptr(_grad_buf(params[0][3]))
+            # the persistent launch also leaves the bias gradients (column sums of dG): no colsum pass below.  Every row
+            # group STORES its share into its own slab (no atomics); the slabs are added to both bias gradients (nn.LSTM
+            # keeps two) with the other k-split slabs, in a fixed order
+            bi, bh = params[0][2], params[0][3]
+            gbi, gbh = _grad_buf(bi), _grad_buf(bh)
+            key = (gbi.data_ptr(), 4 * H, "pers_bias")
+            part = _slab_param.get(key)
+            if part is None:
+                part = _slab_param[key] = torch.zeros(_lib.PERS_BIAS_SLABS * 4 * H, device=dev, dtype=torch.float32)
+            dirs[0].dbias_part = ptr(part)
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
+        if pers_bias:
+            for gb, par in ((gbi, bi), (gbh, bh)):
+                _defer_fold(gb, _owner_of(par), part.data_ptr(), 4 * H, _lib.PERS_BIAS_SLABS, n=4 * H)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((R, In), device=dev, dtype=torch.float32)
@@ -805,24 +1045,23 @@ class LstmLayerFn(torch.autograd.Function):
                 # tiles over 16 384 rows — the forward and the reverse direction's products share ONE launch
                 Nout, K = params[0][0].shape
                 sk = _split_k(2 * _tiles(Nout, K), R)
-                epi = EPI_ATOMIC if sk > 1 else EPI_ACCUM
-                gemm_batched(dgs, [x, x], [_grad_buf(params[0][0]), _grad_buf(params[1][0])], Nout, K, R, ldg, In, K,
-                             False, False, epi, sk, mode)
-                gws = [_grad_buf(params[0][1]), _grad_buf(params[1][1])]
+                wgrad_gemm_batched(dgs, [x, x], [params[0][0], params[1][0]], Nout, K, R, ldg, In, sk, mode)
                 if T > 1:
                     rows = R - N
                     sk = _split_k(2 * _tiles(4 * H, H), rows)
-                    gemm_batched([dgs[0].data_ptr() + esz * N * ldg, dgs[1].data_ptr()],
-                                 [h_out.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)], gws, 4 * H, H, rows, ldg, ldh, H,
-                                 False, False, EPI_ATOMIC if sk > 1 else EPI_ACCUM, sk, mode,
-                                 flags=(A_BF16 | B_BF16) if s16 else 0)
+                    wgrad_gemm_batched([dgs[0].data_ptr() + esz * N * ldg, dgs[1].data_ptr()],
+                                       [h_out.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)],
+                                       [params[0][1], params[1][1]], 4 * H, H, rows, ldg, ldh, sk, mode,
+                                       flags=(A_BF16 | B_BF16) if s16 else 0)
+                else:
+                    _grad_buf(params[0][1]), _grad_buf(params[1][1])
                 for d, (wi, wh, bi, bh) in enumerate(params):
                     if not pers_bias:
                         colsum_add(dgs[d], _grad_buf(bi), _grad_buf(bh), rows=R, cols=4 * H, ld=ldg)
             else:
               for d, (wi, wh, bi, bh) in enumerate(params):
                 dg = dgs[d]
-                linear_wgrad_acc(dg, x, _grad_buf(wi), mode=mode)
+                linear_wgrad_acc(dg, x, _grad_buf(wi), mode=mode, owner=_owner_of(wi))
                 gw = _grad_buf(wh)      # exists (zero) even when T == 1 leaves W_hh without a gradient
                 if T > 1:
                     rows = R - N
@@ -832,8 +1071,8 @@ class LstmLayerFn(torch.autograd.Function):
                     else:
                         a_ptr, b_ptr = dg.data_ptr(), h_out.data_ptr() + esz * (N * ldh + H)
                     sk = _split_k(_tiles(4 * H, H), rows)
-                    gemm(a_ptr, b_ptr, gw, None, 4 * H, H, rows, 4 * H, ldh, H, False, False, ACT_NONE, EPI_ATOMIC, sk, mode,
-                         flags=(A_BF16 | B_BF16) if s16 else 0)
+                    wgrad_gemm(a_ptr, b_ptr, gw, _owner_of(wh), 4 * H, H, rows, 4 * H, ldh, False, False, sk, mode,
+                               flags=(A_BF16 | B_BF16) if s16 else 0)
                 if not pers_bias:
                     colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         for (wi, wh, bi, bh) in params:
@@ -962,12 +1201,12 @@ class LstmStack2Fn(torch.autograd.Function):
         with side_work(x, h1, h2, dg1, dg2):
             for dg, inp, hh, wi, wh, bi, bh in ((dg2, h1, h2, w_ih2, w_hh2, b_ih2, b_hh2),
                                                 (dg1, x, h1, w_ih1, w_hh1, b_ih1, b_hh1)):
-                linear_wgrad_acc(dg, inp, _grad_buf(wi), mode=mode)
+                linear_wgrad_acc(dg, inp, _grad_buf(wi), mode=mode, owner=_owner_of(wi))
                 gw = _grad_buf(wh)
                 rws = R - N
                 sk = _split_k(_tiles(4 * H, H), rws)
-                gemm(dg.data_ptr() + esz * N * 4 * H, hh, gw, None, 4 * H, H, rws, 4 * H, H, H, False, False, ACT_NONE,
-                     EPI_ATOMIC, sk, mode, flags=A_BF16 if s16 else 0)
+                wgrad_gemm(dg.data_ptr() + esz * N * 4 * H, hh, gw, _owner_of(wh), 4 * H, H, rws, 4 * H, H, False, False, sk,
+                           mode, flags=(A_BF16 if s16 else 0) | (B_BF16 if hh.dtype == torch.bfloat16 else 0))
                 colsum_add(dg, _grad_buf(bi), _grad_buf(bh))
         _ready(w_ih2, w_hh2, b_ih2, b_hh2)
         _ready(w_ih1, w_hh1, b_ih1, b_hh1)

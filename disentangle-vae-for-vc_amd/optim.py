@@ -111,6 +111,7 @@ class FlatAdam:
         for p in self.params:
             if getattr(p, "_dvae_grad_store_first", False):
                 p._dvae_sf_writes = 0
+        self.__dict__.get("_slab_pending", {}).clear()      # slabs of an abandoned backward pass are not this step's
         if self._clean:
             return      # the previous step's Adam launch cleared these ranges and nothing has accumulated since
         for lo, hi in self._zero_ranges:
@@ -182,6 +183,7 @@ class FlatAdam:
                                    "(use optimizer.zero_grad(), never model.zero_grad()/p.grad = None/model.to())")
             self._store_first_guard()
             ops.join_side()     # weight-gradient work may still be running on the side stream
+            ops.fold_pending(self)      # the k-split slabs of this step's weight gradients: one table-driven launch, fixed order
             if torch.cuda.is_current_stream_capturing():
                 if self._dev_scalars is None or self._dev_scalars[1] != float(grad_scale):
                     raise RuntimeError("FlatAdam.step under capture: call sync_scalars(grad_scale) before the capture")

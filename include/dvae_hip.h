@@ -44,7 +44,7 @@ extern "C" {
 
 /* ABI revision of this header; dvae_version() of the loaded library must return exactly this (the ctypes binding
  * refuses anything else: a stale .so would misread the argument lists below) */
-#define DVAE_ABI_VERSION 306
+#define DVAE_ABI_VERSION 307
 int dvae_version(void);
 
 /* ---- arithmetic of a contraction (every GEMM / conv / LSTM entry point takes a `mode` argument):
@@ -105,6 +105,45 @@ int dvae_gemm_f32(const void* A, const void* B, void* C, const float* bias,
 int dvae_gemm_f32_batched(const void* const* A, const void* const* B, void* const* C, int batch, int M, int N, int K,
                           int64_t lda, int64_t ldb, int64_t ldc, int a_kcontig, int b_kcontig, int epi, int split_k,
                           int mode, void* stream);
+/* ---- k-split WITHOUT atomics (round 6; replaces the split-K atomic accumulation of every aten::mm / convolution_backward
+ * the reference runs through cuBLAS / cuDNN: /root/reference/model/variational_base_vae.py:68 `loss.backward()`) ----
+ * A product cut along k stores its partial results PLAINLY: split 0 writes C as `epi` says (DVAE_EPI_STORE, or
+ * DVAE_EPI_ACCUM: read-modify-write), split ks >= 1 stores into slab + (ks - 1) * slab_stride (elements; a multiple of 4, >=
+ * the extent of C; the slabs 16-byte aligned; conv weight gradients keep their five per-tap outputs at the same distances
+ * inside a slab).  `slab_cap` = slabs the caller provides: the dispatch may take fewer k-splits than `split_k` asks for, or
+ * — the tiles that want one workgroup per CU — more, never more than slab_cap + 1.  RETURNS the number of k-splits
+ * launched (>= 1), or a negative error code.  The caller then adds the slabs to C in the fixed order ks = 1, 2, ...
+ * (dvae_slab_sum now, or dvae_slab_fold later, e.g. right in front of the optimiser's launch): every output element has
+ * ONE writer per buffer and ONE summation order, so results are run-to-run bit-identical — and the epilogues are plain
+ * 16-byte stores (the atomic epilogue of a weight gradient measured 17 us against 6).  No bias, no activation when split
+ * (dvae_slab_sum applies the activation).  dvae_conv5_fwd_slabs / dvae_conv5_dgrad_t_slabs: the convs with <= 128 output
+ * columns, which the default arithmetic cuts along k to fill the chip (they return 1 when they did not split). */
+int dvae_gemm_f32_slabs(const void* A, const void* B, void* C, float* slab, int64_t slab_stride, int slab_cap,
+                        const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
+                        int a_kcontig, int b_kcontig, int epi, int split_k, int mode, void* stream);
+/* batched form (dvae_gemm_f32_batched): product b stores split ks >= 1 into slab (b * (n - 1) + ks - 1), n = the return value */
+int dvae_gemm_f32_batched_slabs(const void* const* A, const void* const* B, void* const* C, int batch, float* slab,
+                                int64_t slab_stride, int slab_cap, int M, int N, int K, int64_t lda, int64_t ldb,
+                                int64_t ldc, int a_kcontig, int b_kcontig, int epi, int split_k, int mode, void* stream);
+int dvae_conv5_fwd_slabs(const void* X, const void* Wp, const float* bias, float* Y, float* slab, int64_t slab_stride,
+                         int slab_cap, int R, int N, int Cin, int Cout, int mode, void* stream);
+int dvae_conv5_dgrad_t_slabs(const void* dY, const void* Wpt, float* dX, float* slab, int64_t slab_stride, int slab_cap,
+                             int R, int N, int Cin, int Cout, int mode, void* stream);
+int dvae_conv5_wgrad_slabs(const void* dY, const void* X, float* dWp, float* slab, int64_t slab_stride, int slab_cap,
+                           int R, int N, int Cin, int Cout, int epi, int split_k, int mode, void* stream);
+/* C[i] = act(C[i] + sum_{k < nslab} slab[k * slab_stride + i]), i < n  (n, slab_stride multiples of 4) */
+int dvae_slab_sum(float* C, const float* slab, int64_t slab_stride, int nslab, int64_t n, int act, void* stream);
+/* the same for many results in ONE launch per DVAE_SLAB_FOLD_MAX entries (`descs` is read during the call only) */
+typedef struct {
+  float* c;
+  const float* slab;
+  int64_t slab_stride;
+  int64_t n;
+  int nslab;
+  int pad_;
+} dvae_slab_desc_t;
+#define DVAE_SLAB_FOLD_MAX 64
+int dvae_slab_fold(const dvae_slab_desc_t* descs, int n_entries, void* stream);
 /* ---- Conv1d(k=5, stride 1, pad 2) on frame-major data (disentangled_vae.py:111-114, 178-181) ----
  * Weights are used in PACKED form Wp[5][Cout][Cin] (see dvae_conv_pack_w).
  * fwd : Y[R,Cout]   = sum_tap X[r+(tap-2)*N, :] * Wp[tap]^T + bias      (rows outside [0,R) are zero)
@@ -205,11 +244,17 @@ typedef struct {
   float* dbias_hh;    /* column sums of dgates over all frames and rows are ADDED to these [4H] vectors (the gradients of
                          b_ih and b_hh, nn.LSTM keeps two): the caller then skips its dvae_colsum_add pass over dgates.
                          Ignored (and the caller must run dvae_colsum_add) when the per-frame kernels are used */
+  float* dbias_part;  /* optional, PERSISTENT backward launch only, instead of dbias_ih / dbias_hh (ABI 307): row group rb of the
+                         launch STORES its share of the column sums of dgates at dbias_part[(rb * 4 + g) * H + unit] — a
+                         [DVAE_PERS_BIAS_SLABS][4H] buffer (row groups the launch does not have are written as zeros) that
+                         the caller adds up in the fixed order rb = 0, 1, ... (dvae_slab_sum / dvae_slab_fold with
+                         slab_stride 4H): no atomics, run-to-run bit-identical bias gradients */
   int64_t gate_ld;    /* row stride, in elements, of gates and dgates (0: 4H, the dense layout).  H = 64 only: the two
                          directions of the encoder BiLSTM keep their gates side by side in ONE [T*N, 8H] tensor, so that both
                          input projections are one contraction with N = 8H (and both data gradients one with K = 8H);
                          every direction of a call must name the same stride */
 } dvae_lstm_dir_t;
+#define DVAE_PERS_BIAS_SLABS 16  /* rows of dvae_lstm_dir_t.dbias_part */
 /* W_hh [4H,H] -> fragment-ordered copies (each 4H*H floats) for the forward / backward frame kernels */
 int dvae_lstm_pack_w(const float* w_hh, float* packed_fwd, float* packed_bwd, int H, void* stream);
 /* bf16 compute mode: the same copies rounded to bf16 (each 4H*H bf16 values = 2*4H*H bytes) */
@@ -366,6 +411,12 @@ int dvae_mel_to_frames(const float* x1, const float* x2, void* X, int Bh, int C,
 int dvae_frames_to_mel(const float* X, float* out, int N, int C, int T, void* stream);
 int dvae_permute_102(const float* in, float* out, int A, int B, int C, void* stream);
 int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int C, int64_t ld, int x_bf16, void* stream);
+/* the same WITHOUT atomics (round 6): row blocks store partial sums into `ws`, the last workgroup of a column block to arrive
+ * adds them up in row-block order and is the one writer of out[c] — run-to-run bit-identical.  ws: >= dvae_colsum_ws_bytes(R, C)
+ * bytes, 16-byte aligned, its first 4096 bytes ZERO before the first call (every call leaves them zero); one ws per stream
+ * that may have such a launch in flight */
+int64_t dvae_colsum_ws_bytes(int R, int C);
+int dvae_colsum_add_ws(const void* X, float* out1, float* out2, int R, int C, int64_t ld, int x_bf16, void* ws, void* stream);
 int dvae_transpose(const float* in, float* out, int R, int C, void* stream);
 /* dU = dZ * act'(Z), Z = activation OUTPUT (ReLU after enc_linear, disentangled_vae.py:211); dU may alias dZ */
 /* Y = act(Y) in place (used after a split-K Linear) */

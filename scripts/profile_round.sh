@@ -25,6 +25,12 @@ rocprofv3 --kernel-trace --stats -f csv rocpd -d "$OUT/kt16" -o kt16 -- python3 
 DB16=$(find "$OUT/kt16" -name '*results.db' | head -1)
 if [ -n "$DB16" ]; then python3 scripts/rocpd_stats.py "$DB16" "$SUM/${TAG}_bf16_kernel_stats.csv" 40 > "$SUM/${TAG}_bf16_last_step.txt" 2>&1; fi
 tail -1 "$OUT/kt16.json" > "$SUM/${TAG}_bf16_bench_under_profiler.json"
+# 1c. ... and for the per-GPU shape of configs[4] (bf16, B=64, T=512)
+BENCH4="bench.py --dtype bf16 --batch 64 --frames 512 --steps 6 --warmup 3 --no-cpu-baseline --no-other-configs --no-roofline"
+rocprofv3 --kernel-trace --stats -f csv rocpd -d "$OUT/kt4" -o kt4 -- python3 $BENCH4 > "$OUT/kt4.json" 2> "$OUT/kt4.err"
+DB4=$(find "$OUT/kt4" -name '*results.db' | head -1)
+if [ -n "$DB4" ]; then python3 scripts/rocpd_stats.py "$DB4" "$SUM/${TAG}_bf16_c4_kernel_stats.csv" 40 > "$SUM/${TAG}_bf16_c4_last_step.txt" 2>&1; fi
+tail -1 "$OUT/kt4.json" > "$SUM/${TAG}_bf16_c4_bench_under_profiler.json"
 # algorithmic bytes per instantiation (bench.py's own tags), for the fabric / algorithmic column of the PMC summary
 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$OUT/alg.json" 2> "$OUT/alg.err"
 EAGER="bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-other-configs --no-roofline"

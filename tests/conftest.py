@@ -29,21 +29,29 @@ def golden_dir():
     return GOLDEN
 
 
-def trajectory_band(g, factor=3.0, floor=1e-4):
+def trajectory_band(g, factor=3.0, floor=1e-4, perturbed=True):
     """tests/golden/trajectory_*.npz -> (reference trajectory [steps, 8], allowed relative distance [steps, 8]).
 
-    The fixture holds the REAL reference's `step()` trajectory run with 1, 2, 4 and 8 intra-op threads: the same program on
-    the same inputs and noise, only the summation order inside its BLAS / oneDNN kernels differs.  Training is chaotic at
-    round-off level (Adam's first updates are lr * sign(g): every gradient element that is zero up to round-off moves its
-    weight by +-lr either way), so from the third step on the reference is only reproducible to the spread recorded here.
-    An implementation is held to `factor` x that spread around the 8-thread run (the thread count of every other golden),
-    never tighter than `floor` = the 1e-4 of the single-step parity contract.  The spread of four realisations is itself
+    The fixture holds the REAL reference's `step()` trajectory (a) run with 1, 2, 4 and 8 intra-op threads — the same program
+    on the same inputs and noise, only the blocking of its own BLAS / oneDNN kernels differs (a perturbation of ~1e-7) — and
+    (b) run four times with its inputs multiplied by (1 + 1e-6 xi): the size of the forward error of an INDEPENDENT fp32
+    implementation (other summation orders; scripts/op_precision_audit.py measures 3e-7 .. 1e-6 per op for this one).
+    Training is chaotic at round-off level: one ReLU pre-activation within the perturbation of zero flips its mask and moves
+    every gradient upstream of it by ~1e-2 (scripts/dz_diag.py found exactly one such element at step 1), and Adam's first
+    updates are lr * sign(g).  So from the second step on the reference is only reproducible to the spread recorded here, and
+    an implementation is held to `factor` x that spread around the 8-thread run (the thread count of every other golden),
+    never tighter than `floor` = the 1e-4 of the single-step parity contract.  The spread of a few realisations is itself
     noisy, so it enters as its running maximum over the steps so far and over the group of like losses (total + four L1
-    terms; three KL terms) — divergence only grows."""
+    terms; three KL terms) — divergence only grows.  perturbed=False: the thread runs alone (what the oracle, which runs the
+    reference's own kernels, is held to)."""
     import numpy as np
     tr = g["traj_fp32"]
     ref = tr[-1]
-    spread = np.abs(tr - ref[None]).max(0) / np.maximum(1e-12, np.abs(ref))
+    runs = [tr]
+    if perturbed and "traj_fp32_perturbed" in g.files:
+        runs.append(g["traj_fp32_perturbed"])
+    allr = np.concatenate(runs, 0)
+    spread = np.abs(allr - ref[None]).max(0) / np.maximum(1e-12, np.abs(ref))
     env = np.empty_like(spread)
     for sl in (slice(0, 5), slice(5, 8)):
         env[:, sl] = np.maximum.accumulate(spread[:, sl].max(1))[:, None]

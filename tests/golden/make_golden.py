@@ -329,6 +329,9 @@ def run_bf16_autocast_case(name="c0_b4_t64"):
     print(f"wrote {path}: relative distance autocast(bf16) - fp32 per loss: {np.array2string(d, precision=5)}")
 
 
+PERTURB_REL = 1e-6
+
+
 def run_trajectory_case(name="c0_b4_t64", n_steps=20, n_inputs=5):
     """The reference's own training trajectory: `step()` (variational_base_vae.py:58-70: zero_grad, forward, loss, backward,
     Adam, 8 x .item()) called n_steps times on a cycle of n_inputs seeded input pairs, the noise of every step drawn from the
@@ -343,9 +346,14 @@ def run_trajectory_case(name="c0_b4_t64", n_steps=20, n_inputs=5):
     out = {"batch": batch, "n_frames": n_frames, "seed": seed, "eps_seed": eps_seed, "n_steps": n_steps,
            "n_inputs": n_inputs, "input_seeds": np.array([seed + 101 * i for i in range(n_inputs)]), "lr": 1e-4}
 
-    def run(threads, ctx, f64=False):
+    def run(threads, ctx, f64=False, perturb=0):
         torch.set_num_threads(threads)
         w = build(batch, n_frames)
+        noise = None
+        if perturb:      # every input element times (1 + 1e-6 xi): the size of another fp32 implementation's forward error
+            rs = np.random.RandomState(9000 + perturb)
+            noise = [tuple(torch.from_numpy(1.0 + PERTURB_REL * rs.standard_normal(tuple(t.shape))).float() for t in pr)
+                     for pr in inputs]
         if f64:          # the same program in double precision: parameters, inputs, Adam moments (eps stays the fp32 draw)
             w.model.double()
             w.optimizer = torch.optim.Adam(w.model.parameters(), lr=1e-4)
@@ -357,6 +365,8 @@ def run_trajectory_case(name="c0_b4_t64", n_steps=20, n_inputs=5):
                             torch.empty(batch, 4).normal_().numpy()])
             torch.set_rng_state(st)
             x1, x2 = inputs[s % n_inputs]
+            if noise is not None:
+                x1, x2 = x1 * noise[s % n_inputs][0], x2 * noise[s % n_inputs][1]
             if f64:
                 x1, x2 = x1.double(), x2.double()
             with ctx:
@@ -376,6 +386,21 @@ def run_trajectory_case(name="c0_b4_t64", n_steps=20, n_inputs=5):
     out["eps_c1"] = np.stack([e[0] for e in eps_all])            # [steps, B, 28] (the same stream in every run)
     out["eps_c2"] = np.stack([e[1] for e in eps_all])
     out["eps_s"] = np.stack([e[2] for e in eps_all])
+    # The reference's sensitivity to a perturbation of the size of ANOTHER fp32 implementation's forward error.  Its thread
+    # counts perturb it by ~1e-7 (its own kernels in another blocking); an independent implementation (other summation
+    # orders, split arithmetic) is ~1e-6 from exact arithmetic per op (scripts/op_precision_audit.py: 3e-7 .. 1e-6 relative
+    # L2).  Training amplifies any perturbation the same chaotic way (one ReLU pre-activation within 1e-6 of zero flips its
+    # mask: scripts/dz_diag.py found exactly that at step 1), so the reference is run with its inputs multiplied by
+    # (1 + 1e-6 xi), four seeds: how far IT moves is the band an implementation with that forward error is held to.
+    pert = []
+    for sd in (1, 2, 3, 4):
+        tr, _, _ = run(8, contextlib.nullcontext(), perturb=sd)
+        pert.append(tr)
+    out["traj_fp32_perturbed"] = np.stack(pert)                  # [4, steps, 8]
+    out["perturb_rel"] = PERTURB_REL
+    dp = np.abs(out["traj_fp32_perturbed"] - out["traj_fp32"][-1][None]).max(0) / np.maximum(1e-12, np.abs(out["traj_fp32"][-1]))
+    print("reference with inputs perturbed by 1e-6 (4 seeds), per step (max over losses):", np.array2string(dp.max(1), precision=2))
+    print("   step 2 per loss:", np.array2string(dp[1], precision=2))
     # the reference in DOUBLE precision: how far its own fp32 execution is from exact arithmetic, step by step — the
     # distance any other fp32 implementation (another summation order) may equally keep
     tr64, _, _ = run(8, contextlib.nullcontext(), f64=True)

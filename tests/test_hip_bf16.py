@@ -664,3 +664,124 @@ def test_conv_block_bf16_storage(ops, act):
     for k, name in ((1, "dx"), (2, "dW"), (3, "dgamma"), (4, "dbeta")):
         a, b = res[True][k].double(), res[False][k].double()
         assert float((a - b).abs().max()) <= max(tol, 2e-6) * float(b.abs().max()), name
+
+
+# ------------------------------------------------------------------ the 256 x 256 LDS-DMA kernel (csrc/gemm256.hip, round 6)
+def _rel_l2(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return float((got - ref).norm() / max(1e-30, float(ref.norm())))
+
+
+@pytest.mark.parametrize("M,N,K,kc", [(65536, 512, 512, True), (3880, 3848, 576, True), (4096, 4096, 1024, False),
+                                      (3880, 3848, 576, False), (65536, 256, 576, True)])
+def test_gemm_bf16_256_equals_the_128_kernel_bit_for_bit(ops, M, N, K, kc):
+    """Shapes that fill the chip with 256 x 256 tiles (>= 224 of them) take gemm_bf16_256_kernel when both operands are bf16 in
+    memory: operands staged by `buffer_load ... lds` into swizzled LDS images, eight waves.  Same MFMA, same fragment k
+    order, same k-tile walk as the 128 x 128 kernel (which fp32-STORED operands holding the same bf16-exact values take):
+    the results must be bit-identical — ragged M / N (out-of-range rows arrive as zeros from the DMA), an odd number of
+    k-tiles (the extra tile of the two-tile loop is all zeros), both operand layouts."""
+    a, b = r16(rnd(M, K, seed=1)), r16(rnd(K, N, seed=2))
+    A = a if kc else a.t().contiguous()
+    B = b.t().contiguous() if kc else b
+    lda, ldb = (K if kc else M), (K if kc else N)
+    out = []
+    for A_, B_, fl in ((A, B, 0), (A.bfloat16(), B.bfloat16(), ops.A_BF16 | ops.B_BF16)):
+        C_ = torch.empty(M, N, device="cuda")
+        ops.gemm(A_.cuda().contiguous(), B_.cuda().contiguous(), C_, None, M, N, K, lda, ldb, N, kc, kc, 0, ops.EPI_STORE, 1,
+                 ops.MODE_BF16 | fl)
+        out.append(C_)
+    assert torch.equal(out[0], out[1]), float((out[0] - out[1]).abs().max())
+    assert _rel_l2(out[1][:256], a[:256].double() @ b.double()) < 2e-6
+
+
+def test_gemm_bf16_256_bias_relu_and_repeatability(ops):
+    M, N, K = 65536, 512, 4096
+    a, b, bias = rnd(M, K, seed=3).bfloat16().cuda(), rnd(N, K, seed=4).bfloat16().cuda(), rnd(N, seed=5).cuda()
+    first = None
+    for i in range(10):      # a staging race (a fragment read before its DMA piece landed) would show as a changing bit
+        C_ = torch.empty(M, N, device="cuda")
+        ops.gemm(a, b, C_, bias, M, N, K, K, K, N, True, True, 1, ops.EPI_STORE, 1, ops.MODE_BF16 | ops.A_BF16 | ops.B_BF16)
+        first = C_.clone() if first is None else first
+        assert torch.equal(first, C_), i
+    ref = torch.relu(a[:128].double() @ b.double().t() + bias.double())
+    assert _rel_l2(first[:128], ref) < 2e-6
+
+
+@pytest.mark.parametrize("R,N,Cin,Cout", [(65536, 128, 512, 512), (65536 - 256, 256, 512, 512)])
+def test_conv5_bf16_256_against_fp64(ops, R, N, Cin, Cout):
+    """Conv forward (+ BatchNorm statistics epilogue), data gradient and weight gradient at the benchmarked row count with
+    bf16 operands in memory (tap mode 1 on the 256 x 256 kernel: the conv padding is out-of-descriptor offsets the DMA
+    zero-fills; tap mode 2 with the k-splits stored into slabs): against fp64 on slices, statistics against the output."""
+    from dvae_amd._lib import check, lib, ptr, stream
+    L = lib()
+    FL = ops.MODE_BF16 | ops.A_BF16 | ops.B_BF16
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rc = lambda *s_: torch.rand(*s_, device="cuda", generator=g) * 2 - 1
+    x, wp, bias = rc(R, Cin).bfloat16(), (rc(5, Cout, Cin) * 0.1).bfloat16(), rc(Cout)
+    y = torch.empty(R, Cout, device="cuda")
+    ws = torch.zeros(L.dvae_bn_ws_bytes(R, Cout, 2) // 8, device="cuda", dtype=torch.float64)
+    check(L.dvae_conv5_fwd_stats(ptr(x), ptr(wp), ptr(bias), ptr(y), R, N, Cin, Cout, FL, 2, ptr(ws), stream()), "fwd_stats")
+    y2 = torch.empty(R, Cout, device="cuda")
+    check(L.dvae_conv5_fwd(ptr(x), ptr(wp), ptr(bias), ptr(y2), R, N, Cin, Cout, FL, stream()), "fwd")
+    assert torch.equal(y, y2)
+    rows = 2 * N + 64                                   # covers the zero padding above row 0 ...
+    xr = torch.zeros(rows + 4 * N, Cin, device="cuda", dtype=torch.float64)
+    xr[2 * N:] = x[:rows + 2 * N].double()
+    ref = sum(xr[t * N: t * N + rows] @ wp[t].double().t() for t in range(5)) + bias.double()
+    assert _rel_l2(y[:rows], ref) < 2e-6
+    xe = torch.zeros(rows + 4 * N, Cin, device="cuda", dtype=torch.float64)      # ... and below the last row
+    xe[:rows + 2 * N] = x[R - rows - 2 * N:].double()
+    ref_e = sum(xe[t * N: t * N + rows] @ wp[t].double().t() for t in range(5)) + bias.double()
+    assert _rel_l2(y[R - rows:], ref_e) < 2e-6
+    # statistics: per 64-row chunk and group, sum and sum of squares of the stored outputs
+    nch = (R + 63) // 64
+    st = ws[:nch * 2 * Cout * 2].reshape(nch, 2, Cout, 2)
+    yy = y.double()
+    grp = (torch.arange(R, device="cuda") % N) >= N // 2
+    for ch in (0, 1, nch // 2, nch - 1):
+        sl = slice(64 * ch, min(R, 64 * ch + 64))
+        for gi in (0, 1):
+            m = (grp[sl] == bool(gi)).double()[:, None]
+            assert torch.allclose(st[ch, gi, :, 0], (yy[sl] * m).sum(0), rtol=1e-5, atol=1e-4)
+            assert torch.allclose(st[ch, gi, :, 1], (yy[sl] ** 2 * m).sum(0), rtol=1e-5, atol=1e-4)
+    # data gradient
+    gy, wpt = rc(R, Cout).bfloat16(), (rc(5, Cin, Cout) * 0.1).bfloat16()
+    dx = torch.empty(R, Cin, device="cuda")
+    check(L.dvae_conv5_dgrad_t(ptr(gy), ptr(wpt), ptr(dx), R, N, Cin, Cout, FL, stream()), "dgrad")
+    gr = torch.zeros(rows + 4 * N, Cout, device="cuda", dtype=torch.float64)
+    gr[2 * N:] = gy[:rows + 2 * N].double()
+    ref_d = sum(gr[(4 - t) * N: (4 - t) * N + rows] @ wpt[t].double().t() for t in range(5))
+    assert _rel_l2(dx[:rows], ref_d) < 2e-6
+    # weight gradient: k-splits into slabs, summed in a fixed order: twice bit for bit, one tap-slab against fp64
+    dws = []
+    for _ in range(2):
+        dw = torch.zeros(5, Cout, Cin, device="cuda")
+        slab = torch.empty(15 * dw.numel(), device="cuda")
+        n = L.dvae_conv5_wgrad_slabs(ptr(gy), ptr(x), ptr(dw), ptr(slab), dw.numel(), 15, R, N, Cin, Cout, ops.EPI_ACCUM, 6, FL,
+                                     stream())
+        assert n >= 2, n
+        check(L.dvae_slab_sum(ptr(dw), ptr(slab), dw.numel(), n - 1, dw.numel(), 0, stream()), "slab_sum")
+        dws.append(dw)
+    assert torch.equal(dws[0], dws[1])
+    for tap in (0, 2, 4):
+        sh = (tap - 2) * N
+        xs = torch.zeros(R, Cin, device="cuda", dtype=torch.float64)
+        if sh >= 0:
+            xs[:R - sh] = x[sh:].double()
+        else:
+            xs[-sh:] = x[:R + sh].double()
+        assert _rel_l2(dws[0][tap, :64], gy[:, :64].double().t() @ xs) < 5e-6
+
+
+def test_lstm_weight_gradient_shapes_on_the_256_kernel(ops):
+    """dW = dG^T x with K = T*N = 65 536 rows (row-contiguous operands, the ds_read_b64_tr_b16 fragment path of the 256 x 256
+    kernel), k-splits into slabs: fp64 and run-to-run."""
+    M, N, K = 4096, 1024, 65536
+    a, b = rnd(K, M, seed=8).bfloat16().cuda(), rnd(K, N, seed=9).bfloat16().cuda()
+    res = []
+    for _ in range(2):
+        g = torch.zeros(M, N, device="cuda")
+        ops.wgrad_gemm(a, b, g, None, M, N, K, M, N, False, False, 2, ops.MODE_BF16)
+        res.append(g)
+    assert torch.equal(res[0], res[1])
+    assert _rel_l2(res[0][:128], a[:, :128].double().t() @ b.double()) < 5e-6

@@ -660,3 +660,95 @@ def test_sum_f32_and_fanout(ops, n, three):
     loss.backward()
     k = 6.0 if three else 3.0
     assert torch.equal(x.grad, torch.full_like(x, 2.0 * k))
+
+
+# ------------------------------------------------------------------ k-split slabs (round 6): no atomics, fixed summation order
+def _rel_l2(got, ref):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    return float((got - ref).norm() / max(1e-30, float(ref.norm())))
+
+
+@pytest.mark.parametrize("M,N,K,kc,sk", [(128, 2048, 8192, True, 16), (8, 56, 2048, True, 4), (2048, 128, 16384, False, 8),
+                                         (4096, 1024, 16384, False, 4), (512, 512, 4096, False, 6), (256, 8, 2048, True, 8)])
+def test_gemm_slabs_match_fp64_and_are_bitwise_reproducible(ops, M, N, K, kc, sk):
+    """dvae_gemm_f32_slabs + dvae_slab_sum: a product cut along k whose splits are STORED (split 0 into the result, the others
+    into slabs) and added in a fixed order — against fp64 in relative L2 (1e-5: an fp32 contraction in another summation order
+    keeps ~1e-6; 1e-3 would be a lost low plane of the split arithmetic), with bias and ReLU applied by the sum, twice bit
+    for bit (the atomic epilogue this replaces differs from run to run), and equal to the unsplit product to round-off."""
+    a, b, bias = rnd(M, K, seed=1), rnd(K, N, seed=2), rnd(N, seed=3)
+    A = dev(a if kc else a.t().contiguous())
+    B = dev(b.t().contiguous() if kc else b)
+    lda, ldb = (K if kc else M), (K if kc else N)
+    ref = torch.relu(a.double() @ b.double() + bias.double())
+    outs = []
+    for _ in range(2):
+        Cm = torch.empty(M, N, device="cuda")
+        ops.gemm_split(A, B, Cm, dev(bias), M, N, K, lda, ldb, N, kc, kc, 1, sk, None)
+        outs.append(Cm)
+    assert torch.equal(outs[0], outs[1])
+    assert _rel_l2(outs[0], ref) < 1e-5, _rel_l2(outs[0], ref)
+    one = torch.empty(M, N, device="cuda")
+    ops.gemm(A, B, one, dev(bias), M, N, K, lda, ldb, N, kc, kc, 1, ops.EPI_STORE, 1)
+    assert _rel_l2(outs[0], one) < 5e-6      # two fp32 summation orders over K up to 16 384
+
+
+def test_wgrad_slabs_accumulate_and_fold_like_a_plain_sum(ops):
+    """ops.wgrad_gemm on a gradient no optimiser owns: `grad += A^T B` with K cut into slabs, summed right behind the launch;
+    called twice it accumulates twice (the semantics of the atomic epilogue it replaces), bit-identically run to run."""
+    M, N, K = 1024, 512, 32768
+    a, b = rnd(K, M, seed=4), rnd(K, N, seed=5)
+    ref = a.double().t() @ b.double()
+    res = []
+    for _ in range(2):
+        g = torch.zeros(M, N, device="cuda")
+        ops.wgrad_gemm(dev(a), dev(b), g, None, M, N, K, M, N, False, False, 8, None)
+        once = g.clone()
+        ops.wgrad_gemm(dev(a), dev(b), g, None, M, N, K, M, N, False, False, 8, None)
+        res.append((once, g))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert _rel_l2(res[0][0], ref) < 1e-5 and _rel_l2(res[0][1], 2 * ref) < 1e-5
+
+
+@pytest.mark.parametrize("R,C_,ld,b16", [(16384, 512, 512, False), (65536, 4096, 4096, False), (1000, 80, 80, False),
+                                          (8192, 256, 512, False), (512, 2048, 2048, False)])
+def test_colsum_is_deterministic_and_exact(ops, R, C_, ld, b16):
+    """ops.colsum_add (dvae_colsum_add_ws): per-row-block partial sums, the last workgroup of a column block adds them in
+    row-block order and is the one writer — against fp64 and twice bit for bit; it ADDS to what the outputs hold."""
+    x = rnd(R, ld, seed=6)
+    ref = x[:, :C_].double().sum(0)
+    outs = []
+    for _ in range(2):
+        o1, o2 = torch.ones(C_, device="cuda"), torch.zeros(C_, device="cuda")
+        ops.colsum_add(dev(x), o1, o2, rows=R, cols=C_, ld=ld)
+        outs.append((o1, o2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[0][1].cpu().double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max() + R ** 0.5)
+    assert torch.equal(outs[0][0], outs[0][1] + 1.0) or float((outs[0][0] - outs[0][1] - 1.0).abs().max()) < 1e-3
+
+
+def test_conv_wgrad_slabs_match_fp64(ops):
+    """dvae_conv5_wgrad_slabs (tap mode 2: five per-tap outputs inside every slab) through ops.ConvBnActFn's backward on a
+    gradient no optimiser owns: dW against fp64 in relative L2, twice bit for bit."""
+    from dvae_amd.ops import ConvBnActFn
+    N, T, Cin, Cout = 16, 256, 512, 512
+    x, w = rnd(N, Cin, T, seed=1), rnd(Cout, Cin, 5, seed=2) * 0.05
+    gz = rnd(N, Cout, T, seed=7)
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    gam, bet = rnd(Cout, seed=4, lo=0.5, hi=1.5), rnd(Cout, seed=5) * 0.1
+    y = F.conv1d(xr, wr, None, padding=2)
+    torch.relu(F.batch_norm(y, None, None, gam.double(), bet.double(), True, 0.1, 1e-5)).backward(gz.double())
+    grads = []
+    for _ in range(2):
+        P = lambda t: torch.nn.Parameter(dev(t))
+        cw, cb, bw, bb = P(w.permute(2, 0, 1)), P(torch.zeros(Cout)), P(gam), P(bet)
+        for p_ in (cw, cb, bw, bb):
+            p_.grad = torch.zeros_like(p_)
+        xin = dev(to_frames(x)).requires_grad_()
+        rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+        z = ConvBnActFn.apply(xin, cw, cb, bw, bb, rm, rv, torch.zeros((), dtype=torch.long, device="cuda"), None, N, 1, 1,
+                              True, None, None, None, False)
+        z.backward(dev(to_frames(gz)))
+        grads.append((cw.grad.clone(), xin.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    assert _rel_l2(grads[0][0], wr.grad.permute(2, 0, 1)) < 1e-5
+    assert _rel_l2(grads[0][1], to_frames(xr.grad)) < 1e-5

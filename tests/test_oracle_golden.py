@@ -109,7 +109,7 @@ def test_oracle_trajectory_inside_the_references_own_spread(golden_dir):
     chaotic amplification — at the 2e-6 of the single-step goldens."""
     from conftest import trajectory_band
     g = _load(golden_dir, "trajectory_c0_b4_t64")
-    ref, band = trajectory_band(g)
+    ref, band = trajectory_band(g, perturbed=False)      # the oracle runs the reference's own kernels: the thread spread alone
     tr = _trainer(g)
     B, T = int(g["batch"]), int(g["n_frames"])
     inputs = [synthetic_pair(B, T, int(s)) for s in g["input_seeds"]]
