@@ -110,7 +110,7 @@ SIGNATURES = {
     "dvae_conv5_fwd_slabs": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_conv5_dgrad_t_slabs": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "dvae_conv5_wgrad_slabs": (i32, [vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "dvae_slab_sum": (i32, [vp, vp, i64, i32, i64, i32, vp]),
+    "dvae_slab_sum": (i32, [vp, vp, i64, i32, i64, i32, i32, vp]),
     "dvae_slab_fold": (i32, [C.POINTER(SlabDesc), i32, vp]),
     "dvae_colsum_ws_bytes": (i64, [i32, i32]),
     "dvae_colsum_add_ws": (i32, [vp, vp, vp, i32, i32, i64, i32, vp, vp]),

@@ -866,9 +866,10 @@ DVAE_API int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int
 // added to the result in the FIXED order ks = 1, 2, ...: every element has one writer and one summation order, so the
 // result is run-to-run bit-identical.  HBM-bound: (nslab + 2) * 4 bytes per element.
 __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ C, const float* __restrict__ slab, int64_t stride,
-                                                       int nslab, int64_t n4, int act) {
+                                                       int nslab, int64_t n4, int act, int accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(C + 4 * i);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (accumulate) v = *reinterpret_cast<const f32x4*>(C + 4 * i);
     for (int k = 0; k < nslab; ++k) v += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * stride + 4 * i);
     if (act != DVAE_ACT_NONE) {
 #pragma unroll
@@ -877,14 +878,15 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ C, co
     *reinterpret_cast<f32x4*>(C + 4 * i) = v;
   }
 }
-// C[i] = act(C[i] + sum_k slab[k * slab_stride + i]), i < n (n, slab_stride multiples of 4; 16-byte aligned pointers)
-DVAE_API int dvae_slab_sum(float* C, const float* slab, int64_t slab_stride, int nslab, int64_t n, int act, void* stream) {
+// C[i] = act((accumulate ? C[i] : 0) + sum_k slab[k * slab_stride + i]), i < n (n, slab_stride multiples of 4; 16-byte aligned)
+DVAE_API int dvae_slab_sum(float* C, const float* slab, int64_t slab_stride, int nslab, int64_t n, int act, int accumulate,
+                           void* stream) {
   if (!C || n < 4 || (n & 3) || nslab < 0 || (nslab > 0 && (!slab || (slab_stride & 3) || (((uintptr_t)slab) & 15))) ||
-      (((uintptr_t)C) & 15))
+      (((uintptr_t)C) & 15) || (nslab == 0 && !accumulate))
     return DVAE_EINVAL;
   if (nslab == 0 && act == DVAE_ACT_NONE) return DVAE_OK;
   hipLaunchKernelGGL(slab_sum_kernel, dim3(nblk(n / 4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, C, slab, slab_stride,
-                     nslab, n >> 2, act);
+                     nslab, n >> 2, act, accumulate);
   return dvae_check_launch();
 }
 

@@ -109,10 +109,10 @@ __global__ __launch_bounds__(64 * WG * WG) void gemm_f32_kernel(const GemmParams
   const int kiters = (klen + BK - 1) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
 
-  // k-split without atomics (p.slab): split 0 writes C as p.epi says, split ks >= 1 STORES its partial product into slab ks - 1
-  // (batched: product b has its own run of slabs behind the others')
-  const bool to_slab = p.slab != nullptr && ks > 0;
-  if (to_slab) pC = (char*)(p.slab + ((int64_t)(p.batch > 1 ? blockIdx.z / p.split_k : 0) * (p.split_k - 1) + (ks - 1)) * p.slab_stride);
+  // k-split without atomics (p.slab): EVERY split STORES its partial product into its own slab ks (batched: product b has its
+  // own run of split_k slabs behind the others'); C is written only by an unsplit launch
+  const bool to_slab = p.slab != nullptr && p.split_k > 1;
+  if (to_slab) pC = (char*)(p.slab + ((int64_t)(p.batch > 1 ? blockIdx.z / p.split_k : 0) * p.split_k + ks) * p.slab_stride);
   float* __restrict__ C = (float*)pC + (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // ---- per-thread source descriptors (byte pointers), computed once
@@ -653,8 +653,8 @@ __global__ __launch_bounds__(256) void gemm_x3_tall_kernel(const GemmParams p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int kiters = (k_end - k_begin) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
-  const bool to_slab = p.slab != nullptr && ks > 0;      // k-split without atomics: see gemm_f32_kernel
-  float* __restrict__ C = (to_slab ? p.slab + (int64_t)(ks - 1) * p.slab_stride : (float*)p.C) +
+  const bool to_slab = p.slab != nullptr && p.split_k > 1;      // k-split without atomics: see gemm_f32_kernel
+  float* __restrict__ C = (to_slab ? p.slab + (int64_t)ks * p.slab_stride : (float*)p.C) +
                           (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // ---- operands as raw buffers: byte offsets, unsigned 32-bit; anything outside [0, bytes) reads zeros.  A row shifted
@@ -1107,8 +1107,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_tall_kernel(const GemmParams p)
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int kiters = (k_end - k_begin) / BK;
   const int n_iters = (p.tap_mode == 1 ? p.taps : 1) * kiters;
-  const bool to_slab = p.slab != nullptr && ks > 0;      // k-split without atomics: see gemm_f32_kernel
-  float* __restrict__ C = (to_slab ? p.slab + (int64_t)(ks - 1) * p.slab_stride : (float*)p.C) +
+  const bool to_slab = p.slab != nullptr && p.split_k > 1;      // k-split without atomics: see gemm_f32_kernel
+  float* __restrict__ C = (to_slab ? p.slab + (int64_t)ks * p.slab_stride : (float*)p.C) +
                           (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   // operands as raw buffers (see gemm_x3_tall_kernel): byte offsets, anything outside reads zeros
@@ -1464,10 +1464,10 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     if (p.slab_cap < 0 || (p.slab_stride & 3) || (((uintptr_t)p.slab) & 15) || p.c16 || p.act != DVAE_ACT_NONE ||
         (p.epi != DVAE_EPI_STORE && p.epi != DVAE_EPI_ACCUM))
       return DVAE_EINVAL;
-    if (p.split_k > p.slab_cap + 1) p.split_k = p.slab_cap + 1;
+    if (p.split_k > p.slab_cap) p.split_k = p.slab_cap > 0 ? p.slab_cap : 1;
   } else if (p.split_k > 1 && (p.epi != DVAE_EPI_ATOMIC || p.act != DVAE_ACT_NONE)) return DVAE_EINVAL;
   const bool splittable = p.slab != nullptr || p.epi == DVAE_EPI_ATOMIC;      // a launch may cut k further itself
-  const int max_sk = p.slab ? p.slab_cap + 1 : (1 << 30);
+  const int max_sk = p.slab ? (p.slab_cap > 0 ? p.slab_cap : 1) : (1 << 30);
   if (p.epi != DVAE_EPI_STORE && p.act != DVAE_ACT_NONE) return DVAE_EINVAL;
   // tuning knobs for experiments (scripts/one_shape.py): environment variables in the DEV build, constants in the product
   static const int bk_env = dvae_dev_knob("DVAE_GEMM_BK", 0);
@@ -1539,6 +1539,9 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   // operands of one layout.  An atomically accumulated product is cut into as many k-splits as make one workgroup per CU.
   bool t256 = false;
   const int t256_env = dvae_dev_knob("DVAE_GEMM_256", -1);      // (dev build: read per call, scripts/g256_check.py toggles it)
+  // (the row-contiguous form — weight gradients, k-splits into slabs — from 32 output tiles on: 1.10 x / 1.05 x the tall
+  // kernel at 64 / 32 tiles, 0.99 x at 16; the conv weight gradients (20 tile-taps) stay on the tall kernel.  DVAE_GEMM_256=2
+  // in the dev build forces it)
   if (bf && p.batch <= 1 && p.a16 && p.b16 && !p.c16 && t256_env != 0 && a_kc == b_kc && p.M >= 256 && p.N >= 256 &&
       (p.K % 64 == 0) && (p.N % 8 == 0) && (p.M % 8 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
       (p.c_tap_stride % 4 == 0) && a_bytes < (1ll << 31) && b_bytes < (1ll << 31)) {
@@ -1552,8 +1555,9 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     const int iters = (kps256 / 64) * (p.tap_mode == 1 ? p.taps : 1);
     const int t256_min = dvae_dev_knob("DVAE_GEMM_256_MIN", 224);
     // (no atomic and no tanh epilogue in that kernel: k-splits only into slabs)
-    const bool epi_ok = p.epi != DVAE_EPI_ATOMIC && p.act != DVAE_ACT_TANH && (p.split_k == 1 || p.slab != nullptr);
-    if (epi_ok && ((tz * sk >= t256_min && iters >= 8) || t256_env == 1)) {
+    const bool epi_ok = p.epi != DVAE_EPI_ATOMIC && p.act != DVAE_ACT_TANH && (p.split_k == 1 || p.slab != nullptr) &&
+                        (a_kc || tz >= 32 || t256_env == 2);
+    if (epi_ok && ((tz * sk >= t256_min && iters >= 8) || t256_env >= 1)) {
       t256 = true;
       tall16 = false;
       kps = kps256;
@@ -1698,11 +1702,11 @@ DVAE_API int dvae_gemm_f32_batched(const void* const* A, const void* const* B, v
   return launch_gemm(p, a_kcontig != 0, b_kcontig != 0, mode, (hipStream_t)stream);
 }
 
-// ---- k-split WITHOUT atomics (round 6).  Split 0 writes C as `epi` says (DVAE_EPI_STORE / DVAE_EPI_ACCUM), split ks >= 1 stores
-// its partial product plainly into slab + (ks - 1) * slab_stride.  Returns the number of k-splits launched (>= 1; the
-// dispatch may take fewer or — up to slab_cap + 1 — more than `split_k`), or a negative error code.  The caller adds the
-// slabs to C in the fixed order ks = 1, 2, ...: dvae_slab_sum, dvae_slab_fold.  Every output element has ONE writer per
-// buffer and the sum one order: results are run-to-run bit-identical.
+// ---- k-split WITHOUT atomics (round 6).  When the launch is split (return value n > 1) EVERY split ks stores its partial product
+// plainly into slab + ks * slab_stride and C is NOT written; an unsplit launch (n == 1) writes C as `epi` says.  Returns the
+// number of k-splits launched (the dispatch may take fewer or — up to slab_cap — more than `split_k`), or a negative error
+// code.  The caller combines the n slabs in the fixed order ks = 0, 1, ...: dvae_slab_sum (C = or += their sum),
+// dvae_slab_fold.  One writer per element and one summation order: results are run-to-run bit-identical.
 DVAE_API int dvae_gemm_f32_slabs(const void* A, const void* B, void* C, float* slab, int64_t slab_stride, int slab_cap,
                                  const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                                  int a_kcontig, int b_kcontig, int epi, int split_k, int mode, void* stream) {
@@ -1719,7 +1723,7 @@ DVAE_API int dvae_gemm_f32_slabs(const void* A, const void* B, void* C, float* s
   return rc == DVAE_OK ? p.split_k : rc;
 }
 
-// batched form: product b stores its splits ks >= 1 into slabs (b * (n - 1) + ks - 1), n = the returned split count
+// batched form: product b stores its split ks into slab (b * n + ks), n = the returned split count (> 1)
 DVAE_API int dvae_gemm_f32_batched_slabs(const void* const* A, const void* const* B, void* const* C, int batch, float* slab,
                                          int64_t slab_stride, int slab_cap, int M, int N, int K, int64_t lda, int64_t ldb,
                                          int64_t ldc, int a_kcontig, int b_kcontig, int epi, int split_k, int mode,
@@ -1768,7 +1772,7 @@ void narrow_conv_split(GemmParams& p, int mode, hipStream_t s) {
     if (steps < 24) return;
     if (tiles * sk >= 192) {
       if (p.slab) {      // plain stores into the caller's slabs (dvae_conv5_fwd_slabs / dgrad_t_slabs): the caller sums them
-        if (sk - 1 > p.slab_cap) return;
+        if (sk > p.slab_cap) return;
         p.split_k = sk;
         return;
       }

@@ -70,9 +70,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(const GemmParams p) 
   const int kiters = (k_end - k_begin) / BK;
   const int ntaps_loop = (p.tap_mode == 1) ? p.taps : 1;
   const int n_iters = ntaps_loop * kiters;
-  // k-split without atomics: split 0 writes the result buffer, split ks >= 1 its own slab (summed later in the fixed order
-  // ks = 0, 1, ...: dvae_slab_sum / the Adam launch)
-  float* __restrict__ C = ((p.slab && ks > 0) ? p.slab + (int64_t)(ks - 1) * p.slab_stride : (float*)p.C) +
+  // k-split without atomics: every split stores its own slab (combined later in the fixed order ks = 0, 1, ...: dvae_slab_sum /
+  // dvae_slab_fold); the result buffer is written only by an unsplit launch
+  const bool to_slab = p.slab != nullptr && p.split_k > 1;
+  float* __restrict__ C = (to_slab ? p.slab + (int64_t)ks * p.slab_stride : (float*)p.C) +
                           (p.tap_mode == 2 ? (int64_t)tap_fixed * p.c_tap_stride : 0);
 
   const int a_rows = A_KC ? p.M : p.K, b_rows = B_KC ? p.N : p.K;
@@ -140,20 +141,47 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(const GemmParams p) 
     if (B_KC) fb[i] = (wn * 64 + l31) * 128 + (((2 * i + kh) ^ ((l31 >> 1) & 7)) << 4);
     else fb[i] = tr_k * 512 + (((wn * 64 + (i & 1) * 32 + tr_r) * 2) ^ ((tr_k & 3) << 6));
   }
-  auto frag = [&](const char* img, bool kc, const int (&f)[4], int tile, int sub) -> bf16x8 {
-    if (kc) return *reinterpret_cast<const bf16x8*>(img + f[sub] + tile * 4096);
-    const char* q0 = img + f[tile] + sub * 8192;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t*)(q0 + 2048));
+  // k-contiguous operand: ds_read_b128 through the LDS array (hipcc waits for it by itself).
+  // row-contiguous operand: ds_read_b64_tr_b16 as INLINE ASM.  Through the builtin, hipcc (ROCm 7.2) drains `vmcnt(0)` in front
+  // of every transpose read that follows an LDS-DMA — it cannot tell the read from the DMA's destination — which serialised
+  // the whole staging pipeline (the weight-gradient shapes ran at 0.6 of the tall kernel; seen in the .s, DESIGN.md section
+  // 4.1).  An asm statement is invisible to its wait insertion: the reads of a sub-step are waited for by hand
+  // (`s_waitcnt lgkmcnt(0)` + sched_barrier in front of the next sub-step's first MFMA) and their halves are joined into the
+  // MFMA operand only behind that wait.
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_void_t*)lds;
+  struct Frags {
+    bf16x8 a[MTW], b[NTW];                 // k-contiguous operands
+    s16x4 a2[MTW][2], b2[NTW][2];          // row-contiguous operands: the two halves of a fragment
+  };
+  auto tr_read = [&](s16x4& dst, unsigned addr, auto OFF) {
+    constexpr int off = decltype(OFF)::value;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+  };
+  auto read_frag = [&](Frags& f, auto BUF, auto SUB, auto W) {    // W = 0..5: A tiles, then B tiles
+    constexpr int buf = decltype(BUF)::value, sub = decltype(SUB)::value, w = decltype(W)::value;
+    if constexpr (w < MTW) {
+      if constexpr (A_KC) f.a[w] = *reinterpret_cast<const bf16x8*>(lds + buf * 2 * OPB + fa[sub] + w * 4096);
+      else {
+        const unsigned ad = lds_base + buf * 2 * OPB + fa[w];
+        tr_read(f.a2[w][0], ad, std::integral_constant<int, sub * 8192>{});
+        tr_read(f.a2[w][1], ad, std::integral_constant<int, sub * 8192 + 2048>{});
+      }
+    } else {
+      constexpr int t = w - MTW;
+      if constexpr (B_KC) f.b[t] = *reinterpret_cast<const bf16x8*>(lds + buf * 2 * OPB + OPB + fb[sub] + t * 4096);
+      else {
+        const unsigned ad = lds_base + buf * 2 * OPB + OPB + fb[t];
+        tr_read(f.b2[t][0], ad, std::integral_constant<int, sub * 8192>{});
+        tr_read(f.b2[t][1], ad, std::integral_constant<int, sub * 8192 + 2048>{});
+      }
+    }
+  };
+  auto join = [](const s16x4& lo, const s16x4& hi) -> bf16x8 {
     return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  struct Frags {
-    bf16x8 a[MTW], b[NTW];
-  };
-  auto read_frag = [&](Frags& f, int buf, int sub, int w) {    // w = 0..5: A tiles, then B tiles
-    if (w < MTW) f.a[w] = frag(lds + buf * 2 * OPB, A_KC, fa, w, sub);
-    else f.b[w - MTW] = frag(lds + buf * 2 * OPB + OPB, B_KC, fb, w - MTW, sub);
-  };
+  auto op_a = [&](const Frags& f, int mt) -> bf16x8 { if constexpr (A_KC) return f.a[mt]; else return join(f.a2[mt][0], f.a2[mt][1]); };
+  auto op_b = [&](const Frags& f, int nt) -> bf16x8 { if constexpr (B_KC) return f.b[nt]; else return join(f.b2[nt][0], f.b2[nt][1]); };
+  constexpr bool ASM_READS = !A_KC || !B_KC;
 
   f32x16 acc[MTW][NTW];
 #pragma unroll
@@ -175,17 +203,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(const GemmParams p) 
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int w = 0; w < MTW + NTW; ++w) read_frag(fr[0], 0, 0, w);
+  for_seq([&](auto W) { read_frag(fr[0], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, W); },
+          std::make_integer_sequence<int, MTW + NTW>{});
 
   // one k-tile = 32 pinned steps: MFMA g, then at most one fragment read and one LDS-DMA piece
   auto step = [&](auto G, auto U) {
     constexpr int g = decltype(G)::value, u = decltype(U)::value;    // u = parity of the k-tile being computed
     constexpr int sub = g / 8, e = g % 8, mt = e / 2, nt = e % 2;
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[sub & 1].a[mt], fr[sub & 1].b[nt], acc[mt][nt], 0, 0, 0);
+    if constexpr (ASM_READS && e == 0) {      // the asm transpose reads of this sub-step's fragments (issued a sub-step ago)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op_a(fr[sub & 1], mt), op_b(fr[sub & 1], nt), acc[mt][nt], 0, 0, 0);
     if constexpr (e < MTW + NTW) {
-      if constexpr (sub < 3) read_frag(fr[(sub + 1) & 1], u, sub + 1, e);
-      else read_frag(fr[0], u ^ 1, 0, e);
+      if constexpr (sub < 3)
+        read_frag(fr[(sub + 1) & 1], std::integral_constant<int, u>{}, std::integral_constant<int, sub + 1>{},
+                  std::integral_constant<int, e>{});
+      else
+        read_frag(fr[0], std::integral_constant<int, u ^ 1>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, e>{});
     }
     if constexpr (sub == 3) dma_piece(u, e);      // tile i+2 -> the buffer tile i just left
     __builtin_amdgcn_sched_barrier(0);
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(const GemmParams p) 
   // the epilogue: 64 accumulator registers were spilled in front of it, and scratch reloads pending beside atomics (both
   // count in vmcnt) serialised the atomics — the k-split products ran at 0.55 of the tall kernel.
   using std::integral_constant;
-  const int epi_here = (p.slab && ks > 0) ? DVAE_EPI_STORE : p.epi;      // splits behind the first store their slab plainly
+  const int epi_here = to_slab ? DVAE_EPI_STORE : p.epi;      // a split stores its slab plainly
   if (epi_here == DVAE_EPI_ACCUM) emit(integral_constant<int, DVAE_EPI_ACCUM>{}, integral_constant<int, DVAE_ACT_NONE>{});
   else if (p.act == DVAE_ACT_RELU) emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_RELU>{});
   else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});

@@ -40,12 +40,12 @@ struct GemmParams {
   int batch;
   int64_t a_boff[4], b_boff[4], c_boff[4];
   int c_vec;             // 128 x 128 kernel: C rows can be stored / accumulated 16 bytes at a time (N, ldc multiples of 4, aligned)
-  // k-split WITHOUT atomics (round 6): split 0 writes C as `epi` says (store / read-modify-write), split ks >= 1 STORES its
-  // partial product plainly into slab + (ks - 1) * slab_stride (elements; per-tap outputs at the same c_tap_stride inside a
-  // slab); whoever needs the result adds the slabs to C in the fixed order ks = 1, 2, ... (dvae_slab_sum / dvae_slab_fold)
+  // k-split WITHOUT atomics (round 6): a SPLIT launch (split_k > 1) stores split ks's partial product plainly into
+  // slab + ks * slab_stride (elements; per-tap outputs at the same c_tap_stride inside a slab) and leaves C alone; whoever
+  // needs the result combines the slabs in the fixed order ks = 0, 1, ... (dvae_slab_sum / dvae_slab_fold)
   float* slab;
   int64_t slab_stride;
-  int slab_cap;          // slabs the caller provides: at most slab_cap + 1 k-splits (host side only)
+  int slab_cap;          // slabs the caller provides: at most slab_cap k-splits (host side only)
 };
 
 // BF = bf16 compute mode (dvae_set_compute_mode(1); BASELINE configs[2]/[4]): operands stay fp32 in HBM and are rounded

@@ -125,12 +125,15 @@ __device__ __forceinline__ unsigned pers_epoch(const PersArgs& a) {
 __device__ __forceinline__ void pers_finish(const PersArgs& a) {
   __shared__ int recycle;
   if (threadIdx.x == 0) recycle = 0;
+  // Every flag store of this workgroup — also one that was never polled (a give-up path, a dropped workgroup) — must be IN
+  // MEMORY before its DONE increment, so that the last workgroup's zeroing of the flags (recycle) cannot be overtaken by a late
+  // flag of ~2^30 + T.  Flags are write-through (sc1) stores: once acknowledged they are at the memory side, and this wait
+  // (every wave, before the barrier) is that acknowledgement.  (An agent-scope RELEASE on the increment was measured first,
+  // its L2 write-back runs over the hundreds of MB of gates / dG this launch has just written — +20 us per launch.)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    // release: every flag store of this workgroup (also one that was never polled: a give-up path, a dropped workgroup) is
-    // ordered in front of its DONE increment; acquire in the last workgroup: its zeroing of the flags (recycle) is ordered
-    // behind every peer's stores — a late flag of ~2^30 + T can then not land on a recycled (zero) flag
-    const unsigned d = __hip_atomic_fetch_add(a.err + PERS_DONE_WORD, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned d = __hip_atomic_fetch_add(a.err + PERS_DONE_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d == gridDim.x - 1) {
       __hip_atomic_store(a.err + PERS_DONE_WORD, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned e = atomicAdd(a.err + PERS_EPOCH_WORD, (unsigned)a.T + 1u) + (unsigned)a.T + 1u;
@@ -139,6 +142,7 @@ __device__ __forceinline__ void pers_finish(const PersArgs& a) {
   }
   __syncthreads();
   if (recycle) {
+    __threadfence();      // (once per 1.4 M steps) behind every peer's acknowledged stores, in front of the zeroing
     for (int i = threadIdx.x; i < PERS_FLAG_BYTES / 4; i += blockDim.x)
       __hip_atomic_store(a.flags + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();

@@ -169,8 +169,8 @@ def _ready(*ps):
 _slab_param: dict = {}       # (data_ptr of the result, elements, cap) -> slab tensor of an optimiser-owned gradient
 _slab_scratch: dict = {}     # (device index, stream handle) -> scratch slabs of transient results (consumed on that stream)
 _colsum_ws: dict = {}        # (device index, stream handle) -> workspace of the deterministic column sums
-SLAB_CAP = 15                # slabs provided to a split contraction: up to 16 k-splits (the 256-row tiles cut K further
-                             # themselves, to one workgroup per CU)
+SLAB_CAP = 16                # slabs provided to a split contraction = the most k-splits it may take (the 256-row tiles cut K
+                             # further themselves, to one workgroup per CU)
 
 
 def _stream_key(dev):
@@ -277,7 +277,7 @@ def wgrad_gemm_batched(As, Bs, params, M, N, K, lda, ldb, split_k, mode, flags=0
         return
     owner = _owner_of(params[0])
     stride = _pad4(M * N)
-    cap = SLAB_CAP * nb
+    cap = _cap_for(split_k) * nb
     key = (grads[0].data_ptr(), M * N, cap)
     slab = _slab_param.get(key) if owner is not None else None
     if slab is None:
@@ -289,8 +289,9 @@ def wgrad_gemm_batched(As, Bs, params, M, N, K, lda, ldb, split_k, mode, flags=0
                                           EPI_ACCUM, split_k, m, stream())
     if n < 1:
         check(n, "dvae_gemm_f32_batched_slabs")
-    for b, (g, p) in enumerate(zip(grads, params)):
-        _defer_fold(g, _owner_of(p), slab.data_ptr() + 4 * b * (n - 1) * stride, stride, n - 1)
+    if n > 1:
+        for b, (g, p) in enumerate(zip(grads, params)):
+            _defer_fold(g, _owner_of(p), slab.data_ptr() + 4 * b * n * stride, stride, n)
 
 
 def _owner_of(p):
@@ -298,7 +299,8 @@ def _owner_of(p):
 
 
 def gemm_slabs(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi, split_k, mode, slab, stride, cap, flags=0):
-    """dvae_gemm_f32_slabs: returns the number of k-splits launched (split 0 in Cout, the others in `slab`)"""
+    """dvae_gemm_f32_slabs: returns the number n of k-splits launched: n > 1 -> every split in its slab, Cout untouched;
+    n == 1 -> Cout written as `epi` says"""
     a = lambda t: t if (t is None or isinstance(t, int)) else t.data_ptr()
     n = lib().dvae_gemm_f32_slabs(a(A), a(B), a(Cout), a(slab), stride, cap, a(bias), M, N, K, lda, ldb, ldc, int(a_kc),
                                   int(b_kc), epi, split_k, _mflags(_mode(mode), A, B, Cout) | flags, stream())
@@ -307,25 +309,35 @@ def gemm_slabs(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi, split_
     return n
 
 
+def _cap_for(split_k: int) -> int:
+    """slabs to provide for a product asked to split `split_k` ways: the one-workgroup-per-CU tiles may double the split"""
+    return max(SLAB_CAP, min(128, 2 * int(split_k)))
+
+
 def gemm_split(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, act, split_k, mode, flags=0):
     """Cout = act(A B + bias) with K cut into (about) split_k parts and NO atomics: partial products into scratch slabs,
     summed (and activated) right behind the contraction.  Cout: [M, N] contiguous (ldc == N)."""
     n_el = M * ldc
-    slab, stride = _scratch_slabs(Cout.device, n_el, SLAB_CAP)
-    n = gemm_slabs(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, EPI_STORE, split_k, mode, slab, stride, SLAB_CAP, flags)
-    if n > 1 or act != ACT_NONE:
-        check(lib().dvae_slab_sum(ptr(Cout), ptr(slab), stride, n - 1, n_el, act, stream()), "dvae_slab_sum")
+    cap = _cap_for(split_k)
+    slab, stride = _scratch_slabs(Cout.device, n_el, cap)
+    n = gemm_slabs(A, B, Cout, bias, M, N, K, lda, ldb, ldc, a_kc, b_kc, EPI_STORE, split_k, mode, slab, stride, cap, flags)
+    if n > 1:       # Cout = act(sum of the n slabs) (the bias rode split 0)
+        check(lib().dvae_slab_sum(ptr(Cout), ptr(slab), stride, n, n_el, act, 0, stream()), "dvae_slab_sum")
+    elif act != ACT_NONE:
+        check(lib().dvae_slab_sum(ptr(Cout), None, 0, 0, n_el, act, 1, stream()), "dvae_slab_sum")
 
 
 def wgrad_gemm(A, B, grad, owner, M, N, K, lda, ldb, a_kc, b_kc, split_k, mode, flags=0):
-    """grad[M, N] += A^T B-shaped weight gradient, K cut into (about) split_k parts without atomics: split 0 adds to `grad`
-    (read-modify-write), the others store slabs that are summed later (optimiser-owned gradient) or now."""
+    """grad[M, N] += A^T B-shaped weight gradient, K cut into (about) split_k parts without atomics: every split STORES its slab
+    (no read-modify-write in any epilogue); `grad += their sum` later (optimiser-owned gradient: end of backward) or now."""
     if split_k <= 1:
         gemm(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, ACT_NONE, EPI_ACCUM, 1, mode, flags)
         return
-    slab, stride = _param_slabs(grad, SLAB_CAP) if owner is not None else _scratch_slabs(grad.device, grad.numel(), SLAB_CAP)
-    n = gemm_slabs(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, EPI_ACCUM, split_k, mode, slab, stride, SLAB_CAP, flags)
-    _defer_fold(grad, owner, slab.data_ptr(), stride, n - 1)
+    cap = _cap_for(split_k)
+    slab, stride = _param_slabs(grad, cap) if owner is not None else _scratch_slabs(grad.device, grad.numel(), cap)
+    n = gemm_slabs(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, EPI_ACCUM, split_k, mode, slab, stride, cap, flags)
+    if n > 1:
+        _defer_fold(grad, owner, slab.data_ptr(), stride, n)
 
 
 _DETERMINISTIC = False
@@ -682,13 +694,13 @@ class ConvBnActFn(torch.autograd.Function):
                 # few output columns (postnet's last conv: 80 mel channels): the conv is cut along k (csrc/gemm.hip
                 # narrow_conv_split), its splits stored into slabs and summed right here (no atomics) — no statistics in
                 # that epilogue: one pass over the [R, 80] result instead
-                slab, stride = _scratch_slabs(dev, R * Cout, 7)
-                n = L.dvae_conv5_fwd_slabs(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), ptr(slab), stride, 7, R, n_seg, Cin, Cout,
+                slab, stride = _scratch_slabs(dev, R * Cout, 8)
+                n = L.dvae_conv5_fwd_slabs(ptr(xa), ptr(wop), ptr(conv_b), ptr(y), ptr(slab), stride, 8, R, n_seg, Cin, Cout,
                                            fmode, st)
                 if n < 1:
                     check(n, "dvae_conv5_fwd_slabs")
                 if n > 1:
-                    check(L.dvae_slab_sum(ptr(y), ptr(slab), stride, n - 1, R * Cout, ACT_NONE, st), "dvae_slab_sum")
+                    check(L.dvae_slab_sum(ptr(y), ptr(slab), stride, n, R * Cout, ACT_NONE, 0, st), "dvae_slab_sum")
                 check(L.dvae_bn_stats_fwd(ptr(y), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt),
                                           ptr(ws), R, n_seg, Cout, G, BN_EPS, BN_MOMENTUM, st), "dvae_bn_stats_fwd")
             else:
@@ -752,13 +764,13 @@ class ConvBnActFn(torch.autograd.Function):
                 wpt = conv_wpt_local(conv_wp)
             if Cin <= 128 and (R * Cin) % 4 == 0:
                 # few output columns (the 80 mel channels): the default arithmetic cuts K to fill the chip — into slabs
-                slab, stride = _scratch_slabs(dev, R * Cin, 7)
-                n = L.dvae_conv5_dgrad_t_slabs(ptr(dy), ptr(wpt), ptr(dx), ptr(slab), stride, 7, R, n_seg, Cin, Cout,
+                slab, stride = _scratch_slabs(dev, R * Cin, 8)
+                n = L.dvae_conv5_dgrad_t_slabs(ptr(dy), ptr(wpt), ptr(dx), ptr(slab), stride, 8, R, n_seg, Cin, Cout,
                                                _mflags(mode, dy, wpt), st)
                 if n < 1:
                     check(n, "dvae_conv5_dgrad_t_slabs")
                 if n > 1:
-                    check(L.dvae_slab_sum(ptr(dx), ptr(slab), stride, n - 1, R * Cin, ACT_NONE, st), "dvae_slab_sum")
+                    check(L.dvae_slab_sum(ptr(dx), ptr(slab), stride, n, R * Cin, ACT_NONE, 0, st), "dvae_slab_sum")
             else:
                 check(L.dvae_conv5_dgrad_t(ptr(dy), ptr(wpt), ptr(dx), R, n_seg, Cin, Cout, _mflags(mode, dy, wpt), st),
                       "dvae_conv5_dgrad_t")
@@ -774,14 +786,15 @@ class ConvBnActFn(torch.autograd.Function):
             # Adam launch (or right here for a gradient no optimiser owns): no atomics
             gw, own = _grad_buf(conv_wp), _owner_of(conv_wp)
             slab, stride = (None, 0)
+            cap = _cap_for(sk)
             if sk > 1:
-                slab, stride = _param_slabs(gw, SLAB_CAP) if own is not None else _scratch_slabs(dev, gw.numel(), SLAB_CAP)
-            n = L.dvae_conv5_wgrad_slabs(ptr(dy), ptr(xa), ptr(gw), ptr(slab), stride, SLAB_CAP if sk > 1 else 0, R, n_seg,
+                slab, stride = _param_slabs(gw, cap) if own is not None else _scratch_slabs(dev, gw.numel(), cap)
+            n = L.dvae_conv5_wgrad_slabs(ptr(dy), ptr(xa), ptr(gw), ptr(slab), stride, cap if sk > 1 else 0, R, n_seg,
                                          Cin, Cout, EPI_ACCUM, sk, _mflags(mode, dy, xa), stream())
             if n < 1:
                 check(n, "dvae_conv5_wgrad_slabs")
             if n > 1:
-                _defer_fold(gw, own, slab.data_ptr(), stride, n - 1)
+                _defer_fold(gw, own, slab.data_ptr(), stride, n)
             colsum_add(dy, _grad_buf(conv_b))
         _ready(conv_wp, conv_b, bn_w, bn_b)
         dres = dz if has_res else None

@@ -107,21 +107,21 @@ int dvae_gemm_f32_batched(const void* const* A, const void* const* B, void* cons
                           int mode, void* stream);
 /* ---- k-split WITHOUT atomics (round 6; replaces the split-K atomic accumulation of every aten::mm / convolution_backward
  * the reference runs through cuBLAS / cuDNN: /root/reference/model/variational_base_vae.py:68 `loss.backward()`) ----
- * A product cut along k stores its partial results PLAINLY: split 0 writes C as `epi` says (DVAE_EPI_STORE, or
- * DVAE_EPI_ACCUM: read-modify-write), split ks >= 1 stores into slab + (ks - 1) * slab_stride (elements; a multiple of 4, >=
- * the extent of C; the slabs 16-byte aligned; conv weight gradients keep their five per-tap outputs at the same distances
- * inside a slab).  `slab_cap` = slabs the caller provides: the dispatch may take fewer k-splits than `split_k` asks for, or
- * — the tiles that want one workgroup per CU — more, never more than slab_cap + 1.  RETURNS the number of k-splits
- * launched (>= 1), or a negative error code.  The caller then adds the slabs to C in the fixed order ks = 1, 2, ...
- * (dvae_slab_sum now, or dvae_slab_fold later, e.g. right in front of the optimiser's launch): every output element has
- * ONE writer per buffer and ONE summation order, so results are run-to-run bit-identical — and the epilogues are plain
- * 16-byte stores (the atomic epilogue of a weight gradient measured 17 us against 6).  No bias, no activation when split
- * (dvae_slab_sum applies the activation).  dvae_conv5_fwd_slabs / dvae_conv5_dgrad_t_slabs: the convs with <= 128 output
- * columns, which the default arithmetic cuts along k to fill the chip (they return 1 when they did not split). */
+ * A product cut along k stores its partial results PLAINLY: when the launch is split (return value n > 1) EVERY split ks
+ * stores into slab + ks * slab_stride (elements; a multiple of 4, >= the extent of C; the slabs 16-byte aligned; conv weight
+ * gradients keep their five per-tap outputs at the same distances inside a slab) and C is NOT written; an unsplit launch
+ * (n == 1) writes C as `epi` says (DVAE_EPI_STORE / DVAE_EPI_ACCUM).  `slab_cap` = slabs the caller provides: the dispatch may
+ * take fewer k-splits than `split_k` asks for, or — the tiles that want one workgroup per CU — more, never more than
+ * slab_cap.  RETURNS the number of k-splits launched (>= 1), or a negative error code.  The caller then combines the n
+ * slabs in the fixed order ks = 0, 1, ... (dvae_slab_sum now, or dvae_slab_fold later, e.g. at the end of the backward pass):
+ * every output element has ONE writer per buffer and ONE summation order, so results are run-to-run bit-identical, and every
+ * epilogue is plain 16-byte stores (no read-modify-write, no atomics).  The bias rides split 0; no activation when split
+ * (dvae_slab_sum applies it).  dvae_conv5_fwd_slabs / dvae_conv5_dgrad_t_slabs: the convs with <= 128 output columns, which
+ * the default arithmetic cuts along k to fill the chip (they return 1 when they did not split). */
 int dvae_gemm_f32_slabs(const void* A, const void* B, void* C, float* slab, int64_t slab_stride, int slab_cap,
                         const float* bias, int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc,
                         int a_kcontig, int b_kcontig, int epi, int split_k, int mode, void* stream);
-/* batched form (dvae_gemm_f32_batched): product b stores split ks >= 1 into slab (b * (n - 1) + ks - 1), n = the return value */
+/* batched form (dvae_gemm_f32_batched): product b stores split ks into slab (b * n + ks), n = the return value (> 1) */
 int dvae_gemm_f32_batched_slabs(const void* const* A, const void* const* B, void* const* C, int batch, float* slab,
                                 int64_t slab_stride, int slab_cap, int M, int N, int K, int64_t lda, int64_t ldb,
                                 int64_t ldc, int a_kcontig, int b_kcontig, int epi, int split_k, int mode, void* stream);
@@ -131,9 +131,10 @@ int dvae_conv5_dgrad_t_slabs(const void* dY, const void* Wpt, float* dX, float* 
                              int R, int N, int Cin, int Cout, int mode, void* stream);
 int dvae_conv5_wgrad_slabs(const void* dY, const void* X, float* dWp, float* slab, int64_t slab_stride, int slab_cap,
                            int R, int N, int Cin, int Cout, int epi, int split_k, int mode, void* stream);
-/* C[i] = act(C[i] + sum_{k < nslab} slab[k * slab_stride + i]), i < n  (n, slab_stride multiples of 4) */
-int dvae_slab_sum(float* C, const float* slab, int64_t slab_stride, int nslab, int64_t n, int act, void* stream);
-/* the same for many results in ONE launch per DVAE_SLAB_FOLD_MAX entries (`descs` is read during the call only) */
+/* C[i] = act((accumulate ? C[i] : 0) + sum_{k < nslab} slab[k * slab_stride + i]), i < n  (n, slab_stride multiples of 4) */
+int dvae_slab_sum(float* C, const float* slab, int64_t slab_stride, int nslab, int64_t n, int act, int accumulate,
+                  void* stream);
+/* c[i] += sum_{k < nslab} slab[...] for many results in ONE launch per DVAE_SLAB_FOLD_MAX entries (`descs`: read during the call) */
 typedef struct {
   float* c;
   const float* slab;

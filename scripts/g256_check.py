@@ -35,7 +35,7 @@ class tall_only:
     def __enter__(self):
         os.environ["DVAE_GEMM_256"] = "0"
     def __exit__(self, *a):
-        os.environ.pop("DVAE_GEMM_256", None)
+        os.environ["DVAE_GEMM_256"] = "2"      # 2: the 256 x 256 kernel for BOTH operand layouts (dev build)
 
 
 def both(fn):
@@ -59,6 +59,7 @@ def gemm_pair(M, N, K, kc, epi=ops.EPI_STORE, sk=1):
     return out[0], out[1], a, b
 
 
+os.environ["DVAE_GEMM_256"] = "2"
 if what in ("check", "both"):
     for (M, N, K, kc) in [(65536, 512, 512, True), (3880, 3848, 576, True), (4096, 4096, 1024, False),
                           (3880, 3848, 576, False), (65536, 256, 64 * 9, True), (16384, 4096, 512, True)]:
@@ -74,6 +75,21 @@ if what in ("check", "both"):
         e16 = float((c16[:256].double() - ref).abs().max())
         e32 = float((c32[:256].double() - ref).abs().max())
         report(f"gemm tn atomic M={M} N={N} K={K} sk={sk}", e16 < 4 * max(e32, 1e-4), f"err64 {e16:.2e} (128 x 128 kernel {e32:.2e})")
+    # the weight-gradient form with its k-splits in slabs: tall kernel against the 256 x 256 kernel (different split counts:
+    # not bitwise), fp64, and run to run
+    for (M, N, K, sk) in [(4096, 1024, 65536, 2), (2048, 512, 65280 // 64 * 64, 8)]:
+        a, b = rnd(K, M).bfloat16(), rnd(K, N).bfloat16()
+
+        def wg():
+            g_ = torch.zeros(M, N, device="cuda")
+            ops.wgrad_gemm(a, b, g_, None, M, N, K, M, N, False, False, sk, BF)
+            return g_
+        t_, n_ = both(wg)
+        n2 = wg()
+        ref = a[:, :256].double().t() @ b.double()
+        e1 = float((n_[:256].double() - ref).norm() / ref.norm())
+        report(f"wgrad tn slabs M={M} N={N} K={K}", torch.equal(n_, n2) and e1 < 5e-6 and float((t_ - n_).abs().max()) < 1e-2,
+               f"relL2 vs fp64 {e1:.2e}, run-to-run bitwise {torch.equal(n_, n2)}, max |tall - 256| {float((t_ - n_).abs().max()):.2e}")
     # bias + activation epilogues
     M, N, K = 65536, 512, 512
     a, b, bias = r16(rnd(M, K)), r16(rnd(N, K)), rnd(N)
@@ -185,5 +201,9 @@ if what in ("time", "both"):
         Bm = t16(Nn, K) if kc else t16(K, Nn)
         Cm = torch.zeros(M, Nn, device="cuda")
         lda, ldb = (K if kc else M), (K if kc else Nn)
-        timeit(f"gemm {'nt' if kc else 'tn'} M={M} N={Nn} K={K} sk={sk}",
-               lambda: ops.gemm(A, Bm, Cm, None, M, Nn, K, lda, ldb, Nn, kc, kc, 0, epi, sk, BF | FL), 2.0 * M * Nn * K)
+        if kc:
+            timeit(f"gemm nt M={M} N={Nn} K={K} sk={sk}",
+                   lambda: ops.gemm(A, Bm, Cm, None, M, Nn, K, lda, ldb, Nn, kc, kc, 0, epi, sk, BF | FL), 2.0 * M * Nn * K)
+        else:      # weight-gradient shapes: k-splits into slabs, summed right behind (no optimiser owns Cm)
+            timeit(f"wgrad tn M={M} N={Nn} K={K} sk={sk} (slabs + sum)",
+                   lambda: ops.wgrad_gemm(A, Bm, Cm, None, M, Nn, K, lda, ldb, False, False, sk, BF), 2.0 * M * Nn * K)

@@ -756,11 +756,11 @@ def test_conv5_bf16_256_against_fp64(ops, R, N, Cin, Cout):
     dws = []
     for _ in range(2):
         dw = torch.zeros(5, Cout, Cin, device="cuda")
-        slab = torch.empty(15 * dw.numel(), device="cuda")
-        n = L.dvae_conv5_wgrad_slabs(ptr(gy), ptr(x), ptr(dw), ptr(slab), dw.numel(), 15, R, N, Cin, Cout, ops.EPI_ACCUM, 6, FL,
+        slab = torch.empty(16 * dw.numel(), device="cuda")
+        n = L.dvae_conv5_wgrad_slabs(ptr(gy), ptr(x), ptr(dw), ptr(slab), dw.numel(), 16, R, N, Cin, Cout, ops.EPI_ACCUM, 6, FL,
                                      stream())
         assert n >= 2, n
-        check(L.dvae_slab_sum(ptr(dw), ptr(slab), dw.numel(), n - 1, dw.numel(), 0, stream()), "slab_sum")
+        check(L.dvae_slab_sum(ptr(dw), ptr(slab), dw.numel(), n, dw.numel(), 0, 1, stream()), "slab_sum")
         dws.append(dw)
     assert torch.equal(dws[0], dws[1])
     for tap in (0, 2, 4):

@@ -62,13 +62,13 @@ def test_against_reference_golden(golden_dir, name):
     gn = np.array([float(p.grad.double().norm()) for _, p in w.model.named_parameters()])
     ref = g["grad_norm"]
     big = np.array([not is_prebn_conv_bias(n) for n in g["param_names"]])
-    # The style head's gradient (norm 32-170 against 1e2-1e4 elsewhere) is the end of the longest cancellation chain of
-    # the backward pass: run to run (atomic split-K accumulation order + ReLU-gate flips) its norm moves between 1.2e-3
-    # and 4.3e-3 of the reference's at B = 64, T = 128 — with the backward recurrence on fp32 fragments and on three-plane
-    # fragments alike (scripts/diag_gradnorm.py) — and was seen at 5.2e-3 once; everything else stays below 2e-3.
+    # Round 6: no atomics on the step, so these norms are run-to-run bit-identical; what is left against the reference is
+    # the ReLU-kink sensitivity of the model itself (one pre-activation within 1e-6 of zero flips its mask and moves the
+    # gradients upstream of it by up to 3.6e-3: scripts/dz_diag.py) — the style head sits at the end
+    # of the longest such chain.
     style = np.array([n.startswith("style.linear_layer.") for n in g["param_names"]])
     np.testing.assert_allclose(gn[big & ~style], ref[big & ~style], rtol=5e-3)
-    np.testing.assert_allclose(gn[style], ref[style], rtol=1e-2)
+    np.testing.assert_allclose(gn[style], ref[style], rtol=5e-3)
     assert np.all(gn[~big] < 0.2) and np.all(ref[~big] < 0.2)   # round-off only; real gradient norms are >= 50
     for k in g.files:
         if k.startswith("g_"):
@@ -76,7 +76,9 @@ def test_against_reference_golden(golden_dir, name):
             # relative L2 (ReLU-gate / |.|-sign flips make single elements differ by ~1% of the largest
             # one between any two fp32 implementations, see test_against_oracle_b8_t64_full_gradients)
             err = float(np.linalg.norm(p.grad.cpu().numpy().astype(np.float64) - g[k]))
-            assert err <= 1e-2 * float(np.linalg.norm(g[k])), (k, err)
+            # (6e-3: the deepest BatchNorm of the encoder measures 5.03e-3 at B = 64, T = 128 — the same value in every run now —
+            # ReLU-kink flips upstream of it, see above; everything else is below 4e-3)
+            assert err <= 6e-3 * float(np.linalg.norm(g[k])), (k, err / float(np.linalg.norm(g[k])))
         if k.startswith("bn_"):
             v = w.model.state_dict()[k[3:]].cpu().numpy()
             np.testing.assert_allclose(v, g[k], rtol=2e-4, atol=1e-5, err_msg=k)
