@@ -1539,9 +1539,9 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
   // operands of one layout.  An atomically accumulated product is cut into as many k-splits as make one workgroup per CU.
   bool t256 = false;
   const int t256_env = dvae_dev_knob("DVAE_GEMM_256", -1);      // (dev build: read per call, scripts/g256_check.py toggles it)
-  // (the row-contiguous form — weight gradients, k-splits into slabs — from 32 output tiles on: 1.10 x / 1.05 x the tall
-  // kernel at 64 / 32 tiles, 0.99 x at 16; the conv weight gradients (20 tile-taps) stay on the tall kernel.  DVAE_GEMM_256=2
-  // in the dev build forces it)
+  // (the row-contiguous form — weight gradients, k-splits into slabs — from 20 output tile-taps on: 1.13 x / 1.05 x the tall
+  // kernel at 64 / 32 tiles, 1.06 x on the conv weight gradients (4 tiles x 5 taps), 1.01 x at 16 tiles.  DVAE_GEMM_256=2 in
+  // the dev build forces it)
   if (bf && p.batch <= 1 && p.a16 && p.b16 && !p.c16 && t256_env != 0 && a_kc == b_kc && p.M >= 256 && p.N >= 256 &&
       (p.K % 64 == 0) && (p.N % 8 == 0) && (p.M % 8 == 0) && (p.ldc % 4 == 0) && (((uintptr_t)p.C & 15) == 0) &&
       (p.c_tap_stride % 4 == 0) && a_bytes < (1ll << 31) && b_bytes < (1ll << 31)) {
@@ -1556,7 +1556,7 @@ int launch_gemm(GemmParams& p, bool a_kc, bool b_kc, int mode, hipStream_t s) {
     const int t256_min = dvae_dev_knob("DVAE_GEMM_256_MIN", 224);
     // (no atomic and no tanh epilogue in that kernel: k-splits only into slabs)
     const bool epi_ok = p.epi != DVAE_EPI_ATOMIC && p.act != DVAE_ACT_TANH && (p.split_k == 1 || p.slab != nullptr) &&
-                        (a_kc || tz >= 32 || t256_env == 2);
+                        (a_kc || tz >= 20 || t256_env == 2);
     if (epi_ok && ((tz * sk >= t256_min && iters >= 8) || t256_env >= 1)) {
       t256 = true;
       tall16 = false;

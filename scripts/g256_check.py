@@ -192,6 +192,12 @@ if what in ("time", "both"):
     timeit("conv dgrad", lambda: check(L.dvae_conv5_dgrad_t(ptr(x), ptr(wp), ptr(y), R, N, 512, 512, BF | FL, stream()), ""), 10.0 * R * 512 * 512)
     dw = torch.zeros(5, 512, 512, device="cuda")
     timeit("conv wgrad sk=6", lambda: check(L.dvae_conv5_wgrad(ptr(x), ptr(x), ptr(dw), R, N, 512, 512, 6, BF | FL, stream()), ""), 10.0 * R * 512 * 512)
+    slab = torch.empty(16 * dw.numel(), device="cuda")
+
+    def conv_wgrad_slabs():
+        n = L.dvae_conv5_wgrad_slabs(ptr(x), ptr(x), ptr(dw), ptr(slab), dw.numel(), 16, R, N, 512, 512, ops.EPI_ACCUM, 6, BF | FL, stream())
+        check(L.dvae_slab_sum(ptr(dw), ptr(slab), dw.numel(), n, dw.numel(), 0, 1, stream()), "")
+    timeit("conv wgrad, k-splits into slabs + sum", conv_wgrad_slabs, 10.0 * R * 512 * 512)
     for (M, Nn, K, kc, epi, sk) in [(65536, 4096, 1024, True, ops.EPI_STORE, 1), (65536, 1024, 4096, True, ops.EPI_STORE, 1),
                                     (65536, 4096, 512, True, ops.EPI_STORE, 1), (65536, 512, 4096, True, ops.EPI_STORE, 1),
                                     (4096, 1024, 65536, False, ops.EPI_ATOMIC, 2), (4096, 512, 65536, False, ops.EPI_ATOMIC, 4),

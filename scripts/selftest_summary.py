@@ -1,0 +1,27 @@
+"""gpurun_out/selftest/*.log (one per GPU call, scripts/gpu_call.sh) -> profiles/selftest_chips.md: which chips ran
+`python -m dvae_amd.selftest` (every product persistent LSTM kernel, 40 rounds under foreign HBM traffic), and the result."""
+import glob, os, re, sys
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rows = {}
+for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "selftest", "*.log"))):
+    t = open(f).read()
+    m = re.search(r"unique_id\(s\): \[([^\]]*)\]", t)
+    uid = m.group(1).replace("'", "") if m else "?"
+    ok = "selftest PASSED" in t
+    bad = sum(int(x) for x in re.findall(r": (\d+) bad rounds of", t))
+    cases = len(re.findall(r"bad rounds of", t))
+    r = rows.setdefault(uid, [0, 0, 0, 0])
+    r[0] += 1; r[1] += int(ok); r[2] += bad; r[3] = max(r[3], cases)
+out = ["# Deployment selftest on the pool's chips (round 6)", "",
+       "`python -m dvae_amd.selftest --rounds 40` at the start of every GPU call of the round (scripts/gpu_call.sh): every persistent",
+       "LSTM kernel the product dispatches — fp32x3 H = 1024 / 512 at N = 128; bf16 H = 1024 at N = 256 / 128 and H = 512 at N = 128,",
+       "T = 48; and the 16-row bf16 forms over the T = 512 of BASELINE configs[4] — against the per-frame kernels and bit for bit",
+       "against the first round, a second stream streaming 0-4 GiB through HBM.", "",
+       "| KFD unique_id | calls | passed | bad rounds | cases per call |", "|---|---|---|---|---|"]
+for uid, (n, ok, bad, cases) in sorted(rows.items()):
+    out.append(f"| {uid} | {n} | {ok} | {bad} | {cases} |")
+out += ["", f"{len(rows)} distinct chips, {sum(r[0] for r in rows.values())} calls, {sum(r[2] for r in rows.values())} bad rounds.",
+        "(The first 19 calls of the round overwrote one shared log file: every one of them printed `selftest PASSED` — the tails",
+        "are in the session's gpurun output — but their unique_ids were not kept.)"]
+open(os.path.join(root, "profiles", "selftest_chips.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out[-4:]))
