@@ -17,7 +17,10 @@ w = bench.build_trainer(dev, B, T, dtype)
 x1, x2, spk = SyntheticPairs(B, T, n_speakers=10, seed=1234, device=dev).batch()
 L = _lib.lib()
 rec = []
-names = ["dvae_gemm_f32", "dvae_conv5_fwd", "dvae_conv5_fwd_stats", "dvae_conv5_wgrad", "dvae_conv5_dgrad_t"]
+names = ["dvae_gemm_f32", "dvae_conv5_fwd", "dvae_conv5_fwd_stats", "dvae_conv5_wgrad", "dvae_conv5_dgrad_t",
+         # round 6: the k-split forms (their slab sums are separate launches: dvae_slab_sum / dvae_slab_fold, listed too)
+         "dvae_gemm_f32_slabs", "dvae_gemm_f32_batched_slabs", "dvae_gemm_f32_batched", "dvae_conv5_wgrad_slabs",
+         "dvae_conv5_fwd_slabs", "dvae_conv5_dgrad_t_slabs", "dvae_slab_sum", "dvae_slab_fold"]
 orig = {n: getattr(L, n) for n in names}
 
 
@@ -29,7 +32,25 @@ def wrap(name):
         e0.record()
         rc = fn(*a)
         e1.record()
-        if name == "dvae_gemm_f32":
+        if name == "dvae_gemm_f32_slabs":
+            M, N, K, a_kc, b_kc, sk = a[7], a[8], a[9], a[13], a[14], a[16]
+            key, fl = f"gemm_slabs M={M} N={N} K={K} akc={a_kc} bkc={b_kc} sk={sk}->{rc}", 2.0 * M * N * K
+        elif name in ("dvae_gemm_f32_batched_slabs", "dvae_gemm_f32_batched"):
+            o = 3 if name.endswith("slabs") else 0
+            nb, M, N, K = a[3], a[4 + o], a[5 + o], a[6 + o]
+            key, fl = f"{name[5:]} x{nb} M={M} N={N} K={K}", 2.0 * nb * M * N * K
+        elif name == "dvae_conv5_wgrad_slabs":
+            R, Cin, Cout, sk = a[6], a[8], a[9], a[11]
+            key, fl = f"conv_wgrad_slabs R={R} Cin={Cin} Cout={Cout} sk={sk}->{rc}", 10.0 * R * Cin * Cout
+        elif name in ("dvae_conv5_fwd_slabs", "dvae_conv5_dgrad_t_slabs"):
+            o = 1 if name == "dvae_conv5_fwd_slabs" else 0
+            R, Cin, Cout = a[6 + o], a[8 + o], a[9 + o]
+            key, fl = f"{name[5:]} R={R} Cin={Cin} Cout={Cout} splits={rc}", 10.0 * R * Cin * Cout
+        elif name == "dvae_slab_sum":
+            key, fl = f"slab_sum n={a[4]} slabs={a[3]}", 0.0
+        elif name == "dvae_slab_fold":
+            key, fl = f"slab_fold entries={a[1]}", 0.0
+        elif name == "dvae_gemm_f32":
             M, N, K, a_kc, b_kc, act, epi, sk = a[4], a[5], a[6], a[10], a[11], a[12], a[13], a[14]
             md = a[15]
             key, fl = f"gemm M={M} N={N} K={K} akc={a_kc} bkc={b_kc} epi={epi} sk={sk} mode={md & 0xff if md >= 0 else md} a16={(md >> 8) & 1 if md >= 0 else 0} b16={(md >> 9) & 1 if md >= 0 else 0}", 2.0 * M * N * K

@@ -91,7 +91,7 @@ if g and g.get("FETCH_SIZE") and g.get("WRITE_SIZE"):
     launches = cnt["gemm_f32_kernel"]["FETCH_SIZE"] / steps
     rd, wr = 2 * g["FETCH_SIZE"] * 1024 / steps, g["WRITE_SIZE"] * 1024 / steps
     h = hashlib.sha256()
-    for f in ("gemm.hip", "common.h"):
+    for f in ("gemm.hip", "gemm256.hip", "gemm_common.h", "common.h"):      # = bench.kernel_source_hash()
         h.update(open(os.path.join(ROOT, "disentangle-vae-for-vc_amd", "csrc", f), "rb").read())
     dtype = os.environ.get("DVAE_COMPUTE_DTYPE", "fp32x3")
     out = {"source": f"profiles/{tag}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 per "
