@@ -376,6 +376,163 @@ __global__ __launch_bounds__(512) void gemm_bf16_256_kernel(const GemmParams p) 
   else emit(integral_constant<int, DVAE_EPI_STORE>{}, integral_constant<int, DVAE_ACT_NONE>{});
 }
 
+
+#ifdef DVAE_DEV
+// ---- experiment (dev build, DVAE_GEMM_256_SHAPE=16): the same pipeline on v_mfma_f32_16x16x32_bf16 — MI355X_MICROARCH.md
+// measures 1.12-1.15 x the FLOP/s of the 32x32x16 shape at equal cycles (the power-limited chip holds a higher clock on it).
+// k-contiguous operands, plain / bias / ReLU store epilogue only.  The LDS images and the DMA are the shipped kernel's (the
+// chunk swizzle c ^ ((row >> 1) & 7) is conflict-free for this shape's ds_read_b128 lane groups too: rows 0-3, 12-15 of one
+// chunk and rows 4-11 of the next cover the 16 slots of the bank row).  Results are NOT bit-identical to the other kernels
+// (32 k per MFMA instead of 16: another summation order).
+__global__ __launch_bounds__(512) void gemm_bf16_256s_kernel(const GemmParams p) {
+  constexpr int BM = 256, BN = 256, BK = 64, MT = 8, NT = 4;
+  constexpr int OPB = 32768;
+  constexpr unsigned OOB = 0xC0000000u;
+  __shared__ __attribute__((aligned(1024))) char lds[4 * OPB];
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, lq = lane >> 4;
+  int tile_m, tile_n;
+  gemm_tile_of(p, tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ks = blockIdx.z;
+  const int k_begin = ks * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int kiters = (k_end - k_begin) / BK;
+  const int ntaps_loop = (p.tap_mode == 1) ? p.taps : 1;
+  const int n_iters = ntaps_loop * kiters;
+  float* __restrict__ C = (float*)p.C;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((int64_t)p.M * p.lda * 2), 0x00020000);
+  const int64_t b_bytes = (int64_t)p.N * p.ldb * 2 * ((p.tap_mode == 1) ? p.taps : 1);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)b_bytes, 0x00020000);
+  unsigned voa[4], vob[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = wave * 4 + j;
+    const int r = 8 * q + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
+    voa[j] = (unsigned)(((int64_t)(m0 + r) * p.lda + k_begin + c * 8) * 2);
+    if (m0 + r >= p.M) voa[j] = OOB;
+    vob[j] = (unsigned)(((int64_t)(n0 + r) * p.ldb + k_begin + c * 8) * 2);
+    if (n0 + r >= p.N) vob[j] = OOB;
+  }
+  const int a_tap_step = (p.tap_mode == 1) ? (int)(p.a_row_shift * p.lda * 2) : 0;
+  const int b_tap_step = (p.tap_mode == 1) ? (int)(p.b_tap_stride * 2) : 0;
+  int tap_n = 0, kit_n = 0;
+  unsigned a_s = 0, b_s = 0;
+  auto next_tile_offsets = [&]() {
+    const bool live = kit_n < kiters;
+    a_s = live ? (unsigned)((tap_n - 2) * a_tap_step + kit_n * BK * 2) : OOB;
+    b_s = live ? (unsigned)(tap_n * b_tap_step + kit_n * BK * 2) : OOB;
+    const bool wrap = (tap_n + 1 == ntaps_loop);
+    tap_n = wrap ? 0 : tap_n + 1;
+    kit_n += wrap ? 1 : 0;
+  };
+  auto dma_piece = [&](int buf, int j) {
+    char* dst = lds + buf * 2 * OPB + (j >= 4 ? OPB : 0) + (wave * 4 + (j & 3)) * 1024;
+    if (j < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void_t*)dst, 16, voa[j] + a_s, 0, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void_t*)dst, 16, vob[j - 4] + b_s, 0, 0, 0);
+  };
+  // fragment addresses: [sub] -> row (first row of the wave + l15), chunk (4 sub + lq) ^ (l15 >> 1); MFMA tile adds 16 rows = 2048 B
+  int fa[2], fb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    fa[i] = (wm * 128 + l15) * 128 + (((4 * i + lq) ^ (l15 >> 1)) << 4);
+    fb[i] = (wn * 64 + l15) * 128 + (((4 * i + lq) ^ (l15 >> 1)) << 4);
+  }
+  f32x4v acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  bf16x8 fA[2][4], fB[2][4];       // A: set = step & 1 (four m-tiles of one half); B: set = sub & 1
+  auto read_a = [&](int set, int buf, int sub, int mh, int i) {
+    fA[set][i] = *reinterpret_cast<const bf16x8*>(lds + buf * 2 * OPB + fa[sub] + (4 * mh + i) * 2048);
+  };
+  auto read_b = [&](int set, int buf, int sub, int i) {
+    fB[set][i] = *reinterpret_cast<const bf16x8*>(lds + buf * 2 * OPB + OPB + fb[sub] + i * 2048);
+  };
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dma_piece(0, j);
+  next_tile_offsets();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dma_piece(1, j);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) read_a(0, 0, 0, 0, i);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) read_b(0, 0, 0, i);
+  // one k-tile = four steps (k32 half `sub`, m-half `mh`) of 16 MFMAs; the next step's fragments are read in its first gaps
+  auto step = [&](auto S, auto E, auto U) {
+    constexpr int s = decltype(S)::value, e = decltype(E)::value, u = decltype(U)::value;
+    constexpr int sub = s >> 1, mh = s & 1, i = e >> 2, nt = e & 3, mt = 4 * mh + i;
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fA[s & 1][i], fB[sub & 1][nt], acc[mt][nt], 0, 0, 0);
+    if constexpr (e < 4) {
+      if constexpr (s < 3) read_a((s + 1) & 1, u, (s + 1) >> 1, (s + 1) & 1, e);
+      else read_a(0, u ^ 1, 0, 0, e);
+    } else if constexpr (e < 8) {
+      if constexpr (s == 1) read_b(1, u, 1, e - 4);
+      else if constexpr (s == 3) read_b(0, u ^ 1, 0, e - 4);
+    }
+    if constexpr (s == 3 && (e & 1)) dma_piece(u, e >> 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto run = [&](auto U) {
+    for_seq([&](auto G) { step(std::integral_constant<int, decltype(G)::value / 16>{},
+                               std::integral_constant<int, decltype(G)::value % 16>{}, U); },
+            std::make_integer_sequence<int, 48>{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    for_seq([&](auto G) { step(std::integral_constant<int, 3>{}, G, U); }, std::make_integer_sequence<int, 16>{});
+  };
+  for (int it0 = 0; it0 < n_iters; it0 += 2) {
+    next_tile_offsets();
+    run(std::integral_constant<int, 0>{});
+    next_tile_offsets();
+    run(std::integral_constant<int, 1>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // epilogue: C/D of the 16 x 16 tile: col = lane & 15, row = 4 (lane >> 4) + reg; 4 x 4 transpose inside each lane quad, 16-byte stores
+  const bool add_bias = p.bias != nullptr;
+  const int q4 = lane & 3;
+  const bool relu = p.act == DVAE_ACT_RELU;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = n0 + wn * 64 + nt * 16 + l15;
+      if (col >= p.N) continue;
+      const float bv = add_bias ? p.bias[col] : 0.f;
+      float x[4], y[4], z[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = acc[mt][nt][e] + bv;
+        x[e] = relu ? (v > 0.f ? v : 0.f) : v;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x[e ^ 1]), 0xB1, 0xF, 0xF, true));
+        y[e] = ((q4 ^ e) & 1) ? o : x[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y[e ^ 2]), 0x4E, 0xF, 0xF, true));
+        z[e] = ((q4 ^ e) & 2) ? o : y[e];
+      }
+      const int row = m0 + wm * 128 + mt * 16 + 4 * lq + q4;
+      if (row < p.M) *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + (col - q4)) = f32x4{z[0], z[1], z[2], z[3]};
+    }
+}
+#endif
+
 }  // namespace
 
 // launch_gemm (gemm.hip) decides; `p` arrives complete (tiles_m for 256-row tiles, the XCD map, k_per_split a multiple of 64)
@@ -386,7 +543,15 @@ int dvae_launch_gemm_bf16_256(const void* params, int a_kc, int b_kc, int bn_uni
   if (p.bn_part) {
     if (!a_kc || !b_kc) return DVAE_EINVAL;
     if (bn_uniform) G256(true, true, true, true); else G256(true, true, true, false);
-  } else if (a_kc && b_kc) G256(true, true, false, false);
+  } else if (a_kc && b_kc) {
+#ifdef DVAE_DEV
+    if (dvae_dev_knob("DVAE_GEMM_256_SHAPE", 32) == 16 && p.epi == DVAE_EPI_STORE && p.split_k == 1 && p.tap_mode != 2) {
+      hipLaunchKernelGGL(gemm_bf16_256s_kernel, grid, dim3(512), 0, s, p);
+      return DVAE_OK;
+    }
+#endif
+    G256(true, true, false, false);
+  }
   else if (!a_kc && !b_kc) G256(false, false, false, false);
   else return DVAE_EINVAL;      // mixed layouts: no caller at these sizes (launch_gemm keeps them on the tall kernel)
 #undef G256
