@@ -371,7 +371,7 @@ def lstm_roofline(tags, tot, prof_steps):
             "timed": f"HIP events around every recurrence call, {prof_steps} eager steps after the timed region"}
 
 
-def time_other_config(dev, name, B, T, dtype, steps=5):
+def time_other_config(dev, name, B, T, dtype, steps=15):
     """One of the non-headline single-GPU configurations, timed here over a few graph-replayed steps, with the
     achieved rates of its two dominant kernel families (eager steps with HIP events afterwards)."""
     from dvae_amd import ops
@@ -421,7 +421,7 @@ def time_other_config(dev, name, B, T, dtype, steps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)      # 50 x 18 ms: a timed region of ~1 s (round 5 review: 0.35 s was short)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="pairs per GPU")
     ap.add_argument("--frames", type=int, default=128)

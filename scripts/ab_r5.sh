@@ -1,5 +1,7 @@
 #!/bin/bash
-# GPU box, round 6: the round-5 tree (build_exp/r5, built here from `git archive 0a3c193`) and HEAD on the SAME box, back to back
+# GPU box, round 6: the round-5 tree and HEAD on the SAME box, back to back.  Prepare in the build container first:
+#   mkdir -p build_exp/r5 && git archive 0a3c193 | tar -x -C build_exp/r5 && (cd build_exp/r5 && bash disentangle-vae-for-vc_amd/csrc/build.sh)
+# (build_exp/ is git-ignored but travels with gpurun)
 (cd build_exp/r5 && timeout 600 python bench.py --no-cpu-baseline > ../../gpurun_out/bench_r5.json 2> ../../gpurun_out/bench_r5.err)
 timeout 900 python bench.py --no-cpu-baseline > gpurun_out/bench_b.json 2> gpurun_out/bench_b.err
 python - <<'PY'
