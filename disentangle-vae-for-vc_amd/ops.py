@@ -166,7 +166,8 @@ def _ready(*ps):
 # collectives issued from the hooks — when their bucket becomes ready (_ready); everything else (Linear outputs and
 # data gradients with few rows, stand-alone use in kernel tests) right behind the contraction (dvae_slab_sum, which also
 # applies the activation).
-_slab_param: dict = {}       # (data_ptr of the result, elements, cap) -> slab tensor of an optimiser-owned gradient
+_slab_param: dict = {}       # (data_ptr of the result, elements, cap) -> slab tensor of a gradient WITHOUT an owning optimiser; the
+                             # slabs of an optimiser-owned gradient live in that optimiser (`_slab_store`) and die with it
 _slab_scratch: dict = {}     # (device index, stream handle) -> scratch slabs of transient results (consumed on that stream)
 _colsum_ws: dict = {}        # (device index, stream handle) -> workspace of the deterministic column sums
 SLAB_CAP = 16                # slabs provided to a split contraction = the most k-splits it may take (the 256-row tiles cut K
@@ -203,13 +204,18 @@ def _scratch_slabs(dev, n_elems: int, cap: int):
     return buf, stride
 
 
-def _param_slabs(c: torch.Tensor, cap: int):
-    """(slab tensor, stride) that lives as long as the gradient view `c` it belongs to"""
+def _slab_store(owner) -> dict:
+    return _slab_param if owner is None else owner.__dict__.setdefault("_slab_store", {})
+
+
+def _param_slabs(c: torch.Tensor, cap: int, owner=None):
+    """(slab tensor, stride) that lives as long as the optimiser that owns the gradient view `c`"""
     stride = _pad4(c.numel())
     key = (c.data_ptr(), c.numel(), cap)
-    buf = _slab_param.get(key)
+    store = _slab_store(owner)
+    buf = store.get(key)
     if buf is None:
-        buf = _slab_param[key] = torch.empty(cap * stride, device=c.device, dtype=torch.float32)
+        buf = store[key] = torch.empty(cap * stride, device=c.device, dtype=torch.float32)
     return buf, stride
 
 
@@ -279,10 +285,10 @@ def wgrad_gemm_batched(As, Bs, params, M, N, K, lda, ldb, split_k, mode, flags=0
     stride = _pad4(M * N)
     cap = _cap_for(split_k) * nb
     key = (grads[0].data_ptr(), M * N, cap)
-    slab = _slab_param.get(key) if owner is not None else None
+    slab = _slab_store(owner).get(key) if owner is not None else None
     if slab is None:
         if owner is not None:
-            slab = _slab_param[key] = torch.empty(cap * stride, device=grads[0].device, dtype=torch.float32)
+            slab = _slab_store(owner)[key] = torch.empty(cap * stride, device=grads[0].device, dtype=torch.float32)
         else:
             slab, _ = _scratch_slabs(grads[0].device, cap * stride, 1)
     n = lib().dvae_gemm_f32_batched_slabs(arr(As), arr(Bs), arr(grads), nb, ptr(slab), stride, cap, M, N, K, lda, ldb, N, 0, 0,
@@ -334,7 +340,7 @@ def wgrad_gemm(A, B, grad, owner, M, N, K, lda, ldb, a_kc, b_kc, split_k, mode, 
         gemm(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, ACT_NONE, EPI_ACCUM, 1, mode, flags)
         return
     cap = _cap_for(split_k)
-    slab, stride = _param_slabs(grad, cap) if owner is not None else _scratch_slabs(grad.device, grad.numel(), cap)
+    slab, stride = _param_slabs(grad, cap, owner) if owner is not None else _scratch_slabs(grad.device, grad.numel(), cap)
     n = gemm_slabs(A, B, grad, None, M, N, K, lda, ldb, N, a_kc, b_kc, EPI_ACCUM, split_k, mode, slab, stride, cap, flags)
     if n > 1:
         _defer_fold(grad, owner, slab.data_ptr(), stride, n)
@@ -788,7 +794,7 @@ class ConvBnActFn(torch.autograd.Function):
             slab, stride = (None, 0)
             cap = _cap_for(sk)
             if sk > 1:
-                slab, stride = _param_slabs(gw, cap) if own is not None else _scratch_slabs(dev, gw.numel(), cap)
+                slab, stride = _param_slabs(gw, cap, own) if own is not None else _scratch_slabs(dev, gw.numel(), cap)
             n = L.dvae_conv5_wgrad_slabs(ptr(dy), ptr(xa), ptr(gw), ptr(slab), stride, cap if sk > 1 else 0, R, n_seg,
                                          Cin, Cout, EPI_ACCUM, sk, _mflags(mode, dy, xa), stream())
             if n < 1:
@@ -1034,9 +1040,10 @@ class LstmLayerFn(torch.autograd.Function):
             bi, bh = params[0][2], params[0][3]
             gbi, gbh = _grad_buf(bi), _grad_buf(bh)
             key = (gbi.data_ptr(), 4 * H, "pers_bias")
-            part = _slab_param.get(key)
+            store = _slab_store(_owner_of(bi))
+            part = store.get(key)
             if part is None:
-                part = _slab_param[key] = torch.zeros(_lib.PERS_BIAS_SLABS * 4 * H, device=dev, dtype=torch.float32)
+                part = store[key] = torch.zeros(_lib.PERS_BIAS_SLABS * 4 * H, device=dev, dtype=torch.float32)
             dirs[0].dbias_part = ptr(part)
         check(L.dvae_lstm_seq_bwd(dirs, ndir, T, N, H, ldh, st), "dvae_lstm_seq_bwd")
         if pers_bias:
