@@ -418,3 +418,53 @@ def test_abort_process_group_never_blocks_or_raises():
     # (round 6: the abort runs on a thread of its own with a five-second bound, then os._exit(1) — ADVICE r5)
     assert "target=_abort_process_group" in body and "os._exit(1)" in body
     assert body.index("raise") < body.index("dist.barrier()")
+
+
+def test_ctypes_structs_follow_the_header():
+    """include/dvae_hip.h is the contract: the ctypes mirrors in _lib.py must list the same fields in the same order (a field
+    inserted in one place only — round 6 added dvae_lstm_dir_t.dbias_part and dvae_slab_desc_t — shifts every pointer behind
+    it), and the constants must agree."""
+    import re
+    import dvae_amd  # noqa: F401
+    from dvae_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "dvae_hip.h")).read()
+
+    def fields(struct_name):
+        body = hdr[:hdr.index("} " + struct_name + ";")]
+        body = body[body.rindex("typedef struct {"):]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        body = body[body.index("{") + 1:]
+        out = []
+        for stmt in body.split(";"):                      # `int kind, d0, d1, d2` -> four fields
+            for decl in stmt.split(","):
+                m = re.search(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])?\s*$", decl.strip())
+                if m and decl.strip():
+                    out.append(m.group(1))
+        return out
+
+    assert fields("dvae_lstm_dir_t") == [f[0] for f in _lib.LstmDir._fields_]
+    assert fields("dvae_slab_desc_t") == [f[0] for f in _lib.SlabDesc._fields_]
+    assert fields("dvae_repack_desc_t") == [f[0] for f in _lib.RepackDesc._fields_]
+    assert int(re.search(r"#define DVAE_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
+    assert int(re.search(r"#define DVAE_SLAB_FOLD_MAX (\d+)", hdr).group(1)) == _lib.SLAB_FOLD_MAX
+    assert int(re.search(r"#define DVAE_PERS_BIAS_SLABS (\d+)", hdr).group(1)) == _lib.PERS_BIAS_SLABS
+    import ctypes as C
+    assert C.sizeof(_lib.SlabDesc) == 40
+
+
+def test_trajectory_band_is_monotone_and_floored(golden_dir):
+    """conftest.trajectory_band: never below the 1e-4 of the single-step contract, non-decreasing over the steps inside each
+    group of like losses, and the perturbed runs only widen it."""
+    import numpy as np
+    from conftest import trajectory_band, trajectory_band_bf16
+    g = np.load(os.path.join(golden_dir, "trajectory_c0_b4_t64.npz"))
+    ref, band = trajectory_band(g)
+    _, thin = trajectory_band(g, perturbed=False)
+    assert ref.shape == band.shape == (int(g["n_steps"]), 8)
+    assert np.all(band >= 1e-4) and np.all(np.diff(band, axis=0) >= 0) and np.all(band >= thin)
+    assert np.allclose(band[:, 0], band[:, 4]) and np.allclose(band[:, 5], band[:, 7])
+    _, b16 = trajectory_band_bf16(g)
+    assert np.all(b16 >= band) and np.all(b16 >= 2e-3)
+    # what the fixture says about the reference itself: agrees with itself at step 1, is chaotic by step 5
+    spread = np.abs(g["traj_fp32"] - g["traj_fp32"][-1][None]).max(0) / np.abs(g["traj_fp32"][-1])
+    assert spread[0].max() < 1e-6 and spread[4].max() > 1e-2
