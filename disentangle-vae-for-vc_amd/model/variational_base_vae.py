@@ -111,11 +111,9 @@ class VariationalBaseModelVAE:
                 bool(ops.LSTM_PERSISTENT), bool(ops.deterministic()))
 
     def _eager_train_step(self, data1, data2):
-        from .. import ops
-        if getattr(self, "_zero_arena", None) is None:
-            self._zero_arena = ops.ZeroArena()
-        with self._zero_arena:       # the step's split-k outputs: one clear launch instead of eight
-            return self._train_step_body(data1, data2)
+        # (until round 5 the step ran inside an ops.ZeroArena: one clear launch for the outputs that split-k contractions
+        # accumulated into atomically; split contractions store slabs now and nothing needs clearing)
+        return self._train_step_body(data1, data2)
 
     def _train_step_body(self, data1, data2):
         self.optimizer.zero_grad()

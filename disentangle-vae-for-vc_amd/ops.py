@@ -350,12 +350,11 @@ _DETERMINISTIC = False
 
 
 def set_deterministic(flag: bool = True):
-    """TEST mode (not the benchmarked path): every accumulated output element gets one writer in a fixed order — no
-    split-k atomics (contractions run unsplit), column sums by one workgroup per column block, the recurrences' bias
-    gradients by such a column sum instead of the persistent launches' atomics.  Two runs of a step on the same inputs
-    are then BIT-identical, so graph replay vs eager and RCCL vs plain can be compared exactly
-    (tests/test_hip_determinism.py) instead of through the 1e-5 ... 4e-2 tolerances the atomics' run-to-run noise
-    needs.  Slower (under-filled launches); `DVAE_DETERMINISTIC=1` in the environment switches it on at import."""
+    """TEST mode (not the benchmarked path): every contraction runs UNSPLIT.  Since round 6 the default mode is run-to-run
+    bit-identical as well (k-splits store slabs that are added in a fixed order, deterministic column sums and recurrence
+    bias gradients: no floating-point atomics on the step); this mode is a second deterministic arithmetic with another
+    summation order — tests/test_hip_determinism.py runs every comparison in both.  Slower (under-filled launches);
+    `DVAE_DETERMINISTIC=1` in the environment switches it on at import."""
     global _DETERMINISTIC
     _DETERMINISTIC = bool(flag)
     check(lib().dvae_set_deterministic(int(_DETERMINISTIC)), "dvae_set_deterministic")
@@ -369,14 +368,15 @@ def _split_k(m_tiles: int, k: int, slots: int = 0, fixed: int = 192) -> int:
     """Pick the split of the contraction that minimises (rounds over the chip) x (k per workgroup + fixed cost):
     512 workgroup slots (2 per CU at the 128x128x32 tile), each split keeps >= 256 of K.  Not restricted to
     powers of two: 80 tiles x 6 splits fill one round where x 8 needs two.  `slots` / `fixed`: for shapes that run on the
-    256 x 128 kernels (one workgroup per CU; an atomically accumulated 128 KB epilogue per workgroup)."""
+    256 x 128 kernels (one workgroup per CU; a 128 KB epilogue per workgroup — a slab store since round 6; the constants were
+    fitted to the atomic epilogues of rounds 3-5 and re-checked against the same-box A/B of round 6)."""
     if _DETERMINISTIC:
         return 1
     slots = slots or int(os.environ.get("DVAE_SPLIT_SLOTS", "512"))
     best, best_cost = 1, None
     for s in range(1, max(1, k // 256) + 1):
         rounds = -(-(m_tiles * s) // slots)
-        # + 4 per split: each split is one more atomic epilogue over the output (dW[256 x 64] over K = 65536: 128 splits
+        # + 4 per split: each split is one more epilogue over the output, and one more slab for the fold (dW[256 x 64] over K = 65536: 128 splits
         # 36 us, the 256 a split-free model picks 46; scripts/skinny_wgrad_sweep.py)
         cost = rounds * (-(-k // s) + fixed) * (1.0 if s == 1 else 1.03) + (4 * s if s > 1 else 0)
         if best_cost is None or cost < best_cost:
@@ -467,70 +467,6 @@ def gemm_batched(As, Bs, Cs, M, N, K, lda, ldb, ldc, a_kc, b_kc, epi=EPI_ATOMIC,
     m = _mode(mode)
     check(lib().dvae_gemm_f32_batched(arr(As), arr(Bs), arr(Cs), n, M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), epi,
                                       split_k, _mflags(m, As[0], Bs[0], Cs[0]) | flags, stream()), "dvae_gemm_f32_batched")
-
-
-class ZeroArena:
-    """The zero-initialised outputs that split-k contractions accumulate into atomically (eight Linear outputs and data
-    gradients per train step), handed out as views of ONE buffer that ONE `dvae_zero_f32` launch clears at the start of the
-    step — instead of one clear launch in front of each.  Owned by a trainer and active only inside its train step
-    (`with arena:`): outside, and while the arena is still learning how much a step needs (its first step), `zeros()`
-    clears each tensor on its own.  Views are valid until the owner's NEXT step begins — the step's own forward / backward
-    use them, nothing that outlives the step may.
-    (Round 3 tried this together with an Adam-side clear and dropped it for 1e-5 deviations that turned out to be the
-    persistent launches' flag clear under graph replay, DESIGN_HISTORY.md; tests/test_hip_determinism.py now compares the
-    replayed and the eager step bit for bit with the arena in.)"""
-
-    def __init__(self):
-        self.buf = None          # fp32, persistent (allocated outside any capture)
-        self.need = 0            # elements one step takes (learned from the steps so far)
-        self.off = 0
-        self.ready = False       # this step's views come from `buf` (already cleared)
-        self._prev = None
-
-    def __enter__(self):
-        global _arena
-        self._prev, _arena = _arena, self
-        self.off = 0
-        self.ready = self.buf is not None and self.need > 0 and self.buf.numel() >= self.need
-        if self.ready:
-            check(lib().dvae_zero_f32(ptr(self.buf), self.need, stream()), "dvae_zero_f32")
-        return self
-
-    def __exit__(self, *exc):
-        global _arena
-        _arena = self._prev
-        if self.off > self.need:
-            self.need = self.off
-        if (self.buf is None or self.buf.numel() < self.need) and self.need > 0 and not torch.cuda.is_current_stream_capturing():
-            self.buf = torch.empty(self.need, device=self._dev, dtype=torch.float32)
-        return False
-
-    def take(self, shape, dev):
-        n = 1
-        for d in shape:
-            n *= int(d)
-        n_al = (n + 63) // 64 * 64                       # 256-byte aligned views
-        self._dev = dev
-        o = self.off
-        self.off += n_al
-        if self.ready and self.buf.device == torch.device(dev) and o + n_al <= self.need:
-            return self.buf[o:o + n].view(shape)
-        return None
-
-
-_arena = None
-
-
-def zeros(shape, dev):
-    """fp32 zeros for a launch that accumulates into them atomically: a view of the active ZeroArena (cleared by one launch at
-    the start of the train step), else a tensor of its own cleared by a dvae_zero_f32 launch right here."""
-    if _arena is not None:
-        t = _arena.take(tuple(shape), dev)
-        if t is not None:
-            return t
-    t = torch.empty(shape, device=dev, dtype=torch.float32)
-    check(lib().dvae_zero_f32(ptr(t), t.numel(), stream()), "dvae_zero_f32")
-    return t
 
 
 def linear_fwd(x, w, b, act=ACT_NONE, mode=None, w16=None):
