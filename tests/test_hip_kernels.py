@@ -532,6 +532,23 @@ def test_abi_rejects_bad_arguments_without_crashing():
     assert L.dvae_adam_flat(p, p, p, p, 64, 1e-3, 0.9, 0.999, 1e-8, 1.0, 0, st) == -1                  # step < 1
     assert L.dvae_l1_sum_fwd(p, p + 4, p, p, 64, 1.0, st) == -1                                        # misaligned
     assert L.dvae_mel_to_frames(None, None, p, 4, 80, 64, 0, st) == -1
+    # the slab forms: a split without slabs, a slab stride shorter than one result, misaligned / ragged sums, bad descriptors
+    from dvae_amd._lib import SlabDesc
+    assert L.dvae_gemm_f32_slabs(p, p, p, None, 0, 0, None, 64, 64, 64, 64, 64, 64, 1, 1, 0, 4, -1, st) == -1
+    assert L.dvae_gemm_f32_slabs(p, p, p, p, 64 * 64 - 4, 4, None, 64, 64, 64, 64, 64, 64, 1, 1, 0, 4, -1, st) == -1
+    assert L.dvae_slab_sum(None, p, 64, 2, 64, 0, 0, st) == -1
+    assert L.dvae_slab_sum(p, p + 4, 64, 2, 64, 0, 0, st) == -1                                        # misaligned slab
+    assert L.dvae_slab_sum(p, p, 62, 2, 64, 0, 0, st) == -1                                            # stride % 4
+    assert L.dvae_slab_sum(p, p, 64, 2, 62, 0, 0, st) == -1                                            # n % 4
+    assert L.dvae_slab_sum(p, None, 64, 2, 64, 0, 0, st) == -1                                         # slabs named, none given
+    assert L.dvae_slab_fold(None, 1, st) == -1
+    bad = (SlabDesc * 1)(SlabDesc(p, p, 64, 62, 2, 0))                                                 # n % 4
+    assert L.dvae_slab_fold(bad, 1, st) == -1
+    bad = (SlabDesc * 1)(SlabDesc(p, None, 64, 64, 2, 0))
+    assert L.dvae_slab_fold(bad, 1, st) == -1
+    assert L.dvae_slab_fold(bad, 0, st) == 0                                                           # nothing to fold
+    assert L.dvae_colsum_add_ws(p, p, None, 64, 64, 64, 0, None, st) == -1                             # no workspace
+    assert L.dvae_colsum_add_ws(p, p, None, 64, 64, 62, 0, p, st) == -1                                # ld % 4
     torch.cuda.synchronize()
     assert float(a.abs().sum()) == 0.0
 
