@@ -17,8 +17,10 @@
 // MFMA A-fragment order: 1 KiB per 16 rows x 32 k) into a two-slot exchange ring and then raises its flag:
 //   producer : payload with write-through (sc1) 16-byte stores by ONE wave -> that wave's s_waitcnt vmcnt(0) -> ONE lane
 //              stores flag = frames published (sc1);
-//   consumer : wave w polls (relaxed, sc1 loads, one lane per producer) ONLY the KW producers of its own k-quarter,
-//              then loads their fragments with sc1 loads straight into MFMA operand registers (no LDS staging).
+//   consumer : ONE wave polls the group's flags (relaxed, sc1 loads, one lane per producer), a barrier, then every wave
+//              loads the fragments of its k-quarter with sc1 loads straight into MFMA operand registers (no LDS staging).
+//              (lstm_pers_bwd_bf16 and lstm_pers_fwd_x3h: every wave polls the producers of its OWN k-quarter and goes on
+//              without the barrier — measured faster there and slower in the other kernels, see those two.)
 // This is the "flag" hand-off of MI355X_MICROARCH.md (visibility table, first row): every payload byte stored sc1 and
 // drained before the flag, every load of it sc1, so no acquire fence is needed; nothing depends on placement.
 // Slot reuse is safe with two slots: a workgroup can publish frame t only after it has consumed ALL of frame t-1, which
@@ -177,6 +179,9 @@ constexpr int NWV = 4;
 #endif
 #ifndef PERS_RD_F32
 #define PERS_RD_F32 8
+#endif
+#ifndef PERS_RD_X3H
+#define PERS_RD_X3H 4      // lstm_pers_fwd_x3h: (chunk, row tile) units of h[t-1] in flight, of 8 per wave
 #endif
 #ifndef PERS_PD_FWD2
 #define PERS_PD_FWD2 8      // (lstm_pers_fwd_bf16<1024, 2, 2> spills 5 VGPRs with 8; the spill-free 7 measured SLOWER: 4.68 vs 4.57 us per frame at N = 256)
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   const int slot_bytes = a.n_rb * 4 * NCH * MT * 1024;
   const int xld = (rb * 4 * NCH + wave * KW) * MT * 1024 + lane * 16;     // + g*NCH*MT*1024 per gate
   const int xst = (rb * 4 * NCH + jb) * MT * 1024 + lane * 16;
-  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD + (lane < NCH ? lane : 0) * PERS_FLAG_STRIDE;
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD + (wave * KW + (lane < KW ? lane : 0)) * PERS_FLAG_STRIDE;
   unsigned* myflag = a.flags + rb * PERS_FLAG_LD + jb * PERS_FLAG_STRIDE;
 
   struct Ops {
@@ -543,11 +548,15 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, epoch + (unsigned)step, a.timeout)) {
+      // every wave waits for the KW producers of ITS k-quarter only (one lane each) and goes on alone — no barrier A
+      // (round 6; one polling wave + a barrier: 4.16 -> 3.99 us per frame at H = 1024, N = 128; 3.01 -> 2.87 at H = 512;
+      // 6.27 -> 6.20 at N = 256.  The same change made the forward kernels and both fp32x3 16-unit kernels SLOWER by
+      // 3-7 %, so only this kernel and lstm_pers_fwd_x3h poll per wave).  LDS is safe without the barrier: `red` of the
+      // last frame was read in front of its barrier C; stage / gx are rewritten behind this frame's barrier B only
+      if (!poll_ge(pflag, lane < KW, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
       }
-      __syncthreads();                                             // barrier A
       PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int so = ((step - 1) & 1) * slot_bytes;
@@ -970,6 +979,217 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3(const PersArgs a
         a.c_all[((int64_t)t * N + el_n[i]) * H + j0 + r] = co_[i];
         reinterpret_cast<float*>(a.h_out)[((int64_t)t * N + el_n[i]) * a.ldh + j0 + r] = ho_[i];
       }
+    }
+  }
+  pers_finish(a);
+}
+
+// ======================================================================================================================
+// fp32x3 forward, H = 512 at N <= 128: EIGHT hidden units x 32 rows per workgroup (round 6).
+// The 16-unit kernel above fills 32 x 4 = 128 of the 256 CUs there and each of them spends 192 MFMAs per wave and frame;
+// its 16-ROW form (MT = 1) fills the chip but is the one geometry whose hand-off has failed on some chips (see
+// dvae_pers_launch).  This form halves the COLUMNS instead: 64 x 4 workgroups, 96 MFMAs per wave and frame, and the row
+// groups, flags (64 producers per row group, one poller lane each) and ring (32-row fragments, two slots) are exactly
+// those of the H = 1024 kernel, which has never failed.
+//   column tile tl of the 16x16x32 MFMA = TWO gates x 8 units: columns 0..7 gate 2tl, columns 8..15 gate 2tl+1 (tl 0: i, f;
+//   tl 1: g, o) — a lane permutation of the 16-unit fragment pack (block jb >> 1, lanes q*16 + (jb & 1)*8 + (c & 7)), so the
+//   pack of repack.hip serves both kernels;  all three planes of the slice stay in registers (96 VGPRs);
+//   epilogue: ONE element (row tid / 8, unit tid % 8) per thread; every wave leaves its whole partial tiles in LDS and the
+//   owner adds them in wave order to the pre-activation: one summation order, run-to-run bit-identical;
+//   hand-off: the workgroup's 8 units are a QUARTER of chunk jb / 4 (lanes (jb & 3)*16 + row of its fragments); wave w waits
+//   for the 16 producers of its own four chunks only.
+// Measured (N = 128, T = 128, scripts/lstm_rec_bench.py): 4.43 -> 3.70 us per frame.  In-kernel timeline of a frame (3.52 us,
+// scripts/lstm_pers_timeline.py): own flag -> all awaited flags seen 0.9, fragment loads (96 KiB per CU, sc1) + 96 MFMAs
+// 1.4, barrier B 0.1-0.3, gates 0.4, barrier C 0.04, payload + write-through acknowledgement 0.5: about 2.3 us of it are
+// three fabric round trips (flag, first fragment, acknowledgement) that no tiling shortens.
+// ======================================================================================================================
+struct X3HLds {
+  f32x4 red[NWV][2][2][64];             // every wave's partial tiles [wave][row tile][gate pair][lane]
+  __bf16 hx[3][2][16][8];               // h planes in A-fragment order [plane][row tile][row][8 units]: 16 B per row
+  int dead;
+};
+
+template <int H>
+__global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_x3h(const PersArgs a) {
+  constexpr int NCH = H / 32;           // 32-deep k-chunks of h
+  constexpr int NPR = H / 8;            // producers of a row group
+  constexpr int KW = NCH / NWV;         // chunks per wave
+  constexpr int MT = 2;
+  constexpr int RD = PERS_RD_X3H;
+  static_assert(NPR <= 64, "one poller lane per producer");
+  const int T = a.T, N = a.N;
+  const int bid = blockIdx.x;
+  const int rb = bid % a.n_rb, jb = bid / a.n_rb;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  X3HLds& L = *reinterpret_cast<X3HLds*>(lds_raw);
+  volatile int* dead = &L.dead;
+  if (tid == 0) *dead = 0;
+  const unsigned epoch = pers_epoch(a);
+
+  // resident W_hh fragments of this wave's k-quarter: [gate pair][chunk][plane]
+  bf16x8 W[2][KW][3];
+#pragma unroll
+  for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const int g = tl * 2 + (r >> 3);
+        const int src_lane = q * 16 + (jb & 1) * 8 + (r & 7);
+        W[tl][k][p] = *reinterpret_cast<const bf16x8*>(
+            a.wp + (((((int64_t)(g * (H / 16) + (jb >> 1))) * NCH + wave * KW + k) * 3 + p) * 64 + src_lane) * 16);
+      }
+
+  // this thread's element: row erow of the workgroup's 32, hidden unit j0 + eunit
+  const int erow = tid >> 3, eunit = tid & 7;
+  const bool el_ok = rb * 32 + erow < N;
+  const int el_n = min(rb * 32 + erow, N - 1);
+  const int emt = erow >> 4;
+  const int esrc = ((erow & 15) >> 2) * 16 + eunit, ee = erow & 3;      // its accumulator: lane esrc (+ 8: second gate), register ee
+  float creg = 0.f;
+  const int j0 = jb * 8;
+  const int64_t H4 = 4 * (int64_t)H;
+
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.xch, 0, a.xch_bytes, 0x00020000);
+  const int slot_bytes = a.n_rb * NCH * MT * 3 * 1024;          // fragment (chunk, mt, plane) = 1 KiB
+  const int xld = (rb * NCH + wave * KW) * MT * 3 * 1024 + lane * 16;
+  const int xst = ((rb * NCH + (jb >> 2)) * MT * 3 + (lane >> 4) * 3) * 1024 + ((jb & 3) * 16 + r) * 16;   // lanes 0..31: (row tile, row)
+  const unsigned* pflag = a.flags + rb * PERS_FLAG_LD_X3 + (wave * 4 * KW + (lane & (4 * KW - 1))) * PERS_FLAG_STRIDE;
+  unsigned* myflag = a.flags + rb * PERS_FLAG_LD_X3 + jb * PERS_FLAG_STRIDE;
+
+  auto fetch = [&](int step_, float (&x)[4]) {
+    const int t_ = a.reverse ? (T - 1 - step_) : step_;
+    const float* __restrict__ G_ = a.gates + ((int64_t)t_ * N + el_n) * H4 + j0 + eunit;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) x[g] = G_[g * H];
+  };
+
+  float xn[4];                          // pre-activations of the NEXT frame (fetched under this frame's MFMAs)
+  fetch(0, xn);
+  __syncthreads();
+  for (int step = 0; step < T; ++step) {
+    const int t = a.reverse ? (T - 1 - step) : step;
+    float x[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) x[g] = xn[g];
+    f32x4 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) acc[mt][tl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    PERS_STAMP(0);
+    if (step > 0) {
+      // every wave polls the 4 * KW producers of ITS k-quarter (one lane each) and goes on alone — no barrier A (one polling
+      // wave + a barrier, the 16-unit kernel's form: 3.90 us per frame instead of 3.70).  LDS is safe without it: `red` of the
+      // last frame was read in front of its barrier C, `hx` is rewritten behind this frame's barrier B only
+      if (!poll_ge(pflag, lane < 4 * KW, epoch + (unsigned)step, a.timeout)) {
+        pers_give_up(a.err, 1, bid, step, wave);
+        *dead = 1;
+      }
+      PERS_STAMP(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int so = ((step - 1) & 1) * slot_bytes;
+      // unit u = (chunk k, row tile mt) = three 1-KiB fragments (the planes of h); RD units in flight
+      bf16x8 av[RD][3];
+      auto load = [&](int u) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          av[u % RD][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xld + (u * 3 + p) * 1024, so, 16));
+      };
+#pragma unroll
+      for (int u = 0; u < RD; ++u) load(u);
+      fetch(min(step + 1, T - 1), xn);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < KW * MT; ++u) {
+        const int k = u / MT, mt = u % MT;
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          // the six partial products of weight >= 2^-16: (h plane, W plane)
+          acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W[tl][k][0], acc[mt][tl], 0, 0, 0);
+          acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W[tl][k][1], acc[mt][tl], 0, 0, 0);
+          acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][1], W[tl][k][0], acc[mt][tl], 0, 0, 0);
+          acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][1], W[tl][k][1], acc[mt][tl], 0, 0, 0);
+          acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][0], W[tl][k][2], acc[mt][tl], 0, 0, 0);
+          acc[mt][tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[u % RD][2], W[tl][k][0], acc[mt][tl], 0, 0, 0);
+        }
+        if (u + RD < KW * MT) {
+          __builtin_amdgcn_sched_barrier(0);
+          load(u + RD);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      fetch(min(step + 1, T - 1), xn);
+    }
+    // every wave leaves its partial tiles in LDS (16-byte stores)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) L.red[wave][mt][tl][lane] = acc[mt][tl];
+    PERS_STAMP(2);
+    __syncthreads();                                               // barrier B
+    PERS_STAMP(3);
+    if (*dead) break;
+
+    float gs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float s = x[g];
+#pragma unroll
+      for (int w = 0; w < NWV; ++w)      // wave order: ONE summation order
+        s += reinterpret_cast<const float*>(&L.red[w][emt][g >> 1][esrc + (g & 1) * 8])[ee];
+      gs[g] = s;
+    }
+    const float gi = gate_sigmoid(gs[0]);
+    const float gf = gate_sigmoid(gs[1]);
+    const float gg = gate_tanh(gs[2]);
+    const float go = gate_sigmoid(gs[3]);
+    const float c = gf * creg + gi * gg;
+    const float h = go * gate_tanh(c);
+    creg = c;
+    {
+      // h = h0 + h1 + h2 exactly (two round-to-nearest splits; the last residual is exact in bf16)
+      const __bf16 h0 = (__bf16)h;
+      const float r1 = h - (float)h0;
+      const __bf16 h1 = (__bf16)r1;
+      const __bf16 h2 = (__bf16)(r1 - (float)h1);
+      L.hx[0][emt][erow & 15][eunit] = h0;
+      L.hx[1][emt][erow & 15][eunit] = h1;
+      L.hx[2][emt][erow & 15][eunit] = h2;
+    }
+    PERS_STAMP(4);
+    __syncthreads();                                               // barrier C
+    PERS_STAMP(5);
+    if (wave == 0) {
+      if ((step + 1 < T) && (bid != a.drop_bid)) {
+        const int so = (step & 1) * slot_bytes;
+        if (lane < 32) {                // lane (row tile, row r): its 8 units of the three planes
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&L.hx[p][lane >> 4][r][0]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + p * 1024, so, 16);
+          }
+        }
+        PERS_DRAIN();
+        PERS_STAMP(6);
+        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // the frame's outputs (activated gates, c, h), after the hand-off has left
+    if (el_ok) {
+      float* gp = a.gates + ((int64_t)t * N + el_n) * H4 + j0 + eunit;
+      gp[0] = gi;
+      gp[H] = gf;
+      gp[2 * H] = gg;
+      gp[3 * H] = go;
+      a.c_all[((int64_t)t * N + el_n) * H + j0 + eunit] = c;
+      reinterpret_cast<float*>(a.h_out)[((int64_t)t * N + el_n) * a.ldh + j0 + eunit] = h;
     }
   }
   pers_finish(a);
@@ -2168,7 +2388,8 @@ int pers_go(K kern, int need_lds, const PersArgs& a, int grid, hipStream_t s) {
   return dvae_check_launch();
 }
 
-// kind: 0 bf16 forward, 1 bf16 backward, 2 fp32x3 forward, 3 fp32 backward, 4 fp32x3 backward, 5 fp32x3 backward (k-split)
+// kind: 0 bf16 forward, 1 bf16 backward, 2 fp32x3 forward, 3 fp32 backward, 4 fp32x3 backward, 5 fp32x3 backward (k-split),
+// 6 fp32x3 forward with 8 units per workgroup
 int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStream_t s) {
   constexpr int KL = PERS_KL;
   switch (kind) {
@@ -2195,6 +2416,8 @@ int pers_dispatch(int kind, int H, int mt, const PersArgs& a, int grid, hipStrea
 #endif
       if (mt == 1) return DVAE_EINVAL;
       return pers_go(lstm_pers_fwd_x3<512, 0>, (int)sizeof(X3Lds<4, 0>), a, grid, s);
+    case 6:      // fp32x3 forward, 8 units x 32 rows (H = 512)
+      return pers_go(lstm_pers_fwd_x3h<512>, (int)sizeof(X3HLds), a, grid, s);
     case 3:
       if (H == 1024) return pers_go(lstm_pers_bwd_f32<1024, 8>, (int)sizeof(F32BwdLds<8>), a, grid, s);
       return pers_go(lstm_pers_bwd_f32<512, 0>, (int)sizeof(F32BwdLds<0>), a, grid, s);
@@ -2268,6 +2491,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   const int cus = pers_cu_count();
   if (!d.pers_ws || !d.w_packed || (((uintptr_t)d.pers_ws) & 255)) return DVAE_EINVAL;
   int kind, mt = 2;
+  bool units8 = false;
   if (d.packed_mode == DVAE_MODE_BF16) {
     mt = pers_mt(N, H, cus);
     if (!mt) return DVAE_EINVAL;
@@ -2298,6 +2522,13 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
     if ((kind == 2 ? (mt1 & 1) : (mt1 & 2)) && (kind == 2 || kind == 4) && H == 512 &&
         (H / 16) * ((N + 31) / 32) * 2 <= cus && n_rb16 <= 8 && (H / 16) * n_rb16 <= cus)
       mt = 1;
+    // forward at H = 512: 8 units x 32 rows per workgroup (lstm_pers_fwd_x3h) where that fits the chip — 64 x 4 workgroups at
+    // N = 128 instead of 32 x 4; DVAE_PERS_X3_H8=0 (dev build) keeps the 16-unit kernel
+    static const int h8 = dvae_dev_knob("DVAE_PERS_X3_H8", 1);
+    if (kind == 2 && h8 && mt == 2 && H == 512 && (H / 8) * ((N + 31) / 32) <= cus) units8 = true;
+#ifdef DVAE_DEV      // the diagnostics and the sentinel form exist for the 16-unit kernel only
+    if (g_pers_dbg || g_pers_nslot > 2 || dvae_dev_knob("DVAE_PERS_SENT", 0)) units8 = false;
+#endif
   }
   PersArgs a{};
   a.gates = d.gates; a.wp = (const char*)d.w_packed; a.h_out = (char*)d.h_out; a.c_all = d.c_all;
@@ -2329,7 +2560,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   a.ts = g_pers_ts;
   a.ts_bid = g_pers_ts_bid;
 #endif
-  const int grid = (kind < 2 ? H / 32 : H / 16) * a.n_rb;
+  const int grid = (kind < 2 ? H / 32 : units8 ? H / 8 : H / 16) * a.n_rb;
   const size_t flag_bytes = kind == 5 ? (size_t)PERS_FLAG_BYTES      // + the partial flags behind the dG flags
                                       : (size_t)a.n_rb * (kind < 2 ? PERS_FLAG_LD : PERS_FLAG_LD_X3) * 4;
 #ifdef DVAE_DEV
@@ -2350,7 +2581,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
 #endif
   // (no clearing launch: the flags carry the epoch of their launch, see pers_epoch)
   (void)flag_bytes;
-  return pers_dispatch(kind, H, mt, a, grid, s);
+  return pers_dispatch(units8 ? 6 : kind, H, mt, a, grid, s);
 }
 
 DVAE_API const unsigned* dvae_lstm_pers_err_word(void* ws) {

@@ -118,7 +118,9 @@ def test_persistent_matches_frame_kernels(env, H, T, N, s16, reverse):
 
 
 @pytest.mark.parametrize("H,T,N,reverse", [(1024, 8, 128, 0), (512, 6, 128, 0), (1024, 5, 40, 1), (512, 1, 128, 0),
-                                            (1024, 3, 17, 0)])
+                                            (1024, 3, 17, 0),
+                                            # H = 512 forward: lstm_pers_fwd_x3h (8 units x 32 rows), ragged row groups too
+                                            (512, 5, 40, 1), (512, 3, 17, 0), (512, 7, 97, 1)])
 def test_persistent_fp32x3_forward_fp32_backward_match_frame_kernels(env, H, T, N, reverse):
     """The default arithmetic: the forward recurrence on three resident bf16 planes of W_hh (h handed over as three
     planes, fp32 results); the backward one on three resident planes too (dG handed over in fp32, split by the consumer)
@@ -231,7 +233,7 @@ def test_fp32x3_handoffs_under_uneven_load(env, H, T, N):
 
 
 @pytest.mark.parametrize("mode,H,T,N", [("fp32x3", 1024, 64, 128),     # forward lstm_pers_fwd_x3<1024,8,2>, backward lstm_pers_bwd_x3k<1024>
-                                         ("fp32x3", 512, 64, 128),      # forward lstm_pers_fwd_x3<512,0,2>, backward lstm_pers_bwd_x3<512,0,1> (16 rows)
+                                         ("fp32x3", 512, 64, 128),      # forward lstm_pers_fwd_x3h<512> (8 units x 32 rows), backward lstm_pers_bwd_x3<512,0,1> (16 rows)
                                          ("bf16", 1024, 48, 256),       # lstm_pers_fwd/bwd_bf16<1024,2,2>: configs[2]
                                          ("bf16", 1024, 48, 128),       # lstm_pers_fwd/bwd_bf16<1024,1,0>: configs[4]'s per-GPU shape
                                          ("bf16", 512, 48, 128)])       # lstm_pers_fwd/bwd_bf16<512,1,0>
