@@ -865,12 +865,34 @@ DVAE_API int dvae_colsum_add(const void* X, float* out1, float* out2, int R, int
 // k-split without atomics (round 6): the partial products a contraction stored into slabs (dvae_gemm_f32_slabs ...) are
 // added to the result in the FIXED order ks = 1, 2, ...: every element has one writer and one summation order, so the
 // result is run-to-run bit-identical.  HBM-bound: (nslab + 2) * 4 bytes per element.
+// v + slab 0 + slab 1 + ... in THAT order; eight 16-byte loads in flight per thread (the trip count is a run-time value: without
+// the explicit window the loads of a thread go out one behind the other)
+__device__ __forceinline__ f32x4 slab_add(f32x4 v, const float* __restrict__ p, int64_t stride, int nslab) {
+  int k = 0;
+  for (; k + 8 <= nslab; k += 8) {
+    f32x4 w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + j) * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += w[j];
+  }
+  if (k + 4 <= nslab) {
+    f32x4 w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + j) * stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v += w[j];
+    k += 4;
+  }
+  for (; k < nslab; ++k) v += *reinterpret_cast<const f32x4*>(p + (int64_t)k * stride);
+  return v;
+}
 __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ C, const float* __restrict__ slab, int64_t stride,
                                                        int nslab, int64_t n4, int act, int accumulate) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (accumulate) v = *reinterpret_cast<const f32x4*>(C + 4 * i);
-    for (int k = 0; k < nslab; ++k) v += *reinterpret_cast<const f32x4*>(slab + (int64_t)k * stride + 4 * i);
+    v = slab_add(v, slab + 4 * i, stride, nslab);
     if (act != DVAE_ACT_NONE) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], act);
@@ -900,7 +922,7 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(const SlabTable t) {
   const int64_t n4 = d.n >> 2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
     f32x4 v = *reinterpret_cast<const f32x4*>(d.c + 4 * i);
-    for (int k = 0; k < d.nslab; ++k) v += *reinterpret_cast<const f32x4*>(d.slab + (int64_t)k * d.slab_stride + 4 * i);
+    v = slab_add(v, d.slab + 4 * i, d.slab_stride, d.nslab);
     *reinterpret_cast<f32x4*>(d.c + 4 * i) = v;
   }
 }

@@ -1170,6 +1170,7 @@ int fill_args(StepArgs& a, const dvae_lstm_dir_t* dirs, int ndir, int T, int N, 
 // lstm_pers.hip: the W_hh-resident persistent recurrence (one launch per sequence)
 int dvae_pers_usable(int N, int H, int pm, int bwd);
 int dvae_pers_bwd_ksplit(int H);
+int dvae_pers_fwd_units(int N, int H);
 int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, int64_t ldh, int drop_bid, hipStream_t s);
 
 namespace {
@@ -1202,7 +1203,7 @@ double lstm_bytes(bool bwd, bool pers, const StepArgs& a, const SeqPlan& p, int 
       const double wgs = (H / 16) * ((a.N + 31) / 32);
       // forward: 16 units x 32 rows per workgroup, h[t-1] as three bf16 planes; backward: dG[t+1] in fp32 — all of K = 4H per
       // workgroup, or (k-split kernel) a quarter of it plus the three 32 x 16 partial tiles a workgroup receives
-      if (!bwd) return (double)p.frames * wgs * 32.0 * K * 6.0;
+      if (!bwd) return (double)p.frames * wgs * (16.0 / dvae_pers_fwd_units(a.N, a.H)) * 32.0 * K * 6.0;   // (8-unit kernel: twice the workgroups)
       if (dvae_pers_bwd_ksplit(a.H)) return (double)p.frames * wgs * (32.0 * (K / 4.0) * 4.0 + 3.0 * 2048.0);
       return (double)p.frames * wgs * 32.0 * K * 4.0;
     }

@@ -2460,6 +2460,13 @@ int dvae_pers_bwd_ksplit(int H) {
   return ((H == 1024 && (ksplit & 1)) || (H == 512 && (ksplit & 2))) ? 1 : 0;
 }
 
+// fp32x3 forward: hidden units per workgroup — 8 (lstm_pers_fwd_x3h) at H = 512 where 64 workgroups per row group fit the chip,
+// else 16 (lstm_pers_fwd_x3).  Also read by lstm.hip's byte accounting.
+int dvae_pers_fwd_units(int N, int H) {
+  static const int h8 = dvae_dev_knob("DVAE_PERS_X3_H8", 1);
+  return (h8 && H == 512 && (H / 8) * ((N + 31) / 32) <= pers_cu_count()) ? 8 : 16;
+}
+
 // used by lstm.hip: 1 when (N, H, mode, pass) has a persistent kernel on this device
 int dvae_pers_usable(int N, int H, int pm, int bwd) {
   if (pm == DVAE_MODE_F32X3) return pers_x3_ok(N, H, pers_cu_count());      // forward, and backward with consumer-side split
@@ -2524,8 +2531,7 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
       mt = 1;
     // forward at H = 512: 8 units x 32 rows per workgroup (lstm_pers_fwd_x3h) where that fits the chip — 64 x 4 workgroups at
     // N = 128 instead of 32 x 4; DVAE_PERS_X3_H8=0 (dev build) keeps the 16-unit kernel
-    static const int h8 = dvae_dev_knob("DVAE_PERS_X3_H8", 1);
-    if (kind == 2 && h8 && mt == 2 && H == 512 && (H / 8) * ((N + 31) / 32) <= cus) units8 = true;
+    if (kind == 2 && mt == 2 && dvae_pers_fwd_units(N, H) == 8) units8 = true;
 #ifdef DVAE_DEV      // the diagnostics and the sentinel form exist for the 16-unit kernel only
     if (g_pers_dbg || g_pers_nslot > 2 || dvae_dev_knob("DVAE_PERS_SENT", 0)) units8 = false;
 #endif
