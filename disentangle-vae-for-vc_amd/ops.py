@@ -991,7 +991,11 @@ class LstmLayerFn(torch.autograd.Function):
             if cat is not None:
                 # both directions' data gradients are ONE contraction over K = 8H
                 gemm(dgall, cat.w_ih_t, dx, None, R, In, ldg, ldg, ldg, In, True, True, ACT_NONE, EPI_STORE, mode=mode)
-            for d in range(ndir if cat is None else 0):
+            # a narrow input (dec_lstm1: In = 128, so R / 128 output tiles fill half the chip) is cut along K = 4H into slabs
+            sk = _split_k(_tiles(R, In), 4 * H) if (ndir == 1 and cat is None and (R * In) % 4 == 0) else 1
+            if sk > 1:
+                gemm_split(dgs[0], der[0].w_ih_t, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE, sk, mode)
+            for d in range(ndir if (cat is None and sk == 1) else 0):
                 # dx = dgates @ W_ih contracts over 4H: against W_ih^T both operands are k-contiguous
                 gemm(dgs[d], der[d].w_ih_t, dx, None, R, In, 4 * H, 4 * H, 4 * H, In, True, True, ACT_NONE,
                      EPI_STORE if d == 0 else EPI_ACCUM, mode=mode)
