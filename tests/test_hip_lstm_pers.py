@@ -380,6 +380,36 @@ def test_bounded_spin_gives_up_and_reports(env):
     compare(got, ref, "after a timed-out launch")
 
 
+@pytest.mark.parametrize("H,drop", [(512, 3), (512, 200), (1024, 77)])
+def test_fp32x3_forward_gives_up_on_a_silent_producer(env, H, drop):
+    """The same for the default arithmetic's forward kernels (H = 512: lstm_pers_fwd_x3h, every wave polls its own producers —
+    each wave's give-up must end the whole workgroup; H = 1024: lstm_pers_fwd_x3): workgroup `drop` never publishes."""
+    _lib, ops, lstm_local = env
+    L, st, ptr = _lib.lib(), _lib.stream(), _lib.ptr
+    T, N, X3 = 12, 128, _lib.MODE_F32X3
+    ref = _x3_pass(env, H, T, N, False, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(1005)
+    f = dict(device="cuda", dtype=torch.float32)
+    w_hh = (torch.rand(4 * H, H, generator=g, **f) * 2 - 1) / H ** 0.5
+    der = lstm_local(torch.zeros(4 * H, 64, **f), w_hh, torch.zeros(4 * H, **f), torch.zeros(4 * H, **f), X3)
+    gates = torch.rand(T * N, 4 * H, generator=g, **f) * 2 - 1
+    h, c = torch.zeros(T * N, H, **f), torch.zeros(T * N, H, **f)
+    d = (_lib.LstmDir * 1)()
+    d[0].gates, d[0].c_all, d[0].h_out, d[0].w_hh, d[0].w_packed = ptr(gates), ptr(c), ptr(h), ptr(w_hh), ptr(der.pack_f)
+    d[0].packed_mode, d[0].pers_ws, d[0].pers_timeout_us = X3, ptr(ops.lstm_pers_workspace("cuda")), 20000
+    torch.cuda.synchronize()
+    t0 = time.time()
+    _lib.check(L.dvae_lstm_pers_selftest(d, T, N, H, H, drop, st), "selftest")
+    with pytest.raises(_lib.DvaeHipError, match="gave up"):
+        ops.lstm_pers_check()
+    assert time.time() - t0 < 5.0
+    ops.lstm_pers_check()                   # the record is cleared once reported
+    got = _x3_pass(env, H, T, N, True, seed=5)      # the next launches on the workspace are clean
+    for name, a, b in zip(("gates", "c", "h", "dgates"), got, ref):
+        err = float((a - b).abs().max())
+        assert err <= 2e-5 * float(b.abs().max()), f"{name} after a timed-out launch: {err:.3e}"
+
+
 def test_workspace_size_contract(env):
     _lib, ops, _ = env
     L = _lib.lib()
