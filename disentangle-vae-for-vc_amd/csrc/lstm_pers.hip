@@ -74,6 +74,8 @@ struct PersArgs {
   unsigned timeout;      // 100 MHz ticks
   int xch_bytes;
   int drop_bid;          // self-test: this workgroup never publishes (-1: none)
+  int local_ok;          // 1: the geometry keeps every row group on ONE XCD when workgroups are dealt round-robin (n_rb % 8 == 0): the
+                         // workgroups check that at frame 1 and then keep payload and flags in that XCD's L2 (pers_loc_*)
 #ifdef DVAE_PERS_TS
   unsigned long long* ts;   // dev build: [frame][wave][8] s_memrealtime stamps of workgroup ts_bid (scripts/lstm_pers_timeline.py)
   int ts_bid;
@@ -100,6 +102,59 @@ struct PersArgs {
 #define PERS_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
 
+// ======================================================================================================================
+// XCD-LOCAL hand-off (round 6).  The write-through (sc1) stores of the flag protocol drop their lines from the XCD's L2, so every
+// consumer — also one on the producer's XCD — reads flags and fragments at the fabric's latency (MI355X_MICROARCH.md, "stores of
+// each flavour").  Where ALL workgroups of a row group sit on ONE XCD, that XCD's L2 is their single point of coherence: plain
+// payload stores + `s_waitcnt vmcnt(0)` (acknowledged by the L2) + a workgroup-scope flag store keep the lines there, and the
+// consumers' sc1 loads (which bypass the L1 only) hit them: bf16 H = 1024, N = 128: forward 3.24 -> 2.72 us per frame, backward
+// 4.03 -> 3.30; H = 512: 2.58 -> 2.19 / 2.97 -> 2.26; fp32x3 H = 512 backward 4.62 -> 3.90 (scripts/local_probe.sh).
+// Placement is not promised by HIP, so nothing is assumed:
+//   * geometry: workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one), rb = bid % n_rb: with
+//     n_rb % 8 == 0 a row group's members all have the same bid % 8 (host: PersArgs.local_ok);
+//   * check: with its FIRST publish (always write-through) a workgroup announces {epoch, XCC_ID} in its flag's line; at frame 1
+//     every poller lane compares its producer's announcement with its own XCC_ID.  Every member of a row group evaluates the same
+//     predicate over the same announcements, so they agree; any mismatch (or a stale announcement) = write-through as before;
+//   * the last two publishes of a launch (one per ring slot) and the last flag store are write-through again, and a workgroup that
+//     leaves through a give-up writes its lines through once more: no line of the ring or of a flag stays behind in an L2 for a
+//     later launch, whose geometry and placement may differ, to hit.
+// ======================================================================================================================
+__device__ __forceinline__ unsigned pers_xcc() {
+  unsigned x;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+  return x & 0xfu;
+}
+__device__ __forceinline__ unsigned long long pers_loc_tag(unsigned epoch, unsigned xcc) {
+  return ((unsigned long long)epoch << 8) | 0x80u | xcc;      // (0x80: never equal to a word nobody wrote)
+}
+// the publishing lane, in front of the drain of its first payload: words 2..3 of the flag's own 128-byte line
+__device__ __forceinline__ void pers_loc_announce(unsigned* myflag, unsigned long long tag) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(myflag + 2), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// poller lanes (one per awaited producer), after their flags have matched: does every one of them sit on this XCD?
+__device__ __forceinline__ bool pers_loc_check(const unsigned* pflag, bool active, unsigned long long tag) {
+  const unsigned long long e =
+      active ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(pflag + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+  return __all(e == tag);
+}
+// publish step `s` of T (frames 0 .. T-2 publish): in the L2 only between the check and the last two publishes
+__device__ __forceinline__ bool pers_loc_step(bool loc, int step, int T) { return loc && step >= 1 && step + 4 <= T; }
+#define PERS_ST(lp_, v_, rs_, voff_, soff_)                                                \
+  do {                                                                                     \
+    if (lp_) __builtin_amdgcn_raw_buffer_store_b128(v_, rs_, voff_, soff_, 0);             \
+    else __builtin_amdgcn_raw_buffer_store_b128(v_, rs_, voff_, soff_, 16);                \
+  } while (0)
+#define PERS_FLAG(lp_, p_, val_)                                                                         \
+  do {                                                                                                   \
+    if (lp_) __hip_atomic_store(p_, val_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);               \
+    else __hip_atomic_store(p_, val_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                       \
+  } while (0)
+// a workgroup that leaves through a give-up: its flag's line once more with a write-through store (the payload pieces: caller)
+__device__ __forceinline__ void pers_loc_scrub_flag(unsigned* myflag) {
+  const unsigned v = __hip_atomic_load(myflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(myflag, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // wave-level bounded poll: lanes with `active` re-read their word until every one of them has reached `target`
 // (flags count frames over ALL launches — see pers_epoch — and never wrap)
 __device__ __forceinline__ bool poll_ge(const unsigned* p, bool active, unsigned target, unsigned timeout) {
@@ -120,6 +175,7 @@ __device__ __forceinline__ bool poll_ge(const unsigned* p, bool active, unsigned
 // when workgroup 0 is done.  Whatever an earlier launch left in a flag is below the epoch of every later launch.  No wrap:
 // once the epoch has passed 2^30 the last workgroup — nobody else is left — zeroes every flag and starts again from 0.
 constexpr int PERS_EPOCH_WORD = 8, PERS_DONE_WORD = 9;
+constexpr int PERS_LOCAL_WORD = 10;      // statistics: launches whose workgroup 0 went XCD-local (pers_loc_*); read by tests / the selftest
 constexpr unsigned PERS_EPOCH_MAX = 1u << 30;
 __device__ __forceinline__ unsigned pers_epoch(const PersArgs& a) {
   return __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.err + PERS_EPOCH_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -236,6 +292,7 @@ struct FwdLds {
                                          // (+4: rows 4 apart — the q groups of a wave — land in different banks)
   __bf16 hx[MT][16][40];                 // h in A-fragment order (32 units + pad per row)
   int dead;
+  int loc;                               // pers_loc_check's verdict (frame 1)
 };
 
 template <int H, int MT, int KL>
@@ -257,8 +314,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   FwdLds<MT, KL>& L = *reinterpret_cast<FwdLds<MT, KL>*>(lds_raw);
   volatile int* dead = &L.dead;
-  if (tid == 0) *dead = 0;
+  if (tid == 0) { *dead = 0; L.loc = 0; }
   const unsigned epoch = pers_epoch(a);
+  const unsigned long long loc_tag = pers_loc_tag(epoch, pers_xcc());
+  bool loc = false;                     // XCD-local hand-off from frame 1 on (pers_loc_*)
 
   // resident W_hh fragments: gate g, 16-unit tile u, chunk k of this wave's k-quarter
   bf16x8 W[4][2][KR];
@@ -315,11 +374,20 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NCH, epoch + (unsigned)step, a.timeout)) {
-        pers_give_up(a.err, 1, bid, step, wave);
-        *dead = 1;
+      if (wave == NWV - 1) {
+        if (!poll_ge(pflag, lane < NCH, epoch + (unsigned)step, a.timeout)) {
+          pers_give_up(a.err, 1, bid, step, wave);
+          *dead = 1;
+        } else if (a.local_ok && step == 1) {
+          const bool ok = pers_loc_check(pflag, lane < NCH, loc_tag);
+          if (lane == 0) L.loc = ok;
+        }
       }
       __syncthreads();                                             // barrier A
+      if (a.local_ok && step == 1) {
+        loc = L.loc != 0;
+        if (loc && bid == 0 && tid == 0) atomicAdd(a.err + PERS_LOCAL_WORD, 1u);
+      }
       PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");      // no instruction: keeps the loads below the poll
       const int so = ((step - 1) & 1) * slot_bytes;
@@ -401,14 +469,16 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
     if (wave == 0) {
       if ((step + 1 < T) && (bid != a.drop_bid)) {
         const int so = (step & 1) * slot_bytes;
+        const bool lp = pers_loc_step(loc, step, T);
+        if (a.local_ok && step == 0 && lane == 0) pers_loc_announce(myflag, loc_tag);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const f32x4 v = *reinterpret_cast<const f32x4*>(&L.hx[mt][r][q * 8]);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + mt * 1024, so, 16);
+          PERS_ST(lp, __builtin_bit_cast(u32x4v, v), xrs, xst + mt * 1024, so);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the write-through payload has left before the flag does
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the payload has left (write-through) / reached the L2 (local) before the flag does
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) PERS_FLAG(lp, myflag, epoch + (unsigned)(step + 1));
       }
     } else if (wave == 1 && s16) {
 #pragma unroll
@@ -445,6 +515,14 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_fwd_bf16(const PersArgs
     if (!frame(step, xa, xb)) break;
     if (step + 1 < T && !frame(step + 1, xb, xa)) break;
   }
+  if (loc && *dead && wave == 0) {      // gave up with lines in the L2: both slots' pieces and the flag once more, write-through
+    const u32x4v z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) __builtin_amdgcn_raw_buffer_store_b128(z, xrs, xst + mt * 1024, sl * slot_bytes, 16);
+    if (lane == 0) pers_loc_scrub_flag(myflag);
+  }
   pers_finish(a);
 }
 
@@ -459,6 +537,7 @@ struct BwdLds {
   __bf16 gx[4 * MT][16][40];             // dG in A-fragment order [(g, mt)][row][32 units + pad]
   float bsum[4][32];                     // bias gradient of this workgroup's 128 gate columns (summed at the end)
   int dead;
+  int loc4[4];                           // pers_loc_check's verdict per wave (frame 1)
 };
 
 template <int H, int MT, int KL>
@@ -482,7 +561,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   BwdLds<MT, KL>& L = *reinterpret_cast<BwdLds<MT, KL>*>(lds_raw);
   volatile int* dead = &L.dead;
   if (tid == 0) *dead = 0;
+  if (tid < 4) L.loc4[tid] = 0;
   const unsigned epoch = pers_epoch(a);
+  const unsigned long long loc_tag = pers_loc_tag(epoch, pers_xcc());
+  bool loc = false;                     // XCD-local hand-off from frame 1 on (pers_loc_*)
   if (tid < 128) L.bsum[tid >> 5][tid & 31] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's share of the bias gradient: its elements' dG over all frames
 
@@ -556,6 +638,9 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
       if (!poll_ge(pflag, lane < KW, epoch + (unsigned)step, a.timeout)) {
         pers_give_up(a.err, 2, bid, step, wave);
         *dead = 1;
+      } else if (a.local_ok && step == 1) {      // this wave's producers; the four verdicts meet behind barrier B
+        const bool ok = pers_loc_check(pflag, lane < KW, loc_tag);
+        if (lane == 0) L.loc4[wave] = ok;
       }
       PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -600,6 +685,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
     __syncthreads();                                               // barrier B
     PERS_STAMP(3);
     if (*dead) return false;
+    if (a.local_ok && step == 1) {
+      loc = (L.loc4[0] & L.loc4[1] & L.loc4[2] & L.loc4[3]) != 0;
+      if (loc && bid == 0 && tid == 0) atomicAdd(a.err + PERS_LOCAL_WORD, 1u);
+    }
 
     {
       const int ti = emt * 2 + eu;
@@ -641,16 +730,18 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
     if (wave == 0) {
       if ((step + 1 < T) && (bid != a.drop_bid)) {
         const int so = (step & 1) * slot_bytes;
+        const bool lp = pers_loc_step(loc, step, T);
+        if (a.local_ok && step == 0 && lane == 0) pers_loc_announce(myflag, loc_tag);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(&L.gx[g * MT + mt][r][q * 8]);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst + (g * NCH * MT + mt) * 1024, so, 16);
+            PERS_ST(lp, __builtin_bit_cast(u32x4v, v), xrs, xst + (g * NCH * MT + mt) * 1024, so);
           }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) PERS_FLAG(lp, myflag, epoch + (unsigned)(step + 1));
       }
     } else if (s16) {
       // waves 1..3 archive dG[t] (bf16, whole 64-byte row pieces) for the weight-gradient / dx contractions
@@ -687,6 +778,17 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_bf16(const PersArgs
   for (int step = 0; step < T; step += 2) {
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
+  }
+  if (loc && *dead && wave == 0) {      // gave up with lines in the L2: both slots' pieces and the flag once more, write-through
+    const u32x4v z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          __builtin_amdgcn_raw_buffer_store_b128(z, xrs, xst + (g * NCH * MT + mt) * 1024, sl * slot_bytes, 16);
+    if (lane == 0) pers_loc_scrub_flag(myflag);
   }
   // db_ih = db_hh = sum over frames and rows of dG (replaces a colsum pass over [T*N, 4H])
   pers_bias_out<32>(a, lds_raw, bs, eunit, rb, j0, H);
@@ -1768,6 +1870,7 @@ struct X3BwdLds {
   float gx[4 * MT][16][20];              // dG[t] (fp32) [(g, mt)][row][16 units + pad]
   float bsum[4][16];
   int dead;
+  int loc;                               // pers_loc_check's verdict (frame 1)
 };
 
 template <int H, int K2L, int MT = 2>      // MT: see lstm_pers_fwd_x3
@@ -1789,8 +1892,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   X3BwdLds<K2L, MT>& L = *reinterpret_cast<X3BwdLds<K2L, MT>*>(lds_raw);
   volatile int* dead = &L.dead;
-  if (tid == 0) *dead = 0;
+  if (tid == 0) { *dead = 0; L.loc = 0; }
   const unsigned epoch = pers_epoch(a);
+  const unsigned long long loc_tag = pers_loc_tag(epoch, pers_xcc());
+  bool loc = false;                     // XCD-local hand-off from frame 1 on (pers_loc_*)
   if (tid < 64) L.bsum[tid >> 4][tid & 15] = 0.f;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -1856,11 +1961,20 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
 
     PERS_STAMP(0);
     if (step > 0) {
-      if (wave == NWV - 1 && !poll_ge(pflag, lane < NPR, epoch + (unsigned)step, a.timeout)) {
-        pers_give_up(a.err, 2, bid, step, wave);
-        *dead = 1;
+      if (wave == NWV - 1) {
+        if (!poll_ge(pflag, lane < NPR, epoch + (unsigned)step, a.timeout)) {
+          pers_give_up(a.err, 2, bid, step, wave);
+          *dead = 1;
+        } else if (a.local_ok && step == 1) {
+          const bool ok = pers_loc_check(pflag, lane < NPR, loc_tag);
+          if (lane == 0) L.loc = ok;
+        }
       }
       __syncthreads();                                             // barrier A
+      if (a.local_ok && step == 1) {
+        loc = L.loc != 0;
+        if (loc && bid == 0 && tid == 0) atomicAdd(a.err + PERS_LOCAL_WORD, 1u);
+      }
       PERS_STAMP(1);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int so = ((step - 1) & 1) * slot_bytes;
@@ -1955,6 +2069,8 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
     if (wave == 0) {
       if ((step + 1 < T) && (bid != a.drop_bid)) {
         const int so = (step & 1) * slot_bytes;
+        const bool lp = pers_loc_step(loc, step, T);
+        if (a.local_ok && step == 0 && lane == 0) pers_loc_announce(myflag, loc_tag);
         if (lane < 32) {               // lane (r, q' in {0,1}): units 8q' + 4h .. + 3 of row r go to half h
 #pragma unroll
           for (int g = 0; g < 4; ++g)
@@ -1963,13 +2079,12 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
 #pragma unroll
               for (int h = 0; h < 2; ++h) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(&L.gx[g * MT + mt][r][(q & 1) * 8 + 4 * h]);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), xrs, xst,
-                                                       so + ((g * NCH * MT) + mt) * 2048 + h * 1024, 16);
+                PERS_ST(lp, __builtin_bit_cast(u32x4v, v), xrs, xst, so + ((g * NCH * MT) + mt) * 2048 + h * 1024);
               }
         }
         PERS_DRAIN();
         PERS_STAMP(6);
-        if (lane == 0) __hip_atomic_store(myflag, epoch + (unsigned)(step + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) PERS_FLAG(lp, myflag, epoch + (unsigned)(step + 1));
       }
     } else {
       for (int f = wave - 1; f < 4 * MT; f += NWV - 1) {
@@ -1994,6 +2109,21 @@ __global__ __launch_bounds__(64 * NWV, 1) void lstm_pers_bwd_x3(const PersArgs a
   for (int step = 0; step < T; step += 2) {
     if (!frame(step, oa, ob)) break;
     if (step + 1 < T && !frame(step + 1, ob, oa)) break;
+  }
+  if (loc && *dead && wave == 0) {      // gave up with lines in the L2: both slots' pieces and the flag once more, write-through
+    const u32x4v z = {0u, 0u, 0u, 0u};
+    if (lane < 32) {
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              __builtin_amdgcn_raw_buffer_store_b128(z, xrs, xst, sl * slot_bytes + ((g * NCH * MT) + mt) * 2048 + h * 1024, 16);
+    }
+    if (lane == 0) pers_loc_scrub_flag(myflag);
   }
   pers_bias_out<16>(a, lds_raw, bs, r, rb, j0, H);
   pers_finish(a);
@@ -2559,6 +2689,10 @@ int dvae_pers_launch(const dvae_lstm_dir_t& d, bool bwd, int T, int N, int H, in
   }
 #endif
   a.drop_bid = drop_bid;
+  // XCD-local hand-off (pers_loc_*): the kernels that have it, where a row group's workgroups share bid % 8; the workgroups
+  // verify their placement at frame 1.  DVAE_PERS_XCD_LOCAL=0 in the environment keeps every hand-off write-through.
+  static const bool loc_env = []() { const char* e = getenv("DVAE_PERS_XCD_LOCAL"); return !(e && e[0] == '0'); }();
+  a.local_ok = (loc_env && (kind == 0 || kind == 1 || (kind == 4 && !units8)) && (a.n_rb % 8) == 0) ? 1 : 0;
 #ifdef DVAE_DEV
   a.nodrain = dvae_dev_knob("DVAE_PERS_NODRAIN", 0);
 #endif

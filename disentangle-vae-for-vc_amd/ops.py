@@ -798,6 +798,15 @@ def lstm_pers_workspace(dev) -> torch.Tensor:
     return ws
 
 
+def lstm_pers_local_launches(dev="cuda") -> int:
+    """Statistics word of the workspace: the persistent launches so far whose cross-workgroup hand-offs stayed in their XCD's
+    L2 (csrc/lstm_pers.hip pers_loc_*: geometries with a multiple of 8 row groups, after the workgroups have verified at frame 1
+    that each row group shares one XCD; DVAE_PERS_XCD_LOCAL=0 switches the form off).  Synchronises the device."""
+    ws = lstm_pers_workspace(dev)
+    torch.cuda.synchronize(ws.device)
+    return int(ws[65536 + 40:65536 + 44].view(torch.int32).item())      # PERS_ERR_OFF + 4 * PERS_LOCAL_WORD
+
+
 def _pers_claim(dev):
     """ONE persistent launch at a time per device: a launch owns every CU and the device's one workspace (flags, exchange
     ring).  Launches of one stream are ordered by the stream; a DIFFERENT stream may take over only when the previous

@@ -15,6 +15,7 @@ import argparse
 import glob
 import sys
 
+import os
 import torch
 
 
@@ -126,6 +127,11 @@ def run(rounds: int = 200, log=print) -> int:
             bad += case_bad
     finally:
         ops.set_compute_dtype(prev)      # leave the compute mode as it was found, whatever happened
+    try:
+        log(f"XCD-local hand-offs (row groups on one XCD, verified per launch): {ops.lstm_pers_local_launches()} launches so far"
+            + (" — switched off (DVAE_PERS_XCD_LOCAL=0)" if os.environ.get("DVAE_PERS_XCD_LOCAL", "1")[:1] == "0" else ""))
+    except Exception as e:      # statistics only
+        log(f"XCD-local statistics unavailable: {e}")
     log(f"selftest cases: {ran} run, {skipped} skipped")
     log("selftest " + ("PASSED" if bad == 0 else f"FAILED: {bad} bad rounds — train on this GPU with DVAE_LSTM_PERSISTENT=0 and report its unique_id"))
     return 0 if bad == 0 else 1

@@ -24,7 +24,7 @@ noise = [(torch.randn(B, 28, generator=gen), torch.randn(B, 28, generator=gen), 
 
 
 def run(load):
-    w = bench.build_trainer(dev, B, T, "fp32x3")
+    w = bench.build_trainer(dev, B, T, os.environ.get("STRESS_DTYPE", "fp32x3"))      # STRESS_DTYPE=bf16: the bf16 mode (its recurrences hand over inside one XCD, round 6)
     w.enable_graph(True)
     side = torch.cuda.Stream()
     a = torch.empty(1 << 28, device=dev, dtype=torch.float32)

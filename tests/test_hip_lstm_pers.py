@@ -8,6 +8,7 @@ One launch walks all T frames; workgroups hand h[t] / dG[t] to each other throug
   * the bounded spin: a workgroup that never publishes makes every waiter give up inside the timeout and
     dvae_lstm_pers_check report DVAE_ELAUNCH; the next launch on the same workspace is clean.
 (The bf16 oracle comparison of the same path is tests/test_hip_bf16.py::test_lstm_layer_bf16, which runs LstmLayerFn.)"""
+import os
 import time
 
 import pytest
@@ -408,6 +409,32 @@ def test_fp32x3_forward_gives_up_on_a_silent_producer(env, H, drop):
     for name, a, b in zip(("gates", "c", "h", "dgates"), got, ref):
         err = float((a - b).abs().max())
         assert err <= 2e-5 * float(b.abs().max()), f"{name} after a timed-out launch: {err:.3e}"
+
+
+def test_xcd_local_handoff_engages_only_where_row_groups_share_an_xcd(env):
+    """Round 6: with a multiple of 8 row groups the workgroups of a row group share bid % 8, hence (round-robin dispatch) an
+    XCD; they verify that at frame 1 and keep payload and flags in that XCD's L2.  The statistics word counts such launches:
+    it must move for N = 128 (8 row groups of 16 rows) and must NOT for N = 40 (3 row groups) — and the results are those of the
+    per-frame kernels either way (every other test of this file runs over the same workspace, local and write-through
+    launches alternating)."""
+    _lib, ops, _ = env
+    if os.environ.get("DVAE_PERS_XCD_LOCAL", "1")[:1] == "0":
+        pytest.skip("XCD-local hand-off switched off")
+    n0 = ops.lstm_pers_local_launches()
+    lay = Layer(env, 12, 40, 1024, True, seed=21)
+    ref = lay.run(pers=False)
+    compare(lay.run(pers=True), ref, "N = 40")
+    assert ops.lstm_pers_local_launches() == n0, "3 row groups cannot be XCD-local"
+    lay = Layer(env, 12, 128, 1024, True, seed=22)
+    ref = lay.run(pers=False)
+    compare(lay.run(pers=True), ref, "N = 128")
+    n1 = ops.lstm_pers_local_launches()
+    if n1 == n0:
+        pytest.skip("workgroups were not dealt round-robin over the XCDs here: the launches stayed write-through (results checked)")
+    assert n1 == n0 + 2                      # forward + backward
+    lay = Layer(env, 4, 128, 1024, True, seed=23)      # too short: frames 1 .. T-4 only
+    ref = lay.run(pers=False)
+    compare(lay.run(pers=True), ref, "T = 4")
 
 
 def test_workspace_size_contract(env):
