@@ -5,6 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rows = {}
 X3H_SINCE = "20261004T184000"      # calls from here on ran dec_lstm1's forward as lstm_pers_fwd_x3h (8 units x 32 rows)
 x3h_chips, x3h_calls = set(), 0
+loc_chips, loc_calls, loc_zero = set(), 0, 0      # calls whose selftest reported XCD-local hand-offs (pers_loc_*)
 for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "selftest", "*.log"))):
     t = open(f).read()
     m = re.search(r"unique_id\(s\): \[([^\]]*)\]", t)
@@ -16,6 +17,12 @@ for f in sorted(glob.glob(os.path.join(root, "gpurun_out", "selftest", "*.log"))
     r[0] += 1; r[1] += int(ok); r[2] += bad; r[3] = max(r[3], cases)
     if os.path.basename(f) >= X3H_SINCE:
         x3h_chips.add(uid); x3h_calls += 1
+    ml = re.search(r"XCD-local hand-offs[^:]*: (\d+) launches", t)
+    if ml:
+        if int(ml.group(1)) > 0:
+            loc_chips.add(uid); loc_calls += 1
+        else:
+            loc_zero += 1
 out = ["# Deployment selftest on the pool's chips (round 6)", "",
        "`python -m dvae_amd.selftest --rounds 40` at the start of every GPU call of the round (scripts/gpu_call.sh): every persistent",
        "LSTM kernel the product dispatches — fp32x3 H = 1024 / 512 at N = 128; bf16 H = 1024 at N = 256 / 128 and H = 512 at N = 128,",
@@ -27,6 +34,8 @@ for uid, (n, ok, bad, cases) in sorted(rows.items()):
 out += ["", f"{len(rows)} distinct chips, {sum(r[0] for r in rows.values())} calls, {sum(r[2] for r in rows.values())} bad rounds.",
         f"Of these, {x3h_calls} calls on {len(x3h_chips)} distinct chips ran the fp32x3 H = 512 forward case on `lstm_pers_fwd_x3h<512>` (8 units x 32 rows,",
         "the product's kernel from commit 1e951e0 on); the earlier ones on the 16-unit kernel.",
+        f"XCD-local hand-offs (bf16 forward / backward, fp32x3 H = 512 backward; DESIGN.md 4.2): {loc_calls} calls on {len(loc_chips)} distinct chips ran them",
+        f"(the selftest's statistics line showed local launches; {loc_zero} calls reported none: placement not round-robin there, write-through).",
         "(The first 19 calls of the round overwrote one shared log file: every one of them printed `selftest PASSED` — the tails",
         "are in the session's gpurun output — but their unique_ids were not kept.)"]
 open(os.path.join(root, "profiles", "selftest_chips.md"), "w").write("\n".join(out) + "\n")
