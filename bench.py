@@ -325,16 +325,23 @@ LSTM_KINDS = {0: "frame launches, forward", 1: "frame launches, backward", 2: "W
 LSTM_PM = {0: ("fp32", PEAK_F32_MFMA_TFLOPS), 1: ("bf16", PEAK_BF16_MFMA_TFLOPS), 2: ("fp32x3", PEAK_BF16_MFMA_TFLOPS / 6.0)}
 
 
+_XCD_LOCAL_PER_STEP = None
+
+
 def profile_families(w, x1, x2, spk, ops, prof_steps):
     """Eager steps with HIP events around every launch of one kernel family (the library's dvae_prof_* hooks): family 1
     the contraction kernels, family 2 the LSTM recurrence.  Returns (tags1, (ms, launches, flops)1, tags2, (...)2)."""
     out = []
     w.enable_graph(False)
+    global _XCD_LOCAL_PER_STEP
     for fam in (1, 2):
         ops.prof_enable(fam)
+        n_loc = ops.lstm_pers_local_launches() if fam == 2 else 0
         for _ in range(prof_steps):
             w.step(x1, x2, spk, train=True)
         torch.cuda.synchronize()
+        if fam == 2:      # persistent launches of these steps whose hand-offs stayed inside one XCD's L2 (DESIGN.md 4.2)
+            _XCD_LOCAL_PER_STEP = (ops.lstm_pers_local_launches() - n_loc) / prof_steps
         tags = ops.prof_collect_tags()
         tot = ops.prof_collect()
         ops.prof_enable(0)
@@ -368,6 +375,7 @@ def lstm_roofline(tags, tot, prof_steps):
             "l2_to_cu_peak_tb_per_s": list(L2_CU_TBPS), "l2_to_cu_frac": tbps / L2_CU_TBPS[0],
             "kernel_ms_per_step": ms / prof_steps, "calls_per_step": launches / prof_steps, "flops_per_step": flops / prof_steps,
             "instantiations": inst,
+            "xcd_local_launches_per_step": _XCD_LOCAL_PER_STEP,      # of the persistent launches: hand-offs kept in one XCD's L2
             "timed": f"HIP events around every recurrence call, {prof_steps} eager steps after the timed region"}
 
 
