@@ -187,6 +187,16 @@ class VariationalBaseModelVAE:
                 import torch.distributed as _dist
                 pg = _dist.is_available() and _dist.is_initialized()
                 mode = {"capture_error_mode": "thread_local"} if (self.reducer is not None or pg) else {}
+                if self.reducer is not None and pg:
+                    # c10d's watchdog thread polls the end events of the EAGER collectives of the warm-up steps every 100 ms
+                    # until it has seen them complete.  HIP refuses hipEventQuery on an event whose stream has meanwhile
+                    # entered a capture (hipErrorCapturedEvent — RCCL's stream joins this capture), the watchdog rethrows
+                    # and the process aborts: seen as a rare abort of the captured data-parallel step (2 of ~15 complete
+                    # test-suite runs, round 6).  The device is idle here (synchronize above): give the watchdog a few
+                    # periods to retire what it still holds.  (torch's own wait for pending event queries in
+                    # CUDAGraph.capture_begin covers global-mode captures only.)
+                    import time as _time
+                    _time.sleep(0.5)
                 try:
                     with torch.cuda.graph(g, **mode):
                         self._g_losses = self._eager_train_step(self._g_x1, self._g_x2)
